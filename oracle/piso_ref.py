@@ -280,15 +280,17 @@ def pressure_solve(setup, a0_t, div):
 
 
 # ------------------------------------------------------------------------------------------------ the step
-def piso_step(setup, vel_t, p, dt, dirichlet_values_t, forcing_t=None):
+def piso_step(setup, vel_t, p, dt, dirichlet_values_t, forcing_t=None, assembly_vel_t=None):
     """piso_step forward (diffpiso/piso_tf.py:11-81). vel_t staggered tensor, p [Ny,Nx].
-    Returns (vel_new_t, p_new, tape) -- tape holds what the reverse sweep needs plus every intermediate."""
+    Returns (vel_new_t, p_new, tape) -- tape holds what the reverse sweep needs plus every intermediate.
+    assembly_vel_t (tests only): assemble the matrices from this velocity instead of vel_t, which exposes the
+    frozen-coefficient map whose exact transpose the reference's adjoint is."""
     s = setup
     vel_t = np.asarray(vel_t, f32)
     p = np.asarray(p, f32)
     dxdy = float(np.prod(np.asarray(s.dx_yx, np.float64)))
     beta = dxdy / dt                                                               # :26
-    val, rp, col, A_t, A_flat = advection_matrix(s, vel_t, beta)                   # :29-33
+    val, rp, col, A_t, A_flat = advection_matrix(s, vel_t if assembly_vel_t is None else assembly_vel_t, beta)  # :29-33
     rhs_t = vel_t * f32(beta) - fv_gradient(p, s.p_ext, s.dx_yx, s.accessible)     # :36
     if forcing_t is not None:
         rhs_t = rhs_t + np.asarray(forcing_t, f32) * f32(dxdy)                     # :38

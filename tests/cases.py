@@ -1,0 +1,108 @@
+"""Shared synthetic set-ups for the parity tests (inputs only; no reference code).
+
+Each case mirrors a configuration of BASELINE.json / the reference's scripts at test size:
+  periodic      decaying turbulence, doubly periodic                       
+  xper_ywall    temporally evolving mixing layer: x periodic, y walls, v Dirichlet on the walls
+  cavity        lid-driven cavity incl. the solid lid row and no-slip mask   (lid_driven_cavity_2d.py:15-47)
+  spatial_ml    spatially evolving mixing layer: inflow/outflow in x, open y (combined_training_integrated.py:481-539)
+"""
+import numpy as np
+
+f32 = np.float32
+
+
+def _vel_from_stream(ny, nx, dy, dx, rng, periodic_yx, amp=1.0):
+    """Roughly solenoidal random velocity on faces (curl of a smooth random stream function on cell corners)."""
+    ky, kx = np.meshgrid(np.arange(ny + 1), np.arange(nx + 1), indexing="ij")
+    psi = np.zeros((ny + 1, nx + 1))
+    for _ in range(6):
+        a, b = rng.integers(1, 4, size=2)
+        ph = rng.uniform(0, 2 * np.pi, size=2)
+        psi += rng.standard_normal() * np.sin(2 * np.pi * a * ky / ny + ph[0]) * np.sin(2 * np.pi * b * kx / nx + ph[1])
+    u = (psi[1:, :] - psi[:-1, :]) / dy          # [ny, nx+1]
+    v = -(psi[:, 1:] - psi[:, :-1]) / dx         # [ny+1, nx]
+    s = amp / max(1e-12, np.sqrt(np.mean(u ** 2) + np.mean(v ** 2)))
+    t = np.zeros((1, ny + 1, nx + 1, 2), f32)
+    t[0, :, :nx, 0] = v * s
+    t[0, :ny, :, 1] = u * s
+    if periodic_yx[1]:
+        t[0, :ny, nx, 1] = t[0, :ny, 0, 1]
+    if periodic_yx[0]:
+        t[0, ny, :nx, 0] = t[0, 0, :nx, 0]
+    return t
+
+
+def make_case(name, ny, nx, seed=0, viscosity=1e-2, cfl=0.5, variable_viscosity=False):
+    """Returns a dict of plain numpy inputs understood by both the oracle (OracleSetup) and the product package."""
+    rng = np.random.default_rng(seed)
+    st = (1, ny + 1, nx + 1, 2)
+    ones = np.ones((1, ny + 2, nx + 2, 1), f32)
+    c = dict(name=name, ny=ny, nx=nx)
+    dmask = np.zeros(st, bool)
+    dvals = np.zeros(st, f32)
+    no_slip = None
+    if name == "periodic":
+        L = 2 * np.pi
+        c.update(periodic_yx=(True, True), p_ext=("periodic", "periodic"), boundaries="PERIODIC")
+        active, accessible = ones.copy(), ones.copy()
+        size = (L, L * nx / ny)
+    elif name == "xper_ywall":
+        c.update(periodic_yx=(False, True), p_ext=(("constant", "constant"), "periodic"), boundaries="(CLOSED, PERIODIC)")
+        active, accessible = ones.copy(), ones.copy()
+        active[0, 0], active[0, -1], accessible[0, 0], accessible[0, -1] = 0, 0, 0, 0
+        dmask[0, 0, :nx, 0] = True
+        dmask[0, ny, :nx, 0] = True
+        size = (1.0 * ny, 1.0 * nx)
+    elif name == "cavity":
+        c.update(periodic_yx=(False, False), p_ext=(("boundary", "boundary"), ("boundary", "boundary")), boundaries="OPEN")
+        active = np.pad(np.ones((1, ny, nx, 1), f32), ((0, 0), (1, 1), (1, 1), (0, 0)))
+        active[0, -2] = 0
+        accessible = active.copy()
+        dmask[0, 0, :nx, 0] = True
+        dmask[0, -2:, :nx, 0] = True
+        dmask[0, :ny, 0, 1] = True
+        dmask[0, :ny, nx, 1] = True
+        dmask[0, ny - 1, :, 1] = True
+        dvals[0, ny - 1, :, 1] = 1.0
+        ns = np.zeros((ny + 2, nx + 2), bool)
+        ns[0, :], ns[-2:, :], ns[:, 0], ns[:, -1] = True, True, True, True
+        no_slip = ns.ravel()
+        size = (1.0 + 1.0 / (ny - 1), 1.0 * nx / (ny - 1))
+    elif name == "spatial_ml":
+        c.update(periodic_yx=(False, False), p_ext=(("boundary", "boundary"), ("boundary", "constant")),
+                 boundaries="((OPEN, OPEN), (OPEN, CLOSED))")
+        active = np.pad(np.ones((1, ny, nx, 1), f32), ((0, 0), (1, 1), (1, 1), (0, 0)))
+        accessible = ones.copy()
+        accessible[0, :, 0], accessible[0, 0, :], accessible[0, -1, :] = 0, 0, 0
+        dmask[0, 0, :nx, 0] = True
+        dmask[0, ny, :nx, 0] = True
+        dmask[0, :ny, 0, 1] = True
+        prof = 0.5 * np.tanh(2.0 * (np.linspace(0, ny, ny + 2)[1:-1] - ny / 2) / (ny / 8)) + 1.0
+        dvals[0, :ny, 0, 1] = prof
+        no_slip = np.zeros((ny + 2) * (nx + 2), bool)
+        size = (1.0 * ny, 1.0 * nx)
+    else:
+        raise ValueError(name)
+    dy, dx = size[0] / ny, size[1] / nx
+    vel = _vel_from_stream(ny, nx, dy, dx, rng, c["periodic_yx"])
+    if name == "spatial_ml":
+        vel[0, :ny, :, 1] += dvals[0, :ny, 0:1, 1]
+    if name == "cavity":
+        vel[...] *= 0.3
+    vel = np.where(dmask, dvals, vel).astype(f32)
+    umax = float(np.abs(vel).max())
+    dt = cfl * min(dx, dy) / max(umax, 1e-6)
+    visc = viscosity
+    if variable_viscosity:
+        n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
+        visc = (viscosity * (1.0 + rng.random(n_u + n_v))).astype(f32)
+    p = (0.1 * rng.standard_normal((ny, nx))).astype(f32)
+    c.update(dx_yx=(dy, dx), vel=vel, p=p, dt=dt, dirichlet_mask=dmask, dirichlet_values=dvals, active=active,
+             accessible=accessible, no_slip=no_slip, viscosity=visc)
+    return c
+
+
+def oracle_setup(c, **kw):
+    from oracle.piso_ref import OracleSetup
+    return OracleSetup(c["nx"], c["ny"], c["dx_yx"], c["periodic_yx"], c["dirichlet_mask"], c["active"], c["accessible"],
+                       no_slip=c["no_slip"], p_extrapolation=c["p_ext"], viscosity=c["viscosity"], **kw)
