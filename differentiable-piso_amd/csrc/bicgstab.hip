@@ -1,0 +1,779 @@
+// ILU(0)-preconditioned BiCGStab for the two advection-diffusion matrices (u and v) of the PISO predictor on MI355X.
+//
+// Replaces MultiBicgstabIluLinearSolveLauncher / BicgstabIluLinearSolveLauncher[Double]
+// (CUDAsrc/multi_bicgstab_ilu_linear_solve_op.cu.cc:85-531, :540-988) and the cuSPARSE / cuBLAS calls inside them
+// (csr2csc, csrilu02, csrsv2 x4 per iteration, csrmv x2, dot/nrm2/axpy/scal with a host sync each).
+//
+// MI355X design (DESIGN.md "BiCGStab"):
+//  * both components advance in the SAME launches (blockIdx.y = component) instead of two host threads + two streams;
+//  * the CSR input is converted once per solve into a structured "stencil" layout (5 SoA coefficient arrays for the
+//    geometric neighbours k-W, k-1, k, k+1, k+W; the few periodic-wrap entries go to a small per-frame-row exception
+//    table).  The adjoint (transpose_op) is obtained by gathering the transposed coefficients during that conversion --
+//    the role of cusparse?csr2csc;
+//  * the preconditioner is a structured block ILU(0): ILU(0) of the near-neighbour part of the matrix restricted to bands
+//    of `band_rows` face rows (band_rows < 0: one band = global ILU(0) of the near-neighbour part).  For this triangle-free
+//    pattern ILU(0) only modifies the diagonal: d_k = a_kk - a_kW a_Wk / d_W - a_kS a_Sk / d_S.  Inside a band rows are
+//    processed top to bottom; along a row the recurrences are solved by parallel scans across the block
+//    (Moebius-map scan for the pivots, affine-map scan for the triangular sweeps), carries staged through LDS.
+//    Every band is one workgroup: no inter-workgroup dependency, no level schedule;
+//  * Krylov scalars live on the device; dot products are per-block partials reduced by 1-block "scalar" kernels.
+// The iteration itself (order of updates, absolute ||r||_2 test after each half step, zero + one restart on failure,
+// NaN -> warning) is the reference's.
+#include "piso_common.h"
+
+namespace piso {
+
+constexpr int kBiParts = 512;     // max blocks per component of a partial-producing kernel
+constexpr int kExcSlots = 4;      // exception (wrap) entries per frame row
+
+struct Geo {
+  int nx, ny;
+  int W[2], H[2], n[2], r0[2];    // face-array dims, rows, row offset of each component in the concatenated vectors
+  int xw[2], yw[2];               // periodic wrap distances in x / y (skip the duplicate face in the own direction)
+  int F[2], f0[2];                // frame rows (within 2 of a border) and their offset in the exception tables
+  int R, nb[2];                   // band height (face rows) and number of bands
+};
+
+__host__ __device__ inline int frame_rows(int W, int H) {
+  const int wi = W > 4 ? W - 4 : 0, hi = H > 4 ? H - 4 : 0;
+  return W * H - wi * hi;
+}
+// ordinal of a frame row, -1 for interior rows
+__device__ __forceinline__ int frame_ordinal(int i, int j, int W, int H) {
+  if (H <= 4 || W <= 4) return j * W + i;
+  if (j < 2) return j * W + i;
+  if (j >= H - 2) return 2 * W + (j - (H - 2)) * W + i;
+  if (i < 2) return 4 * W + (j - 2) * 4 + i;
+  if (i >= W - 2) return 4 * W + (j - 2) * 4 + 2 + (i - (W - 2));
+  return -1;
+}
+
+template <typename T>
+struct CompScalars {
+  T rho, rho_prev, alpha, omega, beta, nrm;
+  int done;        // 1: converged (||r|| < tol) -- no more work in this pass
+  int it_count;
+  int failed;      // set by the host-side restart logic
+  int pad;
+};
+
+template <typename T>
+struct BiArgs {
+  Geo g;
+  // matrix B (= A or A^T) in stencil form, concatenated components
+  T *cS, *cW, *cC, *cE, *cN;
+  int* ecol;
+  T* eval;
+  // preconditioner
+  T *dinv, *LW, *LS, *UE, *UN;
+  // vectors
+  const T* rhs;
+  T *x, *r, *rh, *p, *v, *t, *y, *ph, *sh;
+  T* parts;                       // [2 comps][4 quantities][kBiParts]
+  CompScalars<T>* sc;             // [2]
+  int* flags;                     // [0]: unsupported pattern, [1]: NaN seen
+  float tol;
+};
+
+__device__ __forceinline__ bool is_nan(float v) { return v != v; }
+__device__ __forceinline__ bool is_nan(double v) { return v != v; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// CSR -> stencil conversion (with optional transpose) + exception table + NaN scan of values, rhs, x0
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ bool csr_find(const int* __restrict__ rp, const int* __restrict__ col,
+                                         const T* __restrict__ val, int m, int k, T* out) {
+  for (int q = rp[m]; q < rp[m + 1]; ++q)
+    if (col[q] == k) { *out = val[q]; return true; }
+  return false;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __restrict__ val_all,
+                                                     const int* __restrict__ rp_all, const int* __restrict__ col_all,
+                                                     const T* __restrict__ x0, int transpose) {
+  const int c = blockIdx.y;
+  const Geo& g = a.g;
+  const int W = g.W[c], H = g.H[c], n = g.n[c], r0 = g.r0[c];
+  const int* rp = rp_all + (c ? g.n[0] + 1 : 0);
+  // the nnz offset of component 1 is the last row pointer of component 0
+  const int k0 = c ? rp_all[g.n[0]] : 0;
+  const T* val = val_all + k0;
+  const int* col = col_all + k0;
+  bool nan_seen = false, bad = false;
+  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+    const int i = row % W, j = row / W;
+    const int fo = frame_ordinal(i, j, W, H);
+    T s = 0, w = 0, cc = 0, e = 0, nn = 0;
+    int ne = 0;
+    int ec[kExcSlots];
+    T ev[kExcSlots];
+    // classify the entries of A's own row (also validates the pattern in transpose mode)
+    for (int q = rp[row]; q < rp[row + 1]; ++q) {
+      const int cq = col[q];
+      const T vq = val[q];
+      nan_seen |= is_nan(vq);
+      int kind;   // 0..4 near slots, 5 exception
+      if (cq == row) kind = 2;
+      else if (cq == row - 1 && i >= 1) kind = 1;
+      else if (cq == row + 1 && i <= W - 2) kind = 3;
+      else if (cq == row - W) kind = 0;
+      else if (cq == row + W) kind = 4;
+      else kind = 5;
+      if (kind == 5) {
+        const int d = cq - row;
+        const bool wrap = (d == g.xw[c] || d == -g.xw[c] || d == g.yw[c] || d == -g.yw[c]);
+        if (!wrap || fo < 0) bad = true;
+      }
+      if (!transpose) {
+        if (kind == 0) s = vq; else if (kind == 1) w = vq; else if (kind == 2) cc = vq;
+        else if (kind == 3) e = vq; else if (kind == 4) nn = vq;
+        else if (ne < kExcSlots) { ec[ne] = cq; ev[ne] = vq; ++ne; }
+        else bad = true;
+      } else if (kind == 2) cc = vq;
+    }
+    if (transpose) {
+      T vq;
+      if (i >= 1 && csr_find(rp, col, val, row - 1, row, &vq)) w = vq;            // A(k-1, k)
+      if (i <= W - 2 && csr_find(rp, col, val, row + 1, row, &vq)) e = vq;        // A(k+1, k)
+      if (j >= 1 && csr_find(rp, col, val, row - W, row, &vq)) s = vq;            // A(k-W, k)
+      if (j <= H - 2 && csr_find(rp, col, val, row + W, row, &vq)) nn = vq;       // A(k+W, k)
+      if (fo >= 0) {
+        const int cand[4] = {row - g.xw[c], row + g.xw[c], row - g.yw[c], row + g.yw[c]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = cand[q];
+          if (m < 0 || m >= n || m == row - 1 || m == row + 1 || m == row - W || m == row + W || m == row) continue;
+          if (csr_find(rp, col, val, m, row, &vq)) {
+            if (ne < kExcSlots) { ec[ne] = m; ev[ne] = vq; ++ne; } else bad = true;
+          }
+        }
+      }
+    }
+    const int k = r0 + row;
+    a.cS[k] = s; a.cW[k] = w; a.cC[k] = cc; a.cE[k] = e; a.cN[k] = nn;
+    if (fo >= 0) {
+      const int base = (g.f0[c] + fo) * kExcSlots;
+      for (int q = 0; q < kExcSlots; ++q) {
+        a.ecol[base + q] = q < ne ? ec[q] : -1;
+        a.eval[base + q] = q < ne ? ev[q] : (T)0;
+      }
+    }
+    nan_seen |= is_nan(a.rhs[k]) | is_nan(x0[k]);
+    a.x[k] = x0[k];                                                     // cublas copy x_old -> x (:261)
+  }
+  if (bad) a.flags[0] = 1;
+  if (nan_seen) a.flags[1] = 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// block-wide exclusive scan of a monoid over kBlock threads (thread order = element order)
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct Affine {   // y -> m y + c
+  T m, c;
+  static __device__ __forceinline__ Affine identity() { return {(T)1, (T)0}; }
+  // apply `first`, then `second`
+  static __device__ __forceinline__ Affine then(const Affine& first, const Affine& second) {
+    return {second.m * first.m, fma(second.m, first.c, second.c)};
+  }
+  __device__ __forceinline__ Affine shfl_up(int off) const { return {__shfl_up(m, off, kWave), __shfl_up(c, off, kWave)}; }
+};
+
+template <typename T>
+struct Moebius {  // x -> (a x + b) / (c x + d), kept normalised
+  T a, b, c, d;
+  static __device__ __forceinline__ Moebius identity() { return {(T)1, (T)0, (T)0, (T)1}; }
+  static __device__ __forceinline__ Moebius then(const Moebius& f, const Moebius& s) {   // matrix(s) * matrix(f)
+    Moebius o = {fma(s.a, f.a, s.b * f.c), fma(s.a, f.b, s.b * f.d), fma(s.c, f.a, s.d * f.c), fma(s.c, f.b, s.d * f.d)};
+    T mx = fmax(fmax(fabs(o.a), fabs(o.b)), fmax(fabs(o.c), fabs(o.d)));
+    if (mx > 0 && mx == mx && mx < (T)1e30) { const T inv = (T)1 / mx; o.a *= inv; o.b *= inv; o.c *= inv; o.d *= inv; }
+    return o;
+  }
+  __device__ __forceinline__ Moebius shfl_up(int off) const {
+    return {__shfl_up(a, off, kWave), __shfl_up(b, off, kWave), __shfl_up(c, off, kWave), __shfl_up(d, off, kWave)};
+  }
+};
+
+// Exclusive scan: returns the composition of the values of all threads BEFORE this one (identity for thread 0).
+// smem: 4 values of M.  Two __syncthreads.
+template <typename M>
+__device__ __forceinline__ M block_exclusive_scan(M v, M* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const M o = v.shfl_up(off);
+    if (lane >= off) v = M::then(o, v);
+  }
+  __syncthreads();
+  if (lane == 63) smem[wave] = v;
+  __syncthreads();
+  M prefix = M::identity();
+  for (int w = 0; w < wave; ++w) prefix = M::then(prefix, smem[w]);
+  M excl = v.shfl_up(1);
+  if (lane == 0) excl = M::identity();
+  return M::then(prefix, excl);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// structured block ILU(0): pivots d (stored as 1/d) and the sweep coefficient arrays, one workgroup per band
+//   d(i,j) = cC - cW(i,j) cE(i-1,j) / d(i-1,j) - [j > band start] cS(i,j) cN(i,j-1) / d(i,j-1)
+//   LW = cW(k)/d(k-1), LS = cS(k)/d(k-W), UE = cE(k)/d(k), UN = cN(k)/d(k) (LS / UN zero across band edges)
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int E>
+__global__ __launch_bounds__(kBlock) void bi_factor(BiArgs<T> a) {
+  __shared__ Moebius<T> smem[4];
+  const int c = blockIdx.y;
+  const Geo& g = a.g;
+  if (blockIdx.x >= g.nb[c]) return;
+  const int W = g.W[c], H = g.H[c], r0 = g.r0[c];
+  const int j0 = blockIdx.x * g.R, j1 = min(j0 + g.R, H);
+  const int i0 = threadIdx.x * E;
+  T d_prev_row[E];          // pivots of the previous row at my columns
+  T cN_prev_row[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { d_prev_row[e] = 1; cN_prev_row[e] = 0; }
+  for (int j = j0; j < j1; ++j) {
+    const int kb = r0 + j * W;
+    T A[E], B[E], cw[E], cs[E], ce[E], cn[E];
+    Moebius<T> f = Moebius<T>::identity();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = i0 + e;
+      A[e] = 1; B[e] = 0; cw[e] = cs[e] = ce[e] = cn[e] = 0;
+      if (i < W) {
+        const int k = kb + i;
+        cw[e] = a.cW[k]; cs[e] = a.cS[k]; ce[e] = a.cE[k]; cn[e] = a.cN[k];
+        const T ce_left = (i >= 1) ? a.cE[k - 1] : (T)0;
+        A[e] = a.cC[k] - ((j > j0) ? cs[e] * cN_prev_row[e] / d_prev_row[e] : (T)0);
+        B[e] = cw[e] * ce_left;
+        const Moebius<T> fi = {A[e], -B[e], (T)1, (T)0};
+        f = Moebius<T>::then(f, fi);
+      }
+    }
+    const Moebius<T> pre = block_exclusive_scan(f, smem);
+    // pivot just left of my chunk: pre(infinity) = a / c  (thread 0: unused because B == 0 at i == 0)
+    T dl = (threadIdx.x == 0 || pre.c == 0) ? (T)1 : pre.a / pre.c;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = i0 + e;
+      if (i < W) {
+        const int k = kb + i;
+        const T d = A[e] - B[e] / dl;
+        const T inv = (T)1 / d;
+        a.dinv[k] = inv;
+        a.LW[k] = (i >= 1) ? cw[e] / dl : (T)0;
+        a.LS[k] = (j > j0) ? cs[e] / d_prev_row[e] : (T)0;
+        a.UE[k] = ce[e] * inv;
+        a.UN[k] = (j < j1 - 1) ? cn[e] * inv : (T)0;
+        dl = d;
+        d_prev_row[e] = d;
+        cN_prev_row[e] = cn[e];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// triangular sweeps inside a band, one workgroup per band, rows sequential, x-recurrence by an affine block scan
+//   forward  (L y = in):            y(k) = in(k)         - LW(k) y(k-1) - LS(k) y(k-W)
+//   backward (U z = y):             z(k) = y(k) dinv(k)  - UE(k) z(k+1) - UN(k) z(k+W)
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int E, bool FWD>
+__global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restrict__ in, T* __restrict__ out) {
+  __shared__ Affine<T> smem[4];
+  const int c = blockIdx.y;
+  const Geo& g = a.g;
+  if (a.sc[c].done) return;
+  if (blockIdx.x >= g.nb[c]) return;
+  const int W = g.W[c], H = g.H[c], r0 = g.r0[c];
+  const int j0 = blockIdx.x * g.R, j1 = min(j0 + g.R, H);
+  const T* __restrict__ ca = FWD ? a.LW : a.UE;
+  const T* __restrict__ cb = FWD ? a.LS : a.UN;
+  // element order along the scan: forward i ascending, backward i descending
+  const int i0 = threadIdx.x * E;
+  T prev[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) prev[e] = 0;
+  for (int jj = 0; jj < j1 - j0; ++jj) {
+    const int j = FWD ? j0 + jj : j1 - 1 - jj;
+    const int kb = r0 + j * W;
+    T m[E], cst[E];
+    Affine<T> f = Affine<T>::identity();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int s = i0 + e;                       // position along the scan
+      const int i = FWD ? s : W - 1 - s;
+      m[e] = 0; cst[e] = 0;
+      if (s < W) {
+        const int k = kb + i;
+        T v = in[k];
+        if (!FWD) v *= a.dinv[k];
+        cst[e] = v - cb[k] * prev[e];
+        m[e] = -ca[k];
+        f = Affine<T>::then(f, Affine<T>{m[e], cst[e]});
+      }
+    }
+    const Affine<T> pre = block_exclusive_scan(f, smem);
+    T yl = pre.c;                                 // value just before my chunk (pre applied to 0; first m is 0 anyway)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int s = i0 + e;
+      const int i = FWD ? s : W - 1 - s;
+      if (s < W) {
+        const T y = fma(m[e], yl, cst[e]);
+        out[kb + i] = y;
+        prev[e] = y;
+        yl = y;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// vector kernels (blockIdx.y = component); partial sums to parts[c][q][blockIdx.x]
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void store_partials(BiArgs<T>& a, int c, T* vals, int count, T* smem) {
+  // vals[0..count) already thread-local sums
+  T tmp[4] = {0, 0, 0, 0};
+  for (int q = 0; q < count; ++q) tmp[q] = vals[q];
+  block_sum<T, 4>(tmp, smem);
+  if (threadIdx.x == 0)
+    for (int q = 0; q < count; ++q) a.parts[(c * 4 + q) * kBiParts + blockIdx.x] = tmp[q];
+}
+
+// y = B x for one row (near stencil + exceptions)
+template <typename T>
+__device__ __forceinline__ T stencil_row(const BiArgs<T>& a, int c, int row, const T* __restrict__ x) {
+  const Geo& g = a.g;
+  const int W = g.W[c], H = g.H[c], r0 = g.r0[c];
+  const int i = row % W, j = row / W, k = r0 + row;
+  T acc = 0;
+  if (j >= 1) acc = fma(a.cS[k], x[k - W], acc);
+  if (i >= 1) acc = fma(a.cW[k], x[k - 1], acc);
+  acc = fma(a.cC[k], x[k], acc);
+  if (i <= W - 2) acc = fma(a.cE[k], x[k + 1], acc);
+  if (j <= H - 2) acc = fma(a.cN[k], x[k + W], acc);
+  const int fo = frame_ordinal(i, j, W, H);
+  if (fo >= 0) {
+    const int base = (g.f0[c] + fo) * kExcSlots;
+#pragma unroll
+    for (int q = 0; q < kExcSlots; ++q) {
+      const int ec = a.ecol[base + q];
+      if (ec >= 0) acc = fma(a.eval[base + q], x[r0 + ec], acc);
+    }
+  }
+  return acc;
+}
+
+// r = rhs - B x ; rh = r ; p = v = 0 ; partial ||r||^2   (:266-300)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bi_residual_init(BiArgs<T> a) {
+  __shared__ T smem[16];
+  const int c = blockIdx.y;
+  if (a.sc[c].done) return;
+  const int n = a.g.n[c], r0 = a.g.r0[c];
+  T acc[1] = {0};
+  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+    const int k = r0 + row;
+    const T r = a.rhs[k] - stencil_row(a, c, row, a.x);
+    a.r[k] = r; a.rh[k] = r; a.p[k] = 0; a.v[k] = 0;
+    acc[0] = fma(r, r, acc[0]);
+  }
+  store_partials(a, c, acc, 1, smem);
+}
+
+// p = r + beta (p - omega v)   (:316-318)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bi_update_p(BiArgs<T> a) {
+  const int c = blockIdx.y;
+  const CompScalars<T> s = a.sc[c];
+  if (s.done) return;
+  const int n = a.g.n[c], r0 = a.g.r0[c];
+  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+    const int k = r0 + row;
+    a.p[k] = (a.p[k] - s.omega * a.v[k]) * s.beta + a.r[k];
+  }
+}
+
+// out = B in ; partials: WHICH 0: rh.out (v = B p_hat)   1: out.r, out.out (t = B s_hat)
+template <typename T, int WHICH>
+__global__ __launch_bounds__(kBlock) void bi_spmv(BiArgs<T> a, const T* __restrict__ in, T* __restrict__ out) {
+  __shared__ T smem[16];
+  const int c = blockIdx.y;
+  if (a.sc[c].done) return;
+  const int n = a.g.n[c], r0 = a.g.r0[c];
+  T acc[2] = {0, 0};
+  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+    const int k = r0 + row;
+    const T o = stencil_row(a, c, row, in);
+    out[k] = o;
+    if (WHICH == 0) acc[0] = fma(a.rh[k], o, acc[0]);
+    else { acc[0] = fma(o, a.r[k], acc[0]); acc[1] = fma(o, o, acc[1]); }
+  }
+  store_partials(a, c, acc, WHICH == 0 ? 1 : 2, smem);
+}
+
+// x += coef * dir ; r -= coef * w ; partials ||r||^2, rh.r     (WHICH 0: alpha, p_hat, v ; 1: omega, s_hat, t)
+template <typename T, int WHICH>
+__global__ __launch_bounds__(kBlock) void bi_update_xr(BiArgs<T> a) {
+  __shared__ T smem[16];
+  const int c = blockIdx.y;
+  const CompScalars<T> s = a.sc[c];
+  if (s.done) return;
+  const int n = a.g.n[c], r0 = a.g.r0[c];
+  const T coef = WHICH == 0 ? s.alpha : s.omega;
+  const T* __restrict__ dir = WHICH == 0 ? a.ph : a.sh;
+  const T* __restrict__ w = WHICH == 0 ? a.v : a.t;
+  T acc[2] = {0, 0};
+  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+    const int k = r0 + row;
+    a.x[k] = a.x[k] + coef * dir[k];
+    const T r = a.r[k] - coef * w[k];
+    a.r[k] = r;
+    acc[0] = fma(r, r, acc[0]);
+    acc[1] = fma(a.rh[k], r, acc[1]);
+  }
+  store_partials(a, c, acc, 2, smem);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bi_zero_x(BiArgs<T> a, int comp_mask) {
+  const int c = blockIdx.y;
+  if (!((comp_mask >> c) & 1)) return;
+  const int n = a.g.n[c], r0 = a.g.r0[c];
+  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) a.x[r0 + row] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// scalar kernels: one block per component reduces the partials of the previous vector kernel and advances the recurrences
+// ------------------------------------------------------------------------------------------------------------------
+enum { ST_INIT = 0, ST_RHO_BETA = 1, ST_ALPHA = 2, ST_CHECK_S = 3, ST_OMEGA = 4, ST_CHECK_R = 5 };
+
+template <typename T>
+__device__ __forceinline__ T sqrt_t(T v);
+template <>
+__device__ __forceinline__ float sqrt_t<float>(float v) { return sqrtf(v); }
+template <>
+__device__ __forceinline__ double sqrt_t<double>(double v) { return sqrt(v); }
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bi_scalar(BiArgs<T> a, int stage) {
+  __shared__ T smem[16];
+  const int c = blockIdx.x;
+  CompScalars<T> s = a.sc[c];
+  if (s.done) return;
+  T q[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    T v = 0;
+    for (int b = threadIdx.x; b < kBiParts; b += kBlock) v += a.parts[(c * 4 + k) * kBiParts + b];
+    q[k] = v;
+  }
+  block_sum<T, 4>(q, smem);
+  if (threadIdx.x != 0) return;
+  const T tol = (T)a.tol;
+  switch (stage) {
+    case ST_INIT:                       // ||r0|| "lucky guess" test (:288-292); rho for the first iteration is rh.r = ||r||^2
+      s.nrm = sqrt_t<T>(q[0]);
+      if (s.nrm < tol) s.done = 1;
+      s.rho_prev = s.rho;               // rho / alpha / omega are NOT reset on a restart (as coded)
+      s.rho = q[0];
+      s.beta = (s.rho / s.rho_prev) * (s.alpha / s.omega);
+      break;
+    case ST_RHO_BETA:                   // start of an iteration after the first: rho = rh.r (:309-312)
+      s.rho_prev = s.rho;
+      s.rho = q[1];
+      s.beta = (s.rho / s.rho_prev) * (s.alpha / s.omega);
+      break;
+    case ST_ALPHA:                      // alpha = rho / rh.v (:336-338)
+      s.alpha = s.rho / q[0];
+      s.it_count += 1;                  // one ST_ALPHA per started iteration (it_count++, :306)
+      break;
+    case ST_CHECK_S:                    // ||s|| test (:347-351)
+      s.nrm = sqrt_t<T>(q[0]);
+      if (s.nrm < tol) s.done = 1;
+      break;
+    case ST_OMEGA:                      // omega = t.r / t.t (:372-374)
+      s.omega = q[0] / q[1];
+      break;
+    case ST_CHECK_R:                    // ||r|| test (:386-390)
+      s.nrm = sqrt_t<T>(q[0]);
+      if (s.nrm < tol) s.done = 1;
+      break;
+  }
+  a.sc[c] = s;
+}
+
+template <typename T>
+__global__ void bi_init_scalars(BiArgs<T> a) {
+  if (threadIdx.x < 2) {
+    CompScalars<T> s;
+    s.rho = 1; s.rho_prev = 1; s.alpha = 1; s.omega = 1; s.beta = 0; s.nrm = 0;
+    s.done = 0; s.it_count = 0; s.failed = 0; s.pad = 0;
+    a.sc[threadIdx.x] = s;
+  }
+  for (int i = threadIdx.x; i < 2 * 4 * kBiParts; i += blockDim.x) a.parts[i] = 0;
+  if (threadIdx.x == 0) { a.flags[0] = 0; a.flags[1] = 0; }
+}
+
+template <typename T>
+__global__ void bi_set_done(BiArgs<T> a, int done0, int done1) {
+  if (threadIdx.x == 0) { a.sc[0].done = done0; a.sc[1].done = done1; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host driver
+// ------------------------------------------------------------------------------------------------------------------
+static Geo make_geo(int nx, int ny, int band_rows) {
+  Geo g;
+  g.nx = nx; g.ny = ny;
+  g.W[0] = nx + 1; g.H[0] = ny; g.W[1] = nx; g.H[1] = ny + 1;
+  for (int c = 0; c < 2; ++c) {
+    g.n[c] = g.W[c] * g.H[c];
+    g.xw[c] = g.W[c] - 1 - (c == 0);
+    g.yw[c] = g.W[c] * (g.H[c] - 1 - (c == 1));
+    g.F[c] = frame_rows(g.W[c], g.H[c]);
+  }
+  g.r0[0] = 0; g.r0[1] = g.n[0];
+  g.f0[0] = 0; g.f0[1] = g.F[0];
+  int R = band_rows;
+  if (R < 0) R = (ny + 1);                                   // one band: global structured ILU(0)
+  if (R == 0) { R = ny / 128; if (R < 8) R = 8; if (R > 32) R = 32; }   // automatic
+  if (R > ny + 1) R = ny + 1;
+  g.R = R;
+  for (int c = 0; c < 2; ++c) g.nb[c] = (g.H[c] + R - 1) / R;
+  return g;
+}
+
+template <typename T>
+static size_t bi_workspace_bytes(int nx, int ny) {
+  const Geo g = make_geo(nx, ny, 8);
+  const size_t ntot = (size_t)g.n[0] + g.n[1];
+  size_t b = 0;
+  b += 18 * align_up(ntot * sizeof(T), 256);
+  b += align_up((size_t)(g.F[0] + g.F[1]) * kExcSlots * sizeof(int), 256);
+  b += align_up((size_t)(g.F[0] + g.F[1]) * kExcSlots * sizeof(T), 256);
+  b += align_up(2 * 4 * kBiParts * sizeof(T), 256) + align_up(2 * sizeof(CompScalars<T>), 256) + 256;
+  return b + 8192;
+}
+
+template <typename T>
+struct BiHost {
+  CompScalars<T> sc[2];
+  int flags[2];
+};
+
+template <typename T, int E>
+static void launch_factor(const BiArgs<T>& a, dim3 gb, hipStream_t s) { bi_factor<T, E><<<gb, kBlock, 0, s>>>(a); }
+template <typename T, int E>
+static void launch_sweeps(const BiArgs<T>& a, dim3 gb, const T* in, T* out, hipStream_t s) {
+  bi_sweep<T, E, true><<<gb, kBlock, 0, s>>>(a, in, a.y);
+  bi_sweep<T, E, false><<<gb, kBlock, 0, s>>>(a, a.y, out);
+}
+
+template <typename T>
+static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rhs, const T* x0, T* x_out, int nx,
+                    int ny, float tol, int max_it, int transpose, int band_rows, uint8_t* warning,
+                    int* iterations_out, void* ws, size_t ws_bytes, piso_stream_t stream_) {
+  if (nx < 4 || ny < 4 || !val || !rowptr || !col || !rhs || !x0 || !x_out || !ws || max_it < 0) {
+    set_error_msg("piso_multi_bicgstab_ilu: invalid argument (need nx, ny >= 4 and non-NULL arrays)");
+    return PISO_ERR_INVALID_ARG;
+  }
+  if (ws_bytes < bi_workspace_bytes<T>(nx, ny)) {
+    set_error_msg("piso_multi_bicgstab_ilu: workspace too small");
+    return PISO_ERR_INVALID_ARG;
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  BiArgs<T> a;
+  a.g = make_geo(nx, ny, band_rows);
+  const Geo& g = a.g;
+  const size_t ntot = (size_t)g.n[0] + g.n[1];
+  Arena ar(ws, ws_bytes);
+  a.cS = ar.take<T>(ntot); a.cW = ar.take<T>(ntot); a.cC = ar.take<T>(ntot); a.cE = ar.take<T>(ntot); a.cN = ar.take<T>(ntot);
+  a.dinv = ar.take<T>(ntot); a.LW = ar.take<T>(ntot); a.LS = ar.take<T>(ntot); a.UE = ar.take<T>(ntot); a.UN = ar.take<T>(ntot);
+  a.r = ar.take<T>(ntot); a.rh = ar.take<T>(ntot); a.p = ar.take<T>(ntot); a.v = ar.take<T>(ntot); a.t = ar.take<T>(ntot);
+  a.y = ar.take<T>(ntot); a.ph = ar.take<T>(ntot); a.sh = ar.take<T>(ntot);
+  a.ecol = ar.take<int>((size_t)(g.F[0] + g.F[1]) * kExcSlots);
+  a.eval = ar.take<T>((size_t)(g.F[0] + g.F[1]) * kExcSlots);
+  a.parts = ar.take<T>(2 * 4 * kBiParts);
+  a.sc = ar.take<CompScalars<T>>(2);
+  a.flags = ar.take<int>(2);
+  a.rhs = rhs; a.x = x_out; a.tol = tol;
+  if (!ar.ok()) { set_error_msg("piso_multi_bicgstab_ilu: workspace too small"); return PISO_ERR_INVALID_ARG; }
+
+  const int nmax = g.n[0] > g.n[1] ? g.n[0] : g.n[1];
+  int gv = (nmax + kBlock * 4 - 1) / (kBlock * 4);
+  if (gv > kBiParts) gv = kBiParts;
+  if (gv < 1) gv = 1;
+  const dim3 grid_v(gv, 2);
+  const int nbmax = g.nb[0] > g.nb[1] ? g.nb[0] : g.nb[1];
+  const dim3 grid_b(nbmax, 2);
+  const int Wmax = nx + 1;
+  const int need = (Wmax + kBlock - 1) / kBlock;
+  if (need > 32) { set_error_msg("piso_multi_bicgstab_ilu: nx > 8191 not supported"); return PISO_ERR_INVALID_ARG; }
+
+  bi_init_scalars<T><<<1, 256, 0, stream>>>(a);
+  bi_convert<T><<<grid_v, kBlock, 0, stream>>>(a, val, rowptr, col, x0, transpose ? 1 : 0);
+  if (need <= 1) launch_factor<T, 1>(a, grid_b, stream);
+  else if (need <= 2) launch_factor<T, 2>(a, grid_b, stream);
+  else if (need <= 4) launch_factor<T, 4>(a, grid_b, stream);
+  else if (need <= 8) launch_factor<T, 8>(a, grid_b, stream);
+  else if (need <= 16) launch_factor<T, 16>(a, grid_b, stream);
+  else launch_factor<T, 32>(a, grid_b, stream);
+  PISO_LAUNCH_CHECK();
+
+  auto precond = [&](const T* in, T* out) {
+    if (need <= 1) launch_sweeps<T, 1>(a, grid_b, in, out, stream);
+    else if (need <= 2) launch_sweeps<T, 2>(a, grid_b, in, out, stream);
+    else if (need <= 4) launch_sweeps<T, 4>(a, grid_b, in, out, stream);
+    else if (need <= 8) launch_sweeps<T, 8>(a, grid_b, in, out, stream);
+    else if (need <= 16) launch_sweeps<T, 16>(a, grid_b, in, out, stream);
+    else launch_sweeps<T, 32>(a, grid_b, in, out, stream);
+  };
+
+  BiHost<T> host;
+  auto fetch = [&]() -> int {
+    PISO_HIP_CHECK(hipMemcpyAsync(host.sc, a.sc, 2 * sizeof(CompScalars<T>), hipMemcpyDeviceToHost, stream));
+    PISO_HIP_CHECK(hipMemcpyAsync(host.flags, a.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    PISO_HIP_CHECK(hipStreamSynchronize(stream));
+    return PISO_OK;
+  };
+
+  int failed_mask = 0;      // components that already used their one restart and failed again
+  bool pattern_checked = false;
+  for (int restart = 0; restart < 2; ++restart) {
+    // r = b - B x, rh = r, p = v = 0, ||r|| test, first rho / beta
+    bi_residual_init<T><<<grid_v, kBlock, 0, stream>>>(a);
+    bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_INIT);
+    PISO_LAUNCH_CHECK();
+    int it = 0;
+    bool all_done = false;
+    while (it < max_it && !all_done) {
+      const int chunk = (max_it - it) < 2 ? (max_it - it) : 2;          // iterations between host looks
+      for (int q = 0; q < chunk; ++q, ++it) {
+        if (it > 0) bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_RHO_BETA);
+        bi_update_p<T><<<grid_v, kBlock, 0, stream>>>(a);
+        precond(a.p, a.ph);
+        bi_spmv<T, 0><<<grid_v, kBlock, 0, stream>>>(a, a.ph, a.v);
+        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_ALPHA);
+        bi_update_xr<T, 0><<<grid_v, kBlock, 0, stream>>>(a);
+        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_CHECK_S);
+        precond(a.r, a.sh);
+        bi_spmv<T, 1><<<grid_v, kBlock, 0, stream>>>(a, a.sh, a.t);
+        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_OMEGA);
+        bi_update_xr<T, 1><<<grid_v, kBlock, 0, stream>>>(a);
+        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_CHECK_R);
+      }
+      PISO_LAUNCH_CHECK();
+      { const int rc = fetch(); if (rc != PISO_OK) return rc; }
+      if (!pattern_checked) {
+        pattern_checked = true;
+        if (host.flags[0]) {
+          set_error_msg("piso_multi_bicgstab_ilu: CSR input is not a 5-point staggered-grid matrix");
+          return PISO_ERR_UNSUPPORTED_PATTERN;
+        }
+      }
+      all_done = host.sc[0].done && host.sc[1].done;
+    }
+    if (max_it == 0 || !pattern_checked) { const int rc = fetch(); if (rc != PISO_OK) return rc; }
+    // failure test per component (:392-407): ||r|| > 100 tol or NaN -> x = 0 and one more pass from x = 0
+    int fail_now = 0;
+    for (int c = 0; c < 2; ++c) {
+      const T nrm = host.sc[c].nrm;
+      if (nrm > (T)tol * 100 || nrm != nrm) fail_now |= 1 << c;
+    }
+    if (!fail_now) break;
+    bi_zero_x<T><<<grid_v, kBlock, 0, stream>>>(a, fail_now);
+    if (restart == 0) {
+      bi_set_done<T><<<1, 64, 0, stream>>>(a, !(fail_now & 1), !((fail_now >> 1) & 1));
+    } else {
+      failed_mask = fail_now;
+    }
+  }
+  (void)failed_mask;
+  PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  if (host.flags[1] && warning) {
+    const uint8_t one = 1;
+    PISO_HIP_CHECK(hipMemcpyAsync(warning, &one, 1, hipMemcpyHostToDevice, stream));
+    PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  if (iterations_out) { iterations_out[0] = host.sc[0].it_count; iterations_out[1] = host.sc[1].it_count; }
+  return PISO_OK;
+}
+
+// y = A x or A^T x on the concatenated CSR (second-corrector H product and its adjoint)
+__global__ __launch_bounds__(kBlock) void csr_matvec_kernel(const float* __restrict__ val_all, const int* __restrict__ rp_all,
+                                                            const int* __restrict__ col_all, const float* __restrict__ x,
+                                                            float* __restrict__ y, Geo g, int transpose) {
+  const int c = blockIdx.y;
+  const int n = g.n[c], r0 = g.r0[c], W = g.W[c];
+  const int* rp = rp_all + (c ? g.n[0] + 1 : 0);
+  const int k0 = c ? rp_all[g.n[0]] : 0;
+  const float* val = val_all + k0;
+  const int* col = col_all + k0;
+  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+    float acc = 0.f;
+    if (!transpose) {
+      for (int q = rp[row]; q < rp[row + 1]; ++q) acc = fmaf(val[q], x[r0 + col[q]], acc);
+    } else {
+      // gather over every row that can hold an entry in column `row` (ascending row order = csr2csc order)
+      const int cand[9] = {row - g.yw[c], row - W, row - g.xw[c], row - 1, row, row + 1, row + g.xw[c], row + W, row + g.yw[c]};
+      int last = -1;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) {
+        const int m = cand[q];
+        if (m < 0 || m >= n || m <= last) continue;
+        last = m;
+        float v;
+        if (csr_find<float>(rp, col, val, m, row, &v)) acc = fmaf(v, x[r0 + m], acc);
+      }
+    }
+    y[r0 + row] = acc;
+  }
+}
+
+}  // namespace piso
+
+using namespace piso;
+
+extern "C" {
+
+size_t piso_bicgstab_workspace_bytes(int nx, int ny, int elem_size) {
+  return elem_size == 8 ? bi_workspace_bytes<double>(nx, ny) : bi_workspace_bytes<float>(nx, ny);
+}
+
+int piso_multi_bicgstab_ilu_f32(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* rhs,
+                                const float* x0, float* x_out, int nx, int ny, float tol, int max_it, int transpose,
+                                int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
+                                size_t workspace_bytes, piso_stream_t stream) {
+  return bi_solve<float>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning,
+                         iterations_out, workspace, workspace_bytes, stream);
+}
+
+int piso_multi_bicgstab_ilu_f64(const double* csr_val, const int* csr_rowptr, const int* csr_col, const double* rhs,
+                                const double* x0, double* x_out, int nx, int ny, float tol, int max_it, int transpose,
+                                int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
+                                size_t workspace_bytes, piso_stream_t stream) {
+  return bi_solve<double>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning,
+                          iterations_out, workspace, workspace_bytes, stream);
+}
+
+int piso_csr_matvec_f32(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* x, float* y,
+                        int nx, int ny, int transpose, piso_stream_t stream) {
+  if (nx < 4 || ny < 4 || !csr_val || !csr_rowptr || !csr_col || !x || !y) {
+    set_error_msg("piso_csr_matvec_f32: invalid argument");
+    return PISO_ERR_INVALID_ARG;
+  }
+  const Geo g = make_geo(nx, ny, 8);
+  const int nmax = g.n[0] > g.n[1] ? g.n[0] : g.n[1];
+  int gv = (nmax + kBlock * 2 - 1) / (kBlock * 2);
+  if (gv > 4096) gv = 4096;
+  csr_matvec_kernel<<<dim3(gv, 2), kBlock, 0, static_cast<hipStream_t>(stream)>>>(csr_val, csr_rowptr, csr_col, x, y, g,
+                                                                                  transpose ? 1 : 0);
+  PISO_LAUNCH_CHECK();
+  return PISO_OK;
+}
+}

@@ -1,0 +1,88 @@
+"""ctypes binding of libpiso_hip.so -- the hand-written gfx950 kernels behind the C ABI of include/piso_hip.h.
+
+Mirrors the reference's `tf.load_op_library(...)` blocks (diffpiso/piso_tf.py:3-8, diffpiso/linear_solver.py:6-12,
+diffpiso/piso_cuda_pressure_solver.py:4-8): importing the package FAILS if the native library is missing -- there is no
+CPU or PyTorch fallback for the solver path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpiso_hip.so")
+
+if not os.path.isfile(LIB_PATH):
+    raise ImportError('HIP binaries not found at %s. Run "python differentiable-piso_amd/build_native.py" '
+                      '(or __graft_entry__.build()) to compile them' % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_ip = C.POINTER(C.c_int)
+
+lib.piso_version.restype = C.c_char_p
+lib.piso_last_error_string.restype = C.c_char_p
+lib.piso_device_count.restype = _i
+lib.piso_csr_nnz.argtypes = [_i, _i, _i, _i, _ip, _ip]
+lib.piso_csr_nnz.restype = None
+lib.piso_assemble_csr.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _f, _vp]
+lib.piso_assemble_csr.restype = _i
+for _n in ("piso_laplace_matrix_f64", "piso_laplace_matrix_f32"):
+    getattr(lib, _n).argtypes = [_i, _i, _vp, _vp, _vp, _vp, _vp]
+    getattr(lib, _n).restype = _i
+lib.piso_cg_workspace_bytes.argtypes = [_i, _i, _i]
+lib.piso_cg_workspace_bytes.restype = _sz
+for _n in ("piso_cg_solve_f64", "piso_cg_solve_f32"):
+    getattr(lib, _n).argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _i, _ip, _vp, _sz, _vp]
+    getattr(lib, _n).restype = _i
+lib.piso_cg_fixed_iterations_f64.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_float), _vp, _sz, _vp]
+lib.piso_cg_fixed_iterations_f64.restype = _i
+lib.piso_cg_profile_enable.argtypes = [_i, _i]
+lib.piso_cg_profile_enable.restype = None
+lib.piso_cg_profile_read.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+lib.piso_cg_profile_read.restype = None
+lib.piso_bicgstab_workspace_bytes.argtypes = [_i, _i, _i]
+lib.piso_bicgstab_workspace_bytes.restype = _sz
+for _n in ("piso_multi_bicgstab_ilu_f32", "piso_multi_bicgstab_ilu_f64"):
+    getattr(lib, _n).argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _ip, _vp, _sz, _vp]
+    getattr(lib, _n).restype = _i
+lib.piso_csr_matvec_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]
+lib.piso_csr_matvec_f32.restype = _i
+
+
+class PisoNativeError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status != 0:
+        raise PisoNativeError("%s failed with status %d: %s" % (what, status, lib.piso_last_error_string().decode()))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise PisoNativeError("libpiso_hip needs device tensors; got a %s tensor (no CPU fallback exists)" % t.device)
+    if not t.is_contiguous():
+        raise PisoNativeError("non-contiguous tensor passed to libpiso_hip")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device, tag):
+    """Cached byte workspace per (device, tag); grown on demand. The library never allocates device memory itself."""
+    key = (str(device), tag)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws

@@ -1,0 +1,226 @@
+"""The PISO step: implicit advection-diffusion predictor + two pressure correctors on a 2-D staggered grid.
+
+Host-side mirror of diffpiso/piso_tf.py (piso_step, advection_matrix_cuda, pressure_extrapolation, SimulationParameters):
+same names, argument order and return values; the three heavy operations call libpiso_hip.so through the C ABI
+(include/piso_hip.h), the element-wise glue is torch on the device, reverse mode is torch autograd with custom nodes
+for the solves (frozen-coefficient adjoint: no gradient through matrix assembly, diffpiso/piso_tf.py:125-126).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .grids import CenteredGrid, Material, StaggeredGrid, as_tensor, default_device
+from .stencils import (arrange_rhs_term_tf, finite_volume_divergence, finite_volume_gradient_tensor, flatten_staggered_data,
+                       padded_velocity_flat, stagger_flattened_data)
+
+
+class Physics(object):
+    """Stand-in for phi.physics.physics.Physics (the reference only uses it as a base class)."""
+
+    def __init__(self, dependencies=None, blocking_dependencies=None):
+        self.dependencies = dependencies
+        self.blocking_dependencies = blocking_dependencies
+
+
+class SimulationParameters(Physics):
+    """diffpiso/piso_tf.py:165-182.  Masks may be numpy arrays (as in the reference's scripts) or tensors; device copies
+    are cached."""
+
+    def __init__(self, dirichlet_mask, dirichlet_values, active_mask, accessible_mask, bool_periodic=None,
+                 no_slip_mask=None, viscosity=0., linear_solver=None, pressure_solver=None):
+        Physics.__init__(self)
+        self.pressure_solver = pressure_solver
+        self.linear_solver = linear_solver
+        self.dirichlet_mask = dirichlet_mask
+        self.dirichlet_values = dirichlet_values
+        self.active_mask = active_mask
+        self.accessible_mask = accessible_mask
+        self.no_slip_mask = no_slip_mask
+        self.bool_periodic = bool_periodic
+        self.viscosity = viscosity
+        self._cache = {}
+
+    def _cached(self, key, src, dtype, device):
+        k = (key, id(src), str(device))
+        t = self._cache.get(k)
+        if t is None:
+            t = as_tensor(src, dtype=dtype, device=device).contiguous()
+            self._cache[k] = t
+        return t
+
+    def active_mask_tensor(self, device):
+        return self._cached("active", self.active_mask, torch.float32, device)
+
+    def accessible_mask_tensor(self, device):
+        return self._cached("accessible", self.accessible_mask, torch.float32, device)
+
+    def dirichlet_mask_flat(self, device):
+        """flatten_staggered_data(dirichlet_mask, True) as bytes (piso_tf.py:30)."""
+        k = ("dmask_flat", id(self.dirichlet_mask), str(device))
+        t = self._cache.get(k)
+        if t is None:
+            m = as_tensor(self.dirichlet_mask, device=device)
+            t = flatten_staggered_data(m.to(torch.float32), True).ne(0).to(torch.uint8).contiguous()
+            self._cache[k] = t
+        return t
+
+    def no_slip_flat(self, device, ny, nx):
+        if self.no_slip_mask is None:
+            return None
+        k = ("noslip", id(self.no_slip_mask), str(device))
+        t = self._cache.get(k)
+        if t is None:
+            t = as_tensor(self.no_slip_mask, device=device).reshape(-1).ne(0).to(torch.uint8).contiguous()
+            if t.numel() < (ny + 2) * (nx + 2):
+                raise ValueError("no_slip_mask must cover the padded cell grid (Ny+2)*(Nx+2)")
+            self._cache[k] = t
+        return t
+
+
+def pressure_extrapolation(boundaries):
+    """diffpiso/piso_tf.py:140-162: the accessible-extrapolation mode of every boundary."""
+    if not boundaries:
+        return None
+    return Material.accessible_extrapolation_mode(boundaries)
+
+
+def advection_matrix_cuda(velocity, dirichlet_mask_flat, viscosity, beta=0, no_slip_wall_mask=None, bool_periodic=None,
+                          active_mask=None, accessible_mask=None, unrolling_step=0):
+    """diffpiso/piso_tf.py:85-137 (the name is kept for drop-in use; the kernel is HIP).  No gradient flows through it
+    (:125-126).  Returns (matrix_values, row_pointers, column_indices, A, matrix_nnz, A_flat)."""
+    with torch.no_grad():
+        ny, nx = [int(r) for r in velocity.resolution]
+        if bool_periodic is None:
+            bool_periodic = (False, False)
+        per_y, per_x = bool(bool_periodic[0]), bool(bool_periodic[1])          # given (y, x); the op wants (x, y) (:89)
+        vel_pad = padded_velocity_flat(velocity).to(torch.float32).contiguous()
+        dev = vel_pad.device
+        dx = velocity.dx
+        grid_spacing = np.array([dx[1], dx[0]], dtype=np.float32)               # :96
+        cell_area = (np.prod(dx) / np.array([dx[1], dx[0]], dtype=np.float32)).astype(np.float32)   # :97
+        nnz_u, nnz_v = C.c_int(0), C.c_int(0)
+        N.lib.piso_csr_nnz(nx, ny, int(per_x), int(per_y), C.byref(nnz_u), C.byref(nnz_v))
+        n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
+        nnz = nnz_u.value + nnz_v.value
+        csr_val = torch.empty(nnz, dtype=torch.float32, device=dev)
+        csr_col = torch.empty(nnz, dtype=torch.int32, device=dev)
+        csr_row = torch.empty(n_u + n_v + 2, dtype=torch.int32, device=dev)
+        diag = torch.empty(n_u + n_v, dtype=torch.float32, device=dev)
+        visc = as_tensor(viscosity, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+        is_field = int(visc.numel() > 1)
+        if is_field and visc.numel() != n_u + n_v:
+            raise ValueError("viscosity field must have n_u + n_v entries (u first)")
+        dmask = dirichlet_mask_flat if dirichlet_mask_flat.dtype == torch.uint8 else dirichlet_mask_flat.ne(0).to(torch.uint8)
+        act = as_tensor(active_mask, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+        if act.numel() != (nx + 2) * (ny + 2):
+            raise ValueError("active_mask must have shape [1, Ny+2, Nx+2, 1]")
+        st = N.lib.piso_assemble_csr(N.ptr(vel_pad), N.ptr(csr_val), N.ptr(csr_col), N.ptr(csr_row), N.ptr(diag),
+                                     N.ptr(dmask.contiguous()), N.ptr(act), N.ptr(visc), is_field, nx, ny, int(per_x),
+                                     int(per_y), C.c_float(cell_area[0]), C.c_float(cell_area[1]),
+                                     C.c_float(grid_spacing[0]), C.c_float(grid_spacing[1]),
+                                     N.ptr(no_slip_wall_mask), C.c_float(np.float32(beta)), N.stream_ptr())
+        N.check(st, "piso_assemble_csr")
+        shape = (1, ny + 1, nx + 1, 2)
+        A = stagger_flattened_data(diag, shape, coord_flip=True)
+    return csr_val, csr_row, csr_col, A, np.array([nnz_u.value, nnz_v.value]), diag
+
+
+class _CsrMatVec(torch.autograd.Function):
+    """The gather / segment-sum product of explicit_H_csr (diffpiso/piso_helpers.py:209-222); matrix values carry no
+    gradient (they come from advection_matrix_cuda), the vector's gradient is the transpose product."""
+
+    @staticmethod
+    def forward(ctx, x_flat, values, row_ptr, col_indices, nx, ny):
+        x_flat = x_flat.contiguous()
+        y = torch.empty_like(x_flat)
+        N.check(N.lib.piso_csr_matvec_f32(N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(x_flat), N.ptr(y),
+                                          nx, ny, 0, N.stream_ptr()), "piso_csr_matvec")
+        ctx.save_for_backward(values, row_ptr, col_indices)
+        ctx.meta = (nx, ny)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        values, row_ptr, col_indices = ctx.saved_tensors
+        nx, ny = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        N.check(N.lib.piso_csr_matvec_f32(N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(dy), N.ptr(dx),
+                                          nx, ny, 1, N.stream_ptr()), "piso_csr_matvec^T")
+        return dx, None, None, None, None, None
+
+
+def explicit_H_csr(matrix_values, row_pointers, column_indices, velocity, staggered_shape, A, beta=0):
+    """diffpiso/piso_helpers.py:209-223: H dv = M dv - (A - beta) dv  (M = [M_u, M_v] in CSR)."""
+    ny, nx = int(staggered_shape[1]) - 1, int(staggered_shape[2]) - 1
+    velocity = velocity if isinstance(velocity, StaggeredGrid) else StaggeredGrid(velocity)
+    v_flat = flatten_staggered_data(velocity, coord_flip=True)
+    prod = _CsrMatVec.apply(v_flat, matrix_values, row_pointers, column_indices, nx, ny)
+    return stagger_flattened_data(prod, staggered_shape, coord_flip=True) - (A - beta) * velocity.staggered_tensor()
+
+
+def piso_step(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_physics, dirichlet_values,
+              viscosity_field=None, forcing_term=None, unrolling_step=0, warn=None, full_output=False, **kwargs):
+    """diffpiso/piso_tf.py:11-81, statement by statement."""
+    staggered_shape = tuple(velocity.staggered_tensor().shape)
+    sim = simulation_physics
+    vel_tensor = velocity.staggered_tensor()
+    dev = vel_tensor.device
+    ny, nx = staggered_shape[1] - 1, staggered_shape[2] - 1
+    if warn is None:
+        warn = torch.zeros(1, dtype=torch.uint8, device=dev)
+
+    def pressure_solve(field, A_0, guess, unrolling_step):
+        res, _, L = sim.pressure_solver.solve(A_0, field, guess, False, sim, unrolling_step=unrolling_step)
+        return res, L
+
+    viscosity = sim.viscosity if viscosity_field is None else viscosity_field      # :21-24
+    dxdy = float(np.prod(velocity.dx))
+    beta = dxdy / dt                                                               # :26
+
+    # ADVECTION MATRICES (:29-33)
+    matrix_values, row_pointers, column_indices, A, matrix_nnz, Aflat = advection_matrix_cuda(
+        velocity, sim.dirichlet_mask_flat(dev), viscosity, beta=beta, no_slip_wall_mask=sim.no_slip_flat(dev, ny, nx),
+        bool_periodic=sim.bool_periodic, active_mask=sim.active_mask_tensor(dev),
+        accessible_mask=sim.accessible_mask_tensor(dev), unrolling_step=unrolling_step)
+
+    # Predictor step (:36-47)
+    implicit_rhs = vel_tensor * beta - finite_volume_gradient_tensor(pressure, sim)
+    if forcing_term is not None:
+        implicit_rhs = implicit_rhs + as_tensor(forcing_term, device=dev) * dxdy
+    implicit_rhs = arrange_rhs_term_tf(implicit_rhs, sim.dirichlet_mask, dirichlet_values, beta, coord_flip=True)
+    sol = sim.linear_solver.solve(-matrix_values, row_pointers, column_indices, implicit_rhs, staggered_shape,
+                                  flatten_staggered_data(velocity, True), offset=1, transpose=False,
+                                  unrolling_step=unrolling_step, warn=warn)
+    warn = sol[1]
+    sol = stagger_flattened_data(sol[0], staggered_shape, coord_flip=True)
+    velocity_star = StaggeredGrid(sol, box=velocity.box, extrapolation=velocity.extrapolation)
+
+    # Corrector step 1 (:49-58); implicitly assumes dx == dy like the reference
+    v1div = finite_volume_divergence(velocity_star)
+    dx_factor = dxdy / (float(velocity.dx[0]) ** 2)
+    bmA = beta - A
+    A_0 = 1 / bmA * dx_factor
+    pressure_inc_data, Lap1 = pressure_solve(v1div, A_0, guess=pressure_inc1.data, unrolling_step=unrolling_step)
+    pressure_inc1 = CenteredGrid(pressure_inc_data, box=pressure_inc1.box, extrapolation=pressure_inc1.extrapolation)
+    star_tensor = velocity_star.staggered_tensor()
+    velocity_s2 = star_tensor - finite_volume_gradient_tensor(pressure_inc1, sim_physics=sim) / bmA / dxdy
+
+    # Corrector step 2 (:60-73)
+    H_contribution = explicit_H_csr(matrix_values, row_pointers, column_indices, StaggeredGrid(velocity_s2 - star_tensor),
+                                    staggered_shape, A, beta)
+    H_div = finite_volume_divergence(StaggeredGrid(H_contribution / bmA, box=velocity.box,
+                                                   extrapolation=velocity.extrapolation))
+    pressure_inc2_data, Lap2 = pressure_solve(H_div, A_0, guess=pressure_inc2.data, unrolling_step=1000 + unrolling_step)
+    pressure_inc2 = CenteredGrid(pressure_inc2_data, box=pressure_inc2.box, extrapolation=pressure_inc2.extrapolation)
+    velocity_s3_data = velocity_s2 + (H_contribution - finite_volume_gradient_tensor(pressure_inc2, sim_physics=sim) / dxdy) / bmA
+    velocity_s3 = StaggeredGrid(velocity_s3_data, box=velocity.box, extrapolation=velocity.extrapolation)
+
+    pressure = pressure + pressure_inc1 + pressure_inc2                             # :75
+
+    if full_output:
+        return velocity_s3, pressure, pressure_inc1, pressure_inc2, matrix_values, column_indices, row_pointers, \
+            star_tensor, velocity_s2, Aflat, implicit_rhs, sol, velocity_s3_data, v1div, Lap1, Lap2, warn
+    return velocity_s3, pressure, warn

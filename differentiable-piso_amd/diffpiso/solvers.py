@@ -1,0 +1,237 @@
+"""Solver classes of the PISO step, backed by libpiso_hip.so (hand-written gfx950 kernels behind a C ABI).
+
+Same class surface as the reference (diffpiso/linear_solver.py, diffpiso/piso_cuda_pressure_solver.py):
+  LinearSolver                              base type                               (linear_solver.py:15-30)
+  LinearSolverCudaMultiBicgstabILU          u+v ILU(0)-BiCGStab, adjoint = A^T solve  (linear_solver.py:113-178)
+  PisoPressureSolverCudaCustom              A0-weighted 5-diagonal CG, adjoint = same solve (piso_cuda_pressure_solver.py:36-114)
+The adjoint linear solves are `torch.autograd.Function` nodes (the reference uses tf.custom_gradient).
+There is NO CPU / PyTorch fallback: tensors must live on the GPU and the native library must be present.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .grids import StaggeredGrid, as_tensor
+from .stencils import flatten_staggered_data
+
+
+class LinearSolver(object):
+    """diffpiso/linear_solver.py:15-30."""
+
+    def __init__(self, name, supported_devices, supports_guess, supports_batch, solver_type, input_format):
+        self.name = name
+        self.supported_devices = supported_devices
+        self.supports_guess = supports_guess
+        self.supports_batch = supports_batch
+        self.solver_type = solver_type
+        self.input_format = input_format
+
+    def solve(self, *args):
+        raise NotImplementedError(self.__class__)
+
+    def __repr__(self):
+        return self.name
+
+
+def _scalar(v):
+    if isinstance(v, torch.Tensor):
+        return float(v.item())
+    return float(v)
+
+
+def multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn):
+    """One call of piso_multi_bicgstab_ilu_{f32,f64}. Returns (x, iterations[2]); sets warn[0] in place on NaN input."""
+    dt = values.dtype
+    assert dt in (torch.float32, torch.float64)
+    values, rhs, x0 = values.contiguous(), rhs.to(dt).contiguous(), x0.to(dt).contiguous()
+    row_ptr, col_indices = row_ptr.contiguous(), col_indices.contiguous()
+    x = torch.empty_like(rhs)
+    elem = 8 if dt == torch.float64 else 4
+    nbytes = N.lib.piso_bicgstab_workspace_bytes(nx, ny, elem)
+    ws = N.workspace(nbytes, rhs.device, "bicgstab")
+    its = (C.c_int * 2)()
+    fn = N.lib.piso_multi_bicgstab_ilu_f64 if dt == torch.float64 else N.lib.piso_multi_bicgstab_ilu_f32
+    st = fn(N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(rhs), N.ptr(x0), N.ptr(x), nx, ny, C.c_float(tol),
+            int(max_it), int(bool(transpose)), int(band_rows), N.ptr(warn), its, N.ptr(ws), C.c_size_t(ws.numel()),
+            N.stream_ptr())
+    N.check(st, "piso_multi_bicgstab_ilu")
+    return x, (its[0], its[1])
+
+
+class _LinearSolveFn(torch.autograd.Function):
+    """solve_call of diffpiso/linear_solver.py:163-175: gradient only w.r.t. the right-hand side, obtained by solving with
+    the transposed matrix (same initial guess), multiplied by (1 - warn)."""
+
+    @staticmethod
+    def forward(ctx, rhs, values, row_ptr, col_indices, x0, solver, nx, ny, transpose, warn):
+        tol = _scalar(solver.accuracy)
+        x, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, solver.max_iterations,
+                                           transpose, solver.band_rows, warn)
+        solver.last_iterations = its
+        ctx.save_for_backward(values, row_ptr, col_indices, x0)
+        ctx.meta = (solver, nx, ny, transpose)
+        return x.to(torch.float32), warn.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, ds, dw):
+        values, row_ptr, col_indices, x0 = ctx.saved_tensors
+        solver, nx, ny, transpose = ctx.meta
+        warn_b = torch.zeros(1, dtype=torch.uint8, device=ds.device)
+        tol = _scalar(solver.accuracy)
+        df, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, ds.to(values.dtype), x0, nx, ny, tol,
+                                            solver.max_iterations, not transpose, solver.band_rows, warn_b)
+        solver.last_adjoint_iterations = its
+        df = df.to(torch.float32) * (1.0 - warn_b.to(torch.float32)[0])
+        return df, None, None, None, None, None, None, None, None, None
+
+
+class LinearSolverCudaMultiBicgstabILU(LinearSolver):
+    """diffpiso/linear_solver.py:113-178.  `accuracy` may be a float or a 0-d/1-element tensor (the reference accepts a
+    placeholder, lid_driven_cavity_2d.py:12-13) and may be re-assigned between steps.
+    band_rows: preconditioner block height of the MI355X engine (0 = automatic, < 0 = one block); not in the reference."""
+
+    def __init__(self, accuracy=1e-5, max_iterations=2000, cast_to_double=False, band_rows=0):
+        LinearSolver.__init__(self, "HIP dual iLU-preconditioned BiCGStab solve", supported_devices=("GPU",),
+                              supports_guess=True, supports_batch=False, solver_type="iterative", input_format="csr")
+        self.max_iterations = max_iterations
+        self.cast_to_double = cast_to_double
+        self.accuracy = accuracy
+        self.band_rows = band_rows
+        self.last_iterations = None
+        self.last_adjoint_iterations = None
+
+    def solve(self, matrix_values, row_ptr, col_indices, rhs, staggered_shape, initial_guess=None, offset=0,
+              transpose=False, unrolling_step=0, warn=None):
+        dt = torch.float64 if self.cast_to_double else torch.float32
+        values = matrix_values.reshape(-1).to(dt)
+        flat_rhs = rhs.reshape(-1)
+        ny, nx = int(staggered_shape[1]) - 1, int(staggered_shape[2]) - 1
+        n_tot = (nx + 1) * ny + nx * (ny + 1)
+        if initial_guess is None:
+            flat_x = torch.zeros(n_tot, dtype=dt, device=flat_rhs.device)
+        else:
+            flat_x = initial_guess.reshape(-1).detach().to(dt)
+        if warn is None:
+            warn = torch.zeros(1, dtype=torch.uint8, device=flat_rhs.device)
+        elif warn.dtype != torch.uint8:
+            warn = (warn != 0).to(torch.uint8)
+        sol, w = _LinearSolveFn.apply(flat_rhs, values.detach(), row_ptr.reshape(-1), col_indices.reshape(-1), flat_x, self,
+                                      nx, ny, bool(transpose), warn)
+        return [sol, w]
+
+
+LinearSolverHipMultiBicgstabILU = LinearSolverCudaMultiBicgstabILU
+
+
+# ------------------------------------------------------------------------------------------------------------------
+class PoissonSolver(object):
+    """PhiFlow/phi/physics/pressuresolver/solver_api.py:10-38 (attribute holder)."""
+
+    def __init__(self, name, supported_devices, supports_guess, supports_loop_counter, supports_continuous_masks):
+        self.name = name
+        self.supported_devices = supported_devices
+        self.supports_guess = supports_guess
+        self.supports_loop_counter = supports_loop_counter
+        self.supports_continuous_masks = supports_continuous_masks
+
+    def __repr__(self):
+        return self.name
+
+
+def laplace_matrix_native(nx, ny, active, accessible, a0_vfirst, dtype):
+    L = torch.empty(nx * ny * 5, dtype=dtype, device=a0_vfirst.device)
+    fn = N.lib.piso_laplace_matrix_f64 if dtype == torch.float64 else N.lib.piso_laplace_matrix_f32
+    N.check(fn(nx, ny, N.ptr(active), N.ptr(accessible), N.ptr(a0_vfirst.contiguous()), N.ptr(L), N.stream_ptr()),
+            "piso_laplace_matrix")
+    return L
+
+
+def cg_solve_native(nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient, residual_reset):
+    dt = L.dtype
+    div = div.reshape(-1).to(dt).contiguous()
+    x = torch.empty_like(div)
+    elem = 8 if dt == torch.float64 else 4
+    ws = N.workspace(N.lib.piso_cg_workspace_bytes(nx, ny, elem), div.device, "cg")
+    it = C.c_int(0)
+    fn = N.lib.piso_cg_solve_f64 if dt == torch.float64 else N.lib.piso_cg_solve_f32
+    st = fn(nx, ny, int(per_x), int(per_y), N.ptr(L), N.ptr(div), N.ptr(x), C.c_float(accuracy), int(max_iterations),
+            int(bool(rank_deficient)), int(residual_reset), C.byref(it), N.ptr(ws), C.c_size_t(ws.numel()), N.stream_ptr())
+    N.check(st, "piso_cg_solve")
+    return x, it.value
+
+
+class _PressureSolveFn(torch.autograd.Function):
+    """psolve of diffpiso/piso_cuda_pressure_solver.py:90-109: gradient only w.r.t. the divergence = the same CG solve
+    applied to the incoming gradient (the operator is symmetric)."""
+
+    @staticmethod
+    def forward(ctx, divergence, L, solver, nx, ny, per_x, per_y, rank_deficient):
+        x, it = cg_solve_native(nx, ny, per_x, per_y, L, divergence, _scalar(solver.accuracy), solver.max_iterations,
+                                rank_deficient, solver.residual_reset)
+        solver.last_iterations = it
+        ctx.save_for_backward(L)
+        ctx.meta = (solver, nx, ny, per_x, per_y, rank_deficient, divergence.shape)
+        iterations = torch.tensor([it], dtype=torch.int32, device=divergence.device)
+        return x.reshape(divergence.shape).to(torch.float32), iterations
+
+    @staticmethod
+    def backward(ctx, dp, di):
+        (L,) = ctx.saved_tensors
+        solver, nx, ny, per_x, per_y, rank_deficient, shape = ctx.meta
+        g, it = cg_solve_native(nx, ny, per_x, per_y, L, dp.reshape(-1), _scalar(solver.accuracy), solver.max_iterations,
+                                rank_deficient, solver.residual_reset)
+        solver.last_adjoint_iterations = it
+        return g.reshape(shape).to(torch.float32), None, None, None, None, None, None, None
+
+
+class PisoPressureSolverCudaCustom(PoissonSolver):
+    """diffpiso/piso_cuda_pressure_solver.py:36-114."""
+
+    def __init__(self, dx, accuracy=1e-5, max_iterations=2000, residual_reset=10, randomized_restarts=0,
+                 cast_to_double=True):
+        PoissonSolver.__init__(self, "HIP Conjugate Gradient", supported_devices=("GPU",), supports_loop_counter=False,
+                               supports_guess=True, supports_continuous_masks=False)
+        self.accuracy = accuracy
+        self.max_iterations = max_iterations
+        self.dx = dx
+        self.scaling_field = None
+        self.solve_count = 0.001
+        self.laplace_rank_deficient = None
+        self.residual_reset = residual_reset
+        assert randomized_restarts >= 0
+        if randomized_restarts != 0:
+            raise NotImplementedError("randomized_restarts > 0 is never used by the reference's scripts "
+                                      "(combined_training_integrated.py:487) and is not implemented")
+        self.randomized_restarts = randomized_restarts
+        self.cast_to_double = cast_to_double
+        self.last_iterations = None
+        self.last_adjoint_iterations = None
+
+    def solve(self, scaling_field, divergence, guess, enable_backprop, simulation_physics, offset=0, unrolling_step=0):
+        # `guess` is ignored exactly like in the reference (init_with_zeros=True, piso_cuda_pressure_solver.py:95)
+        scaling_field = scaling_field if isinstance(scaling_field, StaggeredGrid) else StaggeredGrid(scaling_field)
+        dt = torch.float64 if self.cast_to_double else torch.float32
+        ny, nx = int(divergence.shape[1]), int(divergence.shape[2])
+        dev = divergence.device
+        a0 = flatten_staggered_data(scaling_field, coord_flip=False).detach().to(torch.float32)   # v first (:70)
+        active = simulation_physics.active_mask_tensor(dev)
+        accessible = simulation_physics.accessible_mask_tensor(dev)
+        if self.laplace_rank_deficient is None:                                     # :84-87
+            a, c = accessible, active
+            prod = a * c + (1 - a) * (1 - c)
+            prod = torch.prod(prod[0, 0, 1:-1, 0]) * torch.prod(prod[0, -1, 1:-1, 0]) * \
+                torch.prod(prod[0, 1:-1, 0, 0]) * torch.prod(prod[0, 1:-1, -1, 0])
+            self.laplace_rank_deficient = bool(prod.item() != 0)
+        rank_def = self.laplace_rank_deficient
+        if isinstance(rank_def, torch.Tensor):
+            rank_def = bool(rank_def.reshape(-1)[0].item())
+        L = laplace_matrix_native(nx, ny, active.reshape(-1).contiguous(), accessible.reshape(-1).contiguous(), a0, dt)
+        per_y, per_x = [bool(b) for b in simulation_physics.bool_periodic]          # given (y, x), flipped for the op (:95)
+        pressure, iteration = _PressureSolveFn.apply(divergence, L, self, nx, ny, per_x, per_y, rank_def)
+        self.solve_count = self.solve_count + .001
+        return pressure, iteration, L
+
+
+PisoPressureSolverHip = PisoPressureSolverCudaCustom

@@ -1,0 +1,129 @@
+/*
+ * piso_hip.h -- C ABI of libpiso_hip.so, the MI355X (gfx950) native library behind the differentiable-PISO hot path.
+ *
+ * Drop-in boundary: each entry point replaces one native launcher of tum-pbs/differentiable-piso (the functions the
+ * reference's TensorFlow OpKernel shells call after unpacking their tensors).  Differences from the reference launchers,
+ * all deliberate:
+ *   - every array argument is a DEVICE pointer owned by the caller; small scalars (sizes, tolerances, flags) are passed
+ *     BY VALUE instead of as device arrays that the launcher copies back to the host;
+ *   - an explicit HIP stream (hipStream_t passed as void*; NULL = the null stream);
+ *   - scratch memory is a caller-provided workspace (query *_workspace_bytes first); nothing is hipMalloc'ed per call;
+ *   - an int status is returned (PISO_OK == 0) instead of exit(1)/assert(0);
+ *   - outputs are separate arrays (no input buffer is overwritten in place).
+ * Numerical failure handling mirrors the reference: non-convergence of BiCGStab yields a zero solution after one restart,
+ * NaN input sets warning[0] = 1; the pressure CG reports its iteration count.
+ *
+ * Layout conventions (identical to the reference):
+ *   nx, ny          cell resolution; x is the fastest index everywhere
+ *   u faces         [ny][nx+1]     v faces [ny+1][nx]      "u-first" flat vector = u followed by v
+ *   padded u        [ny+2][nx+3]   padded v [ny+3][nx+2]   (custom_padded, diffpiso/piso_helpers.py:35-55)
+ *   cell masks      [ny+2][nx+2]   (one ghost ring)        pressure / divergence [ny][nx]
+ *   pressure matrix [ny*nx][5]     row = (-y, -x, diag, +x, +y)
+ *   A0 (face coefficient of the pressure matrix) flat "v-first": v faces followed by u faces
+ */
+#ifndef PISO_HIP_H
+#define PISO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PISO_OK 0
+#define PISO_ERR_INVALID_ARG 1       /* bad size / NULL pointer / workspace too small */
+#define PISO_ERR_HIP 2               /* a HIP runtime call failed (piso_last_error_string() has the text) */
+#define PISO_ERR_UNSUPPORTED_PATTERN 3 /* CSR input is not a 5-point staggered-grid matrix */
+#define PISO_ERR_NO_DEVICE 4
+
+typedef void* piso_stream_t;
+
+/* Library / build information. */
+const char* piso_version(void);
+const char* piso_last_error_string(void);
+/* Number of visible HIP devices (0 if none; never initialises a context). */
+int piso_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Advection-diffusion matrix assembly.
+ * Replaces CentralDifferenceMatrixCsrKernelLauncher (CUDAsrc/central_difference_csr_op.cc:33-36,
+ * CUDAsrc/central_difference_csr_op.cu.cc:543-664; kernels :148-453, :472-505).
+ *   vel_pad      [(ny+2)(nx+3) + (ny+3)(nx+2)] padded u then padded v
+ *   csr_val/col  [nnz_u + nnz_v]; csr_rowptr [n_u+1 + n_v+1] (two 0-based segments); diag [n_u + n_v] (the "A" array)
+ *   dirichlet    [n_u + n_v] bytes (u first); active [(ny+2)(nx+2)]; no_slip [(ny+2)(nx+2)] bytes or NULL
+ *   viscosity    1 value, or n_u+n_v values when viscosity_is_field != 0
+ *   cell_area_x/y = area of the x-/y-normal face (dy, dx); spacing_x/y = (dx, dy); beta = dx*dy/dt
+ * nnz_u/nnz_v follow diffpiso/piso_tf.py:102-106; piso_csr_nnz() returns them.
+ * ------------------------------------------------------------------------------------------------------------- */
+void piso_csr_nnz(int nx, int ny, int periodic_x, int periodic_y, int* nnz_u, int* nnz_v);
+
+int piso_assemble_csr(const float* vel_pad, float* csr_val, int* csr_col, int* csr_rowptr, float* diag,
+                      const uint8_t* dirichlet, const float* active, const float* viscosity, int viscosity_is_field,
+                      int nx, int ny, int periodic_x, int periodic_y, float cell_area_x, float cell_area_y,
+                      float spacing_x, float spacing_y, const uint8_t* no_slip, float beta, piso_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * ILU(0)-preconditioned BiCGStab on the u and v matrices (both components advance in the same launches).
+ * Replaces MultiBicgstabIluLinearSolveLauncher (CUDAsrc/multi_bicgstab_ilu_linear_solve_op.cc:50-58,
+ * .cu.cc:455-531 float / :912-988 double; per-component algorithm :85-453 / :540-910).
+ *   csr_*      the concatenated two-matrix CSR produced by piso_assemble_csr (values possibly negated by the caller)
+ *   rhs, x0    [n_u + n_v];  x_out [n_u + n_v]
+ *   tol        absolute ||r||_2 tolerance; max_it per restart; transpose != 0 solves with A^T (adjoint)
+ *   band_rows  rows of faces per preconditioner block: < 0  = one block (global structured ILU0),
+ *              0 = automatic, > 0 = that many.  See DESIGN.md "structured block ILU0".
+ *   warning    device byte, set to 1 on NaN input (never cleared);  iterations_out: host int[2] or NULL
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t piso_bicgstab_workspace_bytes(int nx, int ny, int elem_size);
+
+int piso_multi_bicgstab_ilu_f32(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* rhs,
+                                const float* x0, float* x_out, int nx, int ny, float tol, int max_it, int transpose,
+                                int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
+                                size_t workspace_bytes, piso_stream_t stream);
+int piso_multi_bicgstab_ilu_f64(const double* csr_val, const int* csr_rowptr, const int* csr_col, const double* rhs,
+                                const double* x0, double* x_out, int nx, int ny, float tol, int max_it, int transpose,
+                                int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
+                                size_t workspace_bytes, piso_stream_t stream);
+
+/* y = A x (transpose == 0) or A^T x on the concatenated two-matrix CSR; the H-operator product of the second corrector
+ * (diffpiso/piso_helpers.py:209-223 uses tf.gather/segment_sum for it). */
+int piso_csr_matvec_f32(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* x, float* y,
+                        int nx, int ny, int transpose, piso_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Pressure matrix.  Replaces LaplaceMatrixKernelLauncher (CUDAsrc/pressure_solve_op.cc:78-84,
+ * CUDAsrc/laplace_op.cu.cc:79-239).
+ * ------------------------------------------------------------------------------------------------------------- */
+int piso_laplace_matrix_f64(int nx, int ny, const float* active, const float* fluid, const float* a0_vfirst,
+                            double* laplace, piso_stream_t stream);
+int piso_laplace_matrix_f32(int nx, int ny, const float* active, const float* fluid, const float* a0_vfirst,
+                            float* laplace, piso_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Pressure CG.  Replaces LaunchPressureKernel (CUDAsrc/pressure_solve_op.cc:48-76,
+ * CUDAsrc/pressure_solve_op.cu.cc:140-418 double / :420-696 float): plain CG on (L + c 1 1^T) x = b from x0 = 0,
+ * c = 0.1*mean|diag L| if rank_deficient, p/r re-initialised every residual_reset iterations, max-norm stop tested
+ * every 5th iteration with the reference's flag semantics.
+ *   laplace [N][5], divergence [N], x_out [N]; iterations_out: host int* (also the reference's `iterations` output)
+ * The call returns when the solve has finished (the host must see the convergence flag, as in the reference).
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t piso_cg_workspace_bytes(int nx, int ny, int elem_size);
+
+int piso_cg_solve_f64(int nx, int ny, int periodic_x, int periodic_y, const double* laplace, const double* divergence,
+                      double* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
+                      int* iterations_out, void* workspace, size_t workspace_bytes, piso_stream_t stream);
+int piso_cg_solve_f32(int nx, int ny, int periodic_x, int periodic_y, const float* laplace, const float* divergence,
+                      float* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
+                      int* iterations_out, void* workspace, size_t workspace_bytes, piso_stream_t stream);
+
+/* Fixed-work variant for bandwidth measurements: runs exactly `iterations` CG iterations (no convergence test),
+ * optionally timing the K1 (fused p-update + stencil + dots) and K2 (x/r update + dots) kernels with HIP events on
+ * `stream`; kernel_ms_out: host float[2] = average ms per launch of K1, K2 (NULL to skip). */
+int piso_cg_fixed_iterations_f64(int nx, int ny, int periodic_x, int periodic_y, const double* laplace,
+                                 const double* divergence, double* x_out, int rank_deficient, int iterations,
+                                 float* kernel_ms_out, void* workspace, size_t workspace_bytes, piso_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PISO_HIP_H */

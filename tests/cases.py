@@ -106,3 +106,30 @@ def oracle_setup(c, **kw):
     from oracle.piso_ref import OracleSetup
     return OracleSetup(c["nx"], c["ny"], c["dx_yx"], c["periodic_yx"], c["dirichlet_mask"], c["active"], c["accessible"],
                        no_slip=c["no_slip"], p_extrapolation=c["p_ext"], viscosity=c["viscosity"], **kw)
+
+
+def product_setup(c, lin_tol=1e-5, lin_max_it=2000, lin_double=False, p_tol=1e-5, p_max_it=2000, p_reset=10, p_double=True,
+                  band_rows=0, rank_deficient=None, device="cuda"):
+    """The same case as oracle_setup, expressed through the product's drop-in API (diffpiso package)."""
+    import torch
+    import diffpiso as dp
+    ny, nx = c["ny"], c["nx"]
+    bnd = eval(c["boundaries"], {"PERIODIC": dp.PERIODIC, "CLOSED": dp.CLOSED, "OPEN": dp.OPEN})
+    dy, dx = c["dx_yx"]
+    domain = dp.Domain([ny, nx], boundaries=bnd, box=dp.box[0:dy * ny, 0:dx * nx])
+    lin = dp.LinearSolverCudaMultiBicgstabILU(accuracy=lin_tol, max_iterations=lin_max_it, cast_to_double=lin_double,
+                                              band_rows=band_rows)
+    ps = dp.PisoPressureSolverCudaCustom(dx=[], accuracy=p_tol, max_iterations=p_max_it, residual_reset=p_reset,
+                                         cast_to_double=p_double)
+    if rank_deficient is not None:
+        ps.laplace_rank_deficient = rank_deficient
+    sim = dp.SimulationParameters(dirichlet_mask=c["dirichlet_mask"], dirichlet_values=c["dirichlet_values"],
+                                  active_mask=c["active"], accessible_mask=c["accessible"],
+                                  bool_periodic=c["periodic_yx"], no_slip_mask=c["no_slip"], viscosity=c["viscosity"],
+                                  linear_solver=lin, pressure_solver=ps)
+    dev = torch.device(device)
+    vel_t = torch.tensor(c["vel"], device=dev)
+    velocity = dp.StaggeredGrid.sample(vel_t, domain=domain)
+    p_ext = dp.pressure_extrapolation(domain.boundaries)
+    pressure = dp.CenteredGrid(torch.tensor(c["p"], device=dev)[None, :, :, None], box=domain.box, extrapolation=p_ext)
+    return dict(domain=domain, sim=sim, velocity=velocity, pressure=pressure, lin=lin, ps=ps, vel_tensor=vel_t)

