@@ -1,0 +1,38 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "differentiable-piso_amd"))
+import numpy as np, torch
+from oracle import native as O, piso_ref as R
+from tests.test_gpu_kernels import _laplace_case, dev
+from diffpiso.solvers import cg_solve_native
+
+def apply(L, x, nx, ny, px, py, c):
+    N = nx*ny; L = L.reshape(N,5); X = x.reshape(ny,nx); z = L[:,2]*x
+    def sh(dj,di):
+        Y = np.roll(X,(-dj,-di),(0,1)).copy()
+        if not py:
+            if dj==1: Y[-1,:]=0
+            if dj==-1: Y[0,:]=0
+        if not px:
+            if di==1: Y[:,-1]=0
+            if di==-1: Y[:,0]=0
+        return Y.ravel()
+    z = z + L[:,0]*sh(-1,0) + L[:,1]*sh(0,-1) + L[:,3]*sh(0,1) + L[:,4]*sh(1,0)
+    return z + c*x.sum()
+
+for name, shape, reset in [("periodic",(64,64),10),("xper_ywall",(64,64),10),("xper_ywall",(65,64),1000),("periodic",(40,130),7),("periodic",(33,70),1000),("periodic",(64,64),1000)]:
+    s, L, b = _laplace_case(name, shape[0], shape[1], seed=11)
+    tol=1e-9
+    px, py = s.periodic_yx[1], s.periodic_yx[0]
+    x, it = cg_solve_native(s.nx, s.ny, px, py, dev(L), dev(b), tol, 3000, s.rank_deficient, reset)
+    x = x.cpu().numpy()
+    xo, ito = O.cg_solve(s.nx, s.ny, px, py, L, b, tol, 3000, s.rank_deficient, reset)
+    c = 0.1*np.abs(L.reshape(-1,5)[:,2]).mean() if s.rank_deficient else 0.0
+    r = b - apply(L, x, s.nx, s.ny, px, py, c); ro = b - apply(L, xo, s.nx, s.ny, px, py, c)
+    print(name, shape, reset, "it", it, ito, "maxdiff", np.abs(x-xo).max(), "demeaned", np.abs((x-x.mean())-(xo-xo.mean())).max(),
+          "res", np.abs(r).max(), np.abs(ro).max(), "rankdef", s.rank_deficient)
+    # fixed small iteration counts: trajectories must agree early on
+    for nit in (1,2,3,5,9,10,11,12,20):
+        x, it = cg_solve_native(s.nx, s.ny, px, py, dev(L), dev(b), 1e-30, nit, s.rank_deficient, reset)
+        xo, ito = O.cg_solve(s.nx, s.ny, px, py, L, b, 1e-30, nit, s.rank_deficient, reset)
+        print("   nit", nit, it, ito, "rel diff", np.abs(x.cpu().numpy()-xo).max()/np.abs(xo).max())

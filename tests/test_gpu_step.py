@@ -1,0 +1,119 @@
+"""GPU parity of the composed PISO step (forward + reverse mode, unrolled) through the drop-in API against the oracle.
+Tolerance: 1e-5 relative L2 on fields and back-propagated gradients (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import piso_ref as R
+from tests.cases import make_case, oracle_setup, product_setup
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+TOL = 1e-5
+SOLVER = dict(lin_tol=1e-8, lin_max_it=300, p_tol=1e-9, p_max_it=4000, p_reset=1000)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def run_product_step(c, P, forcing=None, requires_grad=False):
+    import diffpiso as dp
+    vel_t = P["vel_tensor"].clone().requires_grad_(requires_grad)
+    velocity = dp.StaggeredGrid(vel_t, P["velocity"].box, extrapolation=P["velocity"].extrapolation)
+    p_t = P["pressure"].data.clone().requires_grad_(requires_grad)
+    pressure = dp.CenteredGrid(p_t, P["pressure"].box, P["pressure"].extrapolation)
+    inc1 = dp.CenteredGrid(torch.zeros_like(p_t), pressure.box, pressure.extrapolation)
+    inc2 = dp.CenteredGrid(torch.zeros_like(p_t) + 1e-12, pressure.box, pressure.extrapolation)
+    f_t = None
+    if forcing is not None:
+        f_t = torch.tensor(forcing, device=vel_t.device).requires_grad_(requires_grad)
+    v3, pn, warn = dp.piso_step(velocity, pressure, inc1, inc2, c["dt"], P["sim"], torch.tensor(c["dirichlet_values"], device=vel_t.device),
+                                forcing_term=f_t)
+    return vel_t, p_t, f_t, v3, pn, warn
+
+
+@pytest.mark.parametrize("name", ["periodic", "xper_ywall", "cavity", "spatial_ml"])
+@pytest.mark.parametrize("shape", [(16, 12), (24, 40)])
+def test_forward_step_matches_oracle(name, shape):
+    c = make_case(name, shape[0], shape[1], seed=1, variable_viscosity=(name == "spatial_ml"))
+    kw = dict(SOLVER)
+    if name == "cavity":
+        kw["p_tol"] = 1e-7       # above the float32 inconsistency floor of the shifted system (see tests/test_oracle_step.py)
+    s = oracle_setup(c, **kw)
+    P = product_setup(c, **kw)
+    rng = np.random.default_rng(0)
+    forcing = (0.1 * rng.standard_normal(c["vel"].shape)).astype(f32)
+    vo, po, tape = R.piso_step(s, c["vel"], c["p"], c["dt"], c["dirichlet_values"], forcing)
+    _, _, _, v3, pn, warn = run_product_step(c, P, forcing)
+    assert float(warn.sum()) == 0 and not tape["warn"]
+    assert rel(v3.staggered_tensor().cpu().numpy(), vo) < TOL
+    assert rel(pn.data[0, :, :, 0].cpu().numpy(), po) < 5 * TOL      # pressure level ~ solver tolerance * condition number
+    if not s.rank_deficient:      # the shifted operator is indefinite: counts are not reproducible there (test_gpu_kernels.py)
+        assert abs(P["ps"].last_iterations - tape["it2"]) <= 5
+
+
+@pytest.mark.parametrize("name", ["periodic", "xper_ywall", "cavity", "spatial_ml"])
+def test_backward_step_matches_oracle(name):
+    c = make_case(name, 16, 12, seed=4)
+    kw = dict(SOLVER, lin_double=True, lin_tol=1e-10)
+    if name == "cavity":
+        kw["p_tol"] = 1e-6      # stay above the float32 inconsistency floor of the shifted system (tests/test_oracle_step.py)
+    s = oracle_setup(c, **kw)
+    P = product_setup(c, **kw)
+    rng = np.random.default_rng(2)
+    forcing = (0.1 * rng.standard_normal(c["vel"].shape)).astype(f32)
+    valid = np.zeros(c["vel"].shape, f32)
+    valid[0, :, :s.nx, 0] = 1
+    valid[0, :s.ny, :, 1] = 1
+    gv = (rng.standard_normal(c["vel"].shape) * valid).astype(f32)
+    act = s.active[0, 1:-1, 1:-1, 0]
+    gp = rng.standard_normal(c["p"].shape) * act
+    gp = (gp - gp.sum() / act.sum() * act).astype(f32)
+    vo, po, tape = R.piso_step(s, c["vel"], c["p"], c["dt"], c["dirichlet_values"], forcing)
+    go = R.piso_step_backward(s, tape, gv, gp)
+    vel_t, p_t, f_t, v3, pn, warn = run_product_step(c, P, forcing, requires_grad=True)
+    loss = (v3.staggered_tensor() * torch.tensor(gv, device="cuda")).sum() + \
+        (pn.data[0, :, :, 0] * torch.tensor(gp, device="cuda")).sum()
+    loss.backward()
+    # d_p = g_p + G^T(...) cancels to ~1% of |g_p| (the new pressure hardly depends on the old one): measure its error
+    # against the size of the summands, which is what float32 round-off scales with
+    dp_err = np.linalg.norm(p_t.grad[0, :, :, 0].cpu().numpy().astype(np.float64) - go["d_p"]) / \
+        max(np.linalg.norm(go["d_p"]), np.linalg.norm(gp))
+    e = (rel(vel_t.grad.cpu().numpy() * valid, go["d_vel"] * valid), dp_err,
+         rel(f_t.grad.cpu().numpy() * valid, go["d_forcing"] * valid))
+    print("backward rel-L2 (d_vel, d_p, d_forcing):", name, e)
+    tol = 20 * TOL if name == "cavity" else TOL     # cavity: both sides stop at p_tol = 1e-6
+    assert max(e) < tol, e
+
+
+@pytest.mark.parametrize("name,steps,cut", [("periodic", 4, None), ("xper_ywall", 4, 2), ("spatial_ml", 3, None)])
+def test_unrolled_adjoint_matches_oracle(name, steps, cut):
+    import diffpiso as dp
+    c = make_case(name, 16, 16, seed=6)
+    kw = dict(SOLVER, lin_double=True, lin_tol=1e-10)
+    s = oracle_setup(c, **kw)
+    P = product_setup(c, **kw)
+    vels, ps, tapes = R.run_steps(s, c["vel"], c["p"], c["dt"], c["dirichlet_values"], steps)
+    vel_t = P["vel_tensor"].clone().requires_grad_(True)
+    velocity = dp.StaggeredGrid(vel_t, P["velocity"].box, extrapolation=P["velocity"].extrapolation)
+    p_t = P["pressure"].data.clone().requires_grad_(True)
+    pressure = dp.CenteredGrid(p_t, P["pressure"].box, P["pressure"].extrapolation)
+    va, pa, vn, pn, warn = dp.run_piso_steps(velocity, pressure, c["dt"], P["sim"], step_count=steps, loss_influence_range=cut)
+    assert rel(vn.staggered_tensor().detach().cpu().numpy(), vels[-1]) < TOL
+    loss = 0.5 * (vn.staggered_tensor() ** 2).sum()                 # L = 1/2 ||u_N||^2
+    loss.backward()
+    if cut is None:
+        d_vel, d_p, _ = R.run_steps_backward(s, tapes, vels[-1], np.zeros_like(ps[-1]))
+    else:   # gradient cut every `cut` steps: only the last segment contributes (combined_training_integrated.py:436-438)
+        first = (steps - 1) // cut * cut
+        d_vel, d_p, _ = R.run_steps_backward(s, tapes[first:], vels[-1], np.zeros_like(ps[-1]))
+        if first > 0:
+            d_vel, d_p = d_vel * 0, d_p * 0
+    if cut is None or (steps - 1) // cut * cut == 0:
+        e = (rel(vel_t.grad.cpu().numpy(), d_vel), rel(p_t.grad[0, :, :, 0].cpu().numpy(), d_p))
+        print("unrolled backward rel-L2 (d_vel, d_p):", name, steps, e)
+        assert max(e) < 2 * TOL, e
+    else:
+        assert vel_t.grad is None or float(vel_t.grad.abs().max()) == 0.0
