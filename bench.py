@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py -- PISO steps/s (forward + adjoint) on a 2048^2 doubly periodic decaying-turbulence grid, MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
+torch.distributed.run with one rank per GPU.  One "step" = one PISO step (implicit predictor + two pressure correctors)
+forward AND its reverse-mode sweep: the timed region unrolls K steps forward, then back-propagates L = 1/2 |u_K|^2 through
+all K steps (the reference's training pattern, diffpiso/combined_training_integrated.py:396-478).  Inputs are synthetic
+(random solenoidal velocity with E(k) ~ k^4 exp(-(k/8)^2), seed 0, u_rms = 1, nu = 1e-3, CFL 0.5, p0 = 0) and
+resident in HBM before the clock starts.  Solver settings are the reference's training settings: tolerance 1e-6,
+max_iterations 10000, CG residual_reset 1000, pressure solve fp64, advection solve fp32.
+
+Multi-GPU (round 1): "replicas only" -- every rank runs the same independent 2048^2 problem, no data-path collective
+(DESIGN.md "Multi-GPU"); value = N * K / max-over-ranks time, scaling "weak".
+
+One JSON line on stdout (rank 0).  Extra objects: `roofline` (dominant kernel = CG K1, HIP-event timed inside the timed
+region) and `cpu_baseline` (the C oracle on a bounded sample of the same workload, rank 0, N = 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+K1_BYTES_PER_CELL = 80.0     # algorithmic bytes of K1 per cell per launch: 5 matrix + 2 SpMV + 3 p-update words of 8 B
+K2_BYTES_PER_CELL = 48.0     # algorithmic bytes of K2: 3 (x) + 3 (r) words of 8 B     (128 B in total)
+
+
+def turbulence_velocity(n, seed=0, k0=8.0):
+    """Curl of a random stream function with E(k) ~ k^4 exp(-(k/k0)^2), sampled on faces, u_rms = 1."""
+    rng = np.random.default_rng(seed)
+    kx = np.fft.fftfreq(n, 1.0 / n)
+    ky = np.fft.fftfreq(n, 1.0 / n)
+    KX, KY = np.meshgrid(kx, ky, indexing="xy")
+    k = np.sqrt(KX ** 2 + KY ** 2)
+    k[0, 0] = 1.0
+    E = k ** 4 * np.exp(-(k / k0) ** 2)
+    amp = np.sqrt(E) / k
+    psi_hat = amp * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    psi_hat[0, 0] = 0
+    psi = np.real(np.fft.ifft2(psi_hat))            # stream function on cell corners (periodic)
+    h = 2 * np.pi / n
+    u = (np.roll(psi, -1, axis=0) - psi) / h        # u = d(psi)/dy on x-faces   [n, n]
+    v = -(np.roll(psi, -1, axis=1) - psi) / h       # v = -d(psi)/dx on y-faces  [n, n]
+    s = 1.0 / np.sqrt(0.5 * (np.mean(u ** 2) + np.mean(v ** 2)))
+    t = np.zeros((1, n + 1, n + 1, 2), np.float32)
+    t[0, :n, :n, 1] = u * s
+    t[0, :n, n, 1] = u[:, 0] * s                    # duplicate periodic face
+    t[0, :n, :n, 0] = v * s
+    t[0, n, :n, 0] = v[0, :] * s
+    return t
+
+
+def build_problem(n, device, tol, max_it, reset):
+    import torch
+    import diffpiso as dp
+    L = 2 * np.pi
+    domain = dp.Domain([n, n], boundaries=dp.PERIODIC, box=dp.box[0:L, 0:L])
+    ones = np.ones((1, n + 2, n + 2, 1), np.float32)
+    st = (1, n + 1, n + 1, 2)
+    lin = dp.LinearSolverCudaMultiBicgstabILU(accuracy=tol, max_iterations=max_it, cast_to_double=False)
+    ps = dp.PisoPressureSolverCudaCustom(dx=[], accuracy=tol, max_iterations=max_it, residual_reset=reset, cast_to_double=True)
+    sim = dp.SimulationParameters(dirichlet_mask=np.zeros(st, bool), dirichlet_values=np.zeros(st, np.float32),
+                                  active_mask=ones, accessible_mask=ones, bool_periodic=(True, True), no_slip_mask=None,
+                                  viscosity=1e-3, linear_solver=lin, pressure_solver=ps)
+    vel = turbulence_velocity(n)
+    dx = L / n
+    dt = 0.5 * dx / float(np.abs(vel).max())
+    vel_t = torch.tensor(vel, device=device)
+    p_t = torch.zeros((1, n, n, 1), device=device)
+    dv = torch.zeros(st, device=device)
+    sim.dirichlet_values = dv
+    return dict(domain=domain, sim=sim, vel=vel, vel_t=vel_t, p_t=p_t, dt=dt, lin=lin, ps=ps)
+
+
+def run_unrolled(P, steps, stats=None):
+    """K steps forward, then the reverse sweep of L = 1/2 |u_K|^2."""
+    import diffpiso as dp
+    vel_t = P["vel_t"].clone().requires_grad_(True)
+    p_t = P["p_t"].clone().requires_grad_(True)
+    ext = dp.Material.extrapolation_mode(P["domain"].boundaries)
+    velocity = dp.StaggeredGrid(vel_t, P["domain"].box, extrapolation=ext)
+    pressure = dp.CenteredGrid(p_t, P["domain"].box, dp.pressure_extrapolation(P["domain"].boundaries))
+    cg_fwd, cg_adj, bi_fwd, bi_adj = [], [], [], []
+
+    class Hook(object):
+        pass
+
+    vels, ps, vn, pn, warn = dp.run_piso_steps(velocity, pressure, P["dt"], P["sim"], step_count=steps)
+    loss = 0.5 * (vn.staggered_tensor() ** 2).sum()
+    loss.backward()
+    return vel_t.grad, float(loss.detach()), warn
+
+
+def cpu_baseline(P, n, tol, cg_iters_per_step, sample_iters=12):
+    """The C oracle (a port, single thread) on a bounded sample of the SAME 2048^2 workload: one matrix assembly, one
+    forward BiCGStab(ILU0) solve and `sample_iters` CG iterations are timed; a step is priced as
+    assembly x2 + BiCGStab x2 + (CG iterations per fwd+adjoint step observed on the GPU) x time per CG iteration."""
+    from oracle import native as O, piso_ref as R
+    s = R.OracleSetup(n, n, (2 * np.pi / n,) * 2, (True, True), np.zeros((1, n + 1, n + 1, 2), bool),
+                      np.ones((1, n + 2, n + 2, 1), np.float32), np.ones((1, n + 2, n + 2, 1), np.float32),
+                      viscosity=1e-3, lin_tol=tol, lin_max_it=100, p_tol=tol)
+    vel = P["vel"]
+    beta = (2 * np.pi / n) ** 2 / P["dt"]
+    t0 = time.perf_counter()
+    val, rp, col, A_t, A_flat = R.advection_matrix(s, vel, beta)
+    t_asm = time.perf_counter() - t0
+    rhs = (R.flatten_staggered(vel, True) * np.float32(beta)).astype(np.float32)
+    t0 = time.perf_counter()
+    x, warn, its = O.multi_bicgstab_ilu(-val, rp, col, rhs, R.flatten_staggered(vel, True), s.n_u, s.n_v, tol, 100)
+    t_bicg = time.perf_counter() - t0
+    a0 = ((np.float32(1) / (np.float32(beta) - A_t)) * np.float32(1.0)).astype(np.float32)
+    L = O.laplace_matrix(n, n, s.active, s.accessible, R.flatten_staggered(a0, False))
+    div = R.fv_divergence(R.stagger_flattened(x, n, n, True), s.dx_yx).astype(np.float64).ravel()
+    t0 = time.perf_counter()
+    O.cg_solve(n, n, True, True, L, div, 1e-30, sample_iters, True, 1000)
+    t_cg_iter = (time.perf_counter() - t0) / sample_iters
+    step_s = 2 * t_asm + 2 * t_bicg + cg_iters_per_step * t_cg_iter
+    return dict(value=1.0 / step_s, unit="PISO steps/s (fwd+adjoint) at %d^2" % n, cores=1, kind="port",
+                sample=("C oracle, 1 thread, %d^2: 1 assembly (%.2fs) + 1 BiCGStab-ILU0 solve (%.2fs, %s its) + %d CG iterations "
+                        "(%.3fs each) timed; step priced as 2*assembly + 2*BiCGStab + %d CG iterations (the count per fwd+adjoint "
+                        "step observed on the GPU)") % (n, t_asm, t_bicg, its, sample_iters, t_cg_iter, cg_iters_per_step))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=2048)
+    ap.add_argument("--tol", type=float, default=1e-6)
+    ap.add_argument("--max-iterations", type=int, default=10000)
+    ap.add_argument("--residual-reset", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the PISO path has no CPU fallback (libpiso_hip.so is the product)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+
+    import diffpiso._native as N
+    n = args.grid
+    P = build_problem(n, device, args.tol, args.max_iterations, args.residual_reset)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_unrolled(P, 1)
+    N.lib.piso_cg_profile_enable(1, 16)              # HIP-event sampling of every 16th K1 / K2 launch
+    cg_calls = []
+    orig = N.lib.piso_cg_solve_f64
+    barrier()
+    t0 = time.perf_counter()
+    grad, loss, warn = run_unrolled(P, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms_sum = (C.c_double * 2)()
+    cnt = (C.c_longlong * 2)()
+    N.lib.piso_cg_profile_read(ms_sum, cnt)
+    N.lib.piso_cg_profile_enable(0, 16)
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ncell = float(n) * n
+        k1_ms = ms_sum[0] / max(cnt[0], 1)
+        k2_ms = ms_sum[1] / max(cnt[1], 1)
+        achieved = K1_BYTES_PER_CELL * ncell / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        k2_gbs = K2_BYTES_PER_CELL * ncell / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
+        cg_it = P["ps"].last_iterations or 0
+        cg_it_adj = P["ps"].last_adjoint_iterations or 0
+        out = {
+            "metric": "PISO steps/s (fwd+adjoint) at %d^2 staggered grid" % n,
+            "value": world * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "2-D decaying isotropic turbulence %d^2 periodic, PISO step fwd + reverse-mode, "
+                                   "unrolled %d steps, tol %g, max_it %d, CG reset %d, pressure fp64 / advection fp32, "
+                                   "%s" % (n, args.steps, args.tol, args.max_iterations, args.residual_reset,
+                                           "replicas only (one independent grid per GPU)" if world > 1 else "1 GPU"),
+                       "grid": [n, n], "last_cg_iterations_fwd": cg_it, "last_cg_iterations_adjoint": cg_it_adj,
+                       "last_bicgstab_iterations": list(P["lin"].last_iterations or ()),
+                       "loss": loss, "warn": float(sum(float(w.sum()) for w in warn))},
+            "roofline": {"bound": "hbm", "kernel": "cg_k1 (fused p-update + 5-point stencil + dots, fp64)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_ms": k1_ms, "launches_sampled": int(cnt[0]),
+                         "algorithmic_bytes_per_launch": K1_BYTES_PER_CELL * ncell,
+                         "k2": {"achieved": k2_gbs, "avg_launch_ms": k2_ms, "frac": k2_gbs / HBM_PEAK_GBS,
+                                "algorithmic_bytes_per_launch": K2_BYTES_PER_CELL * ncell}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            per_step = 2 * (cg_it + cg_it_adj) if cg_it else 4000
+            try:
+                out["cpu_baseline"] = cpu_baseline(P, n, args.tol, per_step)
+            except Exception as e:   # the baseline must never sink the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
