@@ -170,7 +170,9 @@ def finite_volume_gradient_tensor(centered_field, sim_physics=None):
 # ---------------------------------------------------------------------------------------------------- divergence
 class _Divergence(torch.autograd.Function):
     """custom_divergence (diffpiso/piso_helpers.py:285-306).  Backward = the reference's formula, whose periodic branch
-    feeds face 0 with dc[N-2] instead of dc[N-1] (slice(-2,-1), App. C-7)."""
+    wraps the cell gradient onto the first / duplicate face and feeds face 0 with dc[N-2] instead of dc[N-1]
+    (slice(-2,-1), App. C-7).  The exact transpose of the forward pass (every face, duplicate included, is an independent
+    input) is the zero-padded difference of the non-periodic branch; REFERENCE_ADJOINTS = False selects it everywhere."""
 
     @staticmethod
     def forward(ctx, staggered_tensor, dx_y, dx_x, per_y, per_x):
@@ -186,9 +188,9 @@ class _Divergence(torch.autograd.Function):
         comps = []
         for dim, h, per in ((1, dx_y, per_y), (2, dx_x, per_x)):
             n = dc.shape[dim]
-            if per:
+            if per and REFERENCE_ADJOINTS:
                 first = dc.narrow(dim, 0, 1)
-                last = dc.narrow(dim, n - 2, 1) if REFERENCE_ADJOINTS else dc.narrow(dim, n - 1, 1)
+                last = dc.narrow(dim, n - 2, 1)
                 r = -torch.cat([dc, first], dim=dim) * dxdy / h + torch.cat([last, dc], dim=dim) * dxdy / h
             else:
                 z = torch.zeros_like(dc.narrow(dim, 0, 1))

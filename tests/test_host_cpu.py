@@ -1,0 +1,151 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads and exports every symbol include/piso_hip.h declares,
+the torch glue (layout, padding, stencils, custom adjoints) reproduces the golden vectors of the reference's own Python
+helpers, and the solver entry points refuse to run without a GPU (no silent fallback)."""
+import ast
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import diffpiso as dp
+from diffpiso import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = ["periodic", "xper_ywall", "open", "spatial_ml", "closed"]
+TOL = dict(rtol=2e-6, atol=2e-6)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "piso_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(piso_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 14, names
+    lib = ctypes.CDLL(N.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(lib, n), "libpiso_hip.so does not export %s" % n
+    assert b"gfx950" in N.lib.piso_version()
+
+
+def test_workspace_queries_and_nnz_closed_form():
+    assert N.lib.piso_cg_workspace_bytes(2048, 2048, 8) > 9 * 2048 * 2048 * 8
+    assert N.lib.piso_bicgstab_workspace_bytes(64, 64, 4) > 18 * (65 * 64 + 64 * 65) * 4
+    for (nx, ny, px, py) in [(4, 3, 1, 1), (4, 3, 0, 0), (64, 65, 0, 0), (256, 256, 1, 1), (512, 256, 1, 0)]:
+        a, b = ctypes.c_int(), ctypes.c_int()
+        N.lib.piso_csr_nnz(nx, ny, px, py, ctypes.byref(a), ctypes.byref(b))
+        from oracle.native import matrix_sizes
+        assert (a.value, b.value) == matrix_sizes(nx, ny, px, py)[2:]
+    a, b = ctypes.c_int(), ctypes.c_int()
+    N.lib.piso_csr_nnz(64, 65, 0, 0, ctypes.byref(a), ctypes.byref(b))
+    assert (a.value, b.value) == (20865, 20860)           # SURVEY.md section 8 table, LDC 64
+
+
+def test_no_cpu_fallback():
+    """Solver calls with CPU tensors must fail loudly, never compute."""
+    lin = dp.LinearSolverCudaMultiBicgstabILU()
+    t = torch.zeros(10)
+    with pytest.raises(N.PisoNativeError):
+        lin.solve(t, t.int(), t.int(), t, (1, 5, 5, 2))
+    if not torch.cuda.is_available():
+        bad = N.lib.piso_cg_solve_f64(8, 8, 1, 1, None, None, None, ctypes.c_float(1e-3), 10, 1, 10, None, None, 0, None)
+        assert bad != 0
+
+
+def _load(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, "helpers_%s.npz" % name))
+    vel_ext = ast.literal_eval(str(d["velocity_extrapolation"]))
+    p_ext = ast.literal_eval(str(d["pressure_extrapolation"]))
+    ny, nx = d["resolution"]
+    dy, dx = d["dx_yx"]
+    box = dp.box[0:dy * ny, 0:dx * nx]
+    vel = dp.StaggeredGrid(torch.tensor(d["vel_in"]), box, extrapolation=vel_ext)
+    p = dp.CenteredGrid(torch.tensor(d["p_in"]), box, extrapolation=p_ext)
+    return d, vel, p
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_glue_layout_against_reference_golden(golden_dir, name):
+    d, vel, p = _load(golden_dir, name)
+    ny, nx = d["resolution"]
+    np.testing.assert_array_equal(vel.staggered_tensor().numpy(), d["vel_tensor"])
+    np.testing.assert_array_equal(dp.flatten_staggered_data(vel, True).numpy(), d["flat_ufirst"])
+    np.testing.assert_array_equal(dp.flatten_staggered_data(vel, False).numpy(), d["flat_vfirst"])
+    st = (1, ny + 1, nx + 1, 2)
+    np.testing.assert_array_equal(dp.stagger_flattened_data(torch.tensor(d["flat_ufirst"]), st, True).numpy(), d["restagger_ufirst"])
+    np.testing.assert_array_equal(dp.stagger_flattened_data(torch.tensor(d["flat_vfirst"]), st, False).numpy(), d["restagger_vfirst"])
+    np.testing.assert_array_equal(dp.padded_velocity_flat(vel).numpy(), d["vel_padded_flat"])
+    v_pad, u_pad = dp.custom_padded(vel, 1)
+    assert tuple(u_pad.shape) == tuple(d["padded_u_shape"]) and tuple(v_pad.shape) == tuple(d["padded_v_shape"])
+    got = dp.arrange_rhs_term_tf(torch.tensor(d["rhs_in"]), d["dirichlet_mask"], d["dirichlet_values"], 1.0, coord_flip=True)
+    np.testing.assert_allclose(got.numpy(), d["rhs_arranged"], **TOL)
+
+
+class _Sim(object):
+    def __init__(self, acc):
+        self.acc = torch.tensor(acc)
+
+    def accessible_mask_tensor(self, device):
+        return self.acc
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_glue_stencils_and_custom_adjoints_against_reference_golden(golden_dir, name):
+    d, vel, p = _load(golden_dir, name)
+    ny, nx = d["resolution"]
+    np.testing.assert_allclose(dp.finite_volume_gradient_tensor(p, _Sim(d["accessible_mask"])).numpy(), d["fv_gradient_masked"], **TOL)
+    np.testing.assert_allclose(dp.finite_volume_gradient_tensor(p, None).numpy(), d["fv_gradient_nomask"], **TOL)
+    t = torch.tensor(d["vel_in"]).requires_grad_(True)
+    v = dp.StaggeredGrid(t, vel.box, extrapolation=vel.extrapolation)
+    div = dp.finite_volume_divergence(v)
+    np.testing.assert_allclose(div.detach().numpy(), d["fv_divergence"], **TOL)
+    div.backward(torch.tensor(d["div_adj_in"]))
+    np.testing.assert_allclose(t.grad.numpy(), d["div_adj_out"], **TOL)     # includes the reference's periodic quirk (C-7)
+    for dim in (1, 2):
+        key = "circ_grad_adj_in_dim%d" % dim
+        if key in d.files:                                                  # C-8: TF-semantics custom gradient
+            from diffpiso.stencils import _PeriodicAxisGradient
+            q = torch.tensor(d["p_in"]).requires_grad_(True)
+            out = _PeriodicAxisGradient.apply(q, dim)
+            np.testing.assert_allclose(out.detach().numpy(), d["circ_grad_fwd_dim%d" % dim], **TOL)
+            out.backward(torch.tensor(d[key]))
+            np.testing.assert_allclose(q.grad.numpy(), d["circ_grad_adj_out_dim%d" % dim], **TOL)
+
+
+def test_exact_adjoint_switch_is_a_true_transpose():
+    from diffpiso import stencils
+    dom = dp.Domain([6, 5], boundaries=dp.PERIODIC)
+    rng = np.random.default_rng(0)
+    stencils.REFERENCE_ADJOINTS = False
+    try:
+        t = torch.tensor(rng.standard_normal((1, 7, 6, 2)).astype(np.float32))
+        t[0, :, 5, 0] = 0
+        t[0, 6, :, 1] = 0
+        t.requires_grad_(True)
+        div = dp.finite_volume_divergence(dp.StaggeredGrid(t, dom.box, extrapolation="periodic"))
+        g = torch.tensor(rng.standard_normal(tuple(div.shape)).astype(np.float32))
+        div.backward(g)
+        dt = torch.tensor(rng.standard_normal((1, 7, 6, 2)).astype(np.float32))
+        dt[0, :, 5, 0] = 0
+        dt[0, 6, :, 1] = 0
+        lhs = float((dp.finite_volume_divergence(dp.StaggeredGrid(dt, dom.box, extrapolation="periodic")) * g).sum())
+        rhs = float((t.grad * dt).sum())
+        assert abs(lhs - rhs) < 1e-4 * max(1, abs(lhs))
+    finally:
+        stencils.REFERENCE_ADJOINTS = True
+
+
+def test_field_shim_matches_phiflow_conventions(golden_dir):
+    d = np.load(os.path.join(golden_dir, "mixing_layer_masks.npz"))
+    assert list(dp.calculate_staggered_shape(1, np.array([6, 9]))) == list(d["calc_staggered_shape"])
+    assert list(dp.calculate_centered_shape(1, np.array([6, 9]))) == list(d["calc_centered_shape"])
+    dom = dp.Domain([6, 9], boundaries=((dp.OPEN, dp.OPEN), (dp.OPEN, dp.CLOSED)), box=dp.box[0:6, 0:9])
+    assert dp.Material.extrapolation_mode(dom.boundaries) == ("constant", ("constant", "boundary"))
+    assert dp.pressure_extrapolation(dom.boundaries) == ("boundary", ("boundary", "constant"))
+    assert dp.pressure_extrapolation(dp.Domain([4, 4], boundaries=dp.PERIODIC).boundaries) == "periodic"
+    assert dp.Domain([4, 5], boundaries=(dp.CLOSED, dp.PERIODIC)).boundaries == (dp.CLOSED, dp.PERIODIC)
+    g = dom.staggered_grid(1.0)
+    assert tuple(g.staggered_tensor().shape) == (1, 7, 10, 2)
+    assert float(g.staggered_tensor()[0, :, 9, 0].abs().sum()) == 0
+    assert np.allclose(dom.dx, [1.0, 1.0])
