@@ -29,8 +29,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-K1_BYTES_PER_CELL = 80.0     # algorithmic bytes of K1 per cell per launch: 5 matrix + 2 SpMV + 3 p-update words of 8 B
-K2_BYTES_PER_CELL = 48.0     # algorithmic bytes of K2: 3 (x) + 3 (r) words of 8 B     (128 B in total)
+# 128 B per cell per CG iteration = 16 fp64 words: matrix 5, SpMV 2, x update 3, r update 3, p update 3.
+K1_BYTES_PER_CELL = 104.0    # K1 covers matrix 5 + SpMV 2 + p update 3 + x update 3 words (it adds the previous direction to x)
+K2_BYTES_PER_CELL = 24.0     # K2 covers the r update: 3 words
 
 
 def turbulence_velocity(n, seed=0, k0=8.0):
@@ -88,11 +89,6 @@ def run_unrolled(P, steps, stats=None):
     ext = dp.Material.extrapolation_mode(P["domain"].boundaries)
     velocity = dp.StaggeredGrid(vel_t, P["domain"].box, extrapolation=ext)
     pressure = dp.CenteredGrid(p_t, P["domain"].box, dp.pressure_extrapolation(P["domain"].boundaries))
-    cg_fwd, cg_adj, bi_fwd, bi_adj = [], [], [], []
-
-    class Hook(object):
-        pass
-
     vels, ps, vn, pn, warn = dp.run_piso_steps(velocity, pressure, P["dt"], P["sim"], step_count=steps)
     loss = 0.5 * (vn.staggered_tensor() ** 2).sum()
     loss.backward()
@@ -167,8 +163,6 @@ def main():
     for _ in range(args.warmup):
         run_unrolled(P, 1)
     N.lib.piso_cg_profile_enable(1, 16)              # HIP-event sampling of every 16th K1 / K2 launch
-    cg_calls = []
-    orig = N.lib.piso_cg_solve_f64
     barrier()
     t0 = time.perf_counter()
     grad, loss, warn = run_unrolled(P, args.steps)
@@ -189,6 +183,12 @@ def main():
         k2_ms = ms_sum[1] / max(cnt[1], 1)
         achieved = K1_BYTES_PER_CELL * ncell / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         k2_gbs = K2_BYTES_PER_CELL * ncell / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
+        traffic = None
+        try:   # measured offline with rocprofv3 PMC passes of this same workload (profiles/traffic.json)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = tj[str(n)]["cg_k1"]["bytes"]
+        except Exception:
+            pass
         cg_it = P["ps"].last_iterations or 0
         cg_it_adj = P["ps"].last_adjoint_iterations or 0
         out = {
@@ -202,10 +202,10 @@ def main():
                                            "replicas only (one independent grid per GPU)" if world > 1 else "1 GPU"),
                        "grid": [n, n], "last_cg_iterations_fwd": cg_it, "last_cg_iterations_adjoint": cg_it_adj,
                        "last_bicgstab_iterations": list(P["lin"].last_iterations or ()),
-                       "loss": loss, "warn": float(sum(float(w.sum()) for w in warn))},
-            "roofline": {"bound": "hbm", "kernel": "cg_k1 (fused p-update + 5-point stencil + dots, fp64)",
+                       "loss": loss, "warn": float(sum(float(w.detach().sum()) for w in warn))},
+            "roofline": {"bound": "hbm", "kernel": "cg_k1 (fused x/p update + 5-point stencil + dots, fp64)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": k1_ms, "launches_sampled": int(cnt[0]),
+                         "traffic": traffic, "avg_launch_ms": k1_ms, "launches_sampled": int(cnt[0]),
                          "algorithmic_bytes_per_launch": K1_BYTES_PER_CELL * ncell,
                          "k2": {"achieved": k2_gbs, "avg_launch_ms": k2_ms, "frac": k2_gbs / HBM_PEAK_GBS,
                                 "algorithmic_bytes_per_launch": K2_BYTES_PER_CELL * ncell}},

@@ -17,6 +17,8 @@
 //
 // Traffic per cell and iteration with fp64 vectors: K1 reads r, p, 5 coefficients, writes p, z' (9 words), K2 reads
 // p, z', x, r, writes x, r (6 words) = 120 B against the 128 B "algorithmic" figure of SURVEY.md 8(d).
+#include <stdlib.h>
+
 #include "piso_common.h"
 
 namespace piso {
@@ -30,11 +32,12 @@ struct CgState {
 };
 
 enum { MODE_NORMAL = 0, MODE_INIT = 1, MODE_RESET = 2 };
-enum { SC_C = 0, SC_PZ = 1, SC_VS = 2, SC_COUNT = 8 };
+enum { SC_C = 0, SC_PZ = 1, SC_VS = 2, SC_ALPHA = 3, SC_COUNT = 8 };
 
 template <typename T>
 struct CgArgs {
-  const T *cS, *cW, *cC, *cE, *cN;   // SoA stencil coefficients
+  const T* cC;                       // SoA stencil coefficients: diagonal in T,
+  const void *oS, *oW, *oE, *oN;     //   off-diagonals in the kernel's CT (float when exactly representable, else T)
   const T* b;
   T *x, *r, *z;
   T* p[2];                           // ping-pong search direction
@@ -45,6 +48,7 @@ struct CgArgs {
   CgState* state;                    // [2]
   int nx, ny, per_x, per_y;
   int ntx, nty, rows_per_wave;
+  int nA, nB;                        // blocks (= partial records) of K1 / K2
   float accuracy;
 };
 
@@ -53,28 +57,48 @@ struct Vec {
   T v[V];
 };
 
-template <typename T, int V>
-__device__ __forceinline__ Vec<T, V> ldv(const T* __restrict__ p) {
-  Vec<T, V> o;
-  if constexpr (V == 1) {
-    o.v[0] = p[0];
+// V elements of S from / to an address aligned to min(16, sizeof(S) * V) bytes; 16-byte lane accesses wherever possible
+template <typename S, int V>
+__device__ __forceinline__ Vec<S, V> ldc(const S* __restrict__ p) {
+  Vec<S, V> o;
+  constexpr int B = sizeof(S) * V;
+  using raw4 = __attribute__((ext_vector_type(4))) unsigned int;
+  using raw2 = __attribute__((ext_vector_type(2))) unsigned int;
+  if constexpr (B % 16 == 0) {
+#pragma unroll
+    for (int q = 0; q < B / 16; ++q) {
+      const raw4 t = reinterpret_cast<const raw4*>(p)[q];
+      __builtin_memcpy(reinterpret_cast<char*>(&o) + 16 * q, &t, 16);
+    }
+  } else if constexpr (B == 8) {
+    const raw2 t = *reinterpret_cast<const raw2*>(p);
+    __builtin_memcpy(&o, &t, 8);
   } else {
-    static_assert(sizeof(T) * V == 16, "16-byte vectors only");
-    using raw = __attribute__((ext_vector_type(4))) unsigned int;
-    const raw t = *reinterpret_cast<const raw*>(p);
-    __builtin_memcpy(&o, &t, 16);
+    static_assert(V == 1, "unsupported vector width");
+    o.v[0] = p[0];
   }
   return o;
 }
 template <typename T, int V>
+__device__ __forceinline__ Vec<T, V> ldv(const T* __restrict__ p) { return ldc<T, V>(p); }
+template <typename T, int V>
 __device__ __forceinline__ void stv(T* __restrict__ p, const Vec<T, V>& o) {
-  if constexpr (V == 1) {
-    p[0] = o.v[0];
+  constexpr int B = sizeof(T) * V;
+  using raw4 = __attribute__((ext_vector_type(4))) unsigned int;
+  using raw2 = __attribute__((ext_vector_type(2))) unsigned int;
+  if constexpr (B % 16 == 0) {
+#pragma unroll
+    for (int q = 0; q < B / 16; ++q) {
+      raw4 t;
+      __builtin_memcpy(&t, reinterpret_cast<const char*>(&o) + 16 * q, 16);
+      reinterpret_cast<raw4*>(p)[q] = t;
+    }
+  } else if constexpr (B == 8) {
+    raw2 t;
+    __builtin_memcpy(&t, &o, 8);
+    *reinterpret_cast<raw2*>(p) = t;
   } else {
-    using raw = __attribute__((ext_vector_type(4))) unsigned int;
-    raw t;
-    __builtin_memcpy(&t, &o, 16);
-    *reinterpret_cast<raw*>(p) = t;
+    p[0] = o.v[0];
   }
 }
 
@@ -82,117 +106,218 @@ template <typename T>
 __device__ __forceinline__ T absval(T v) { return v < 0 ? -v : v; }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K1: fused direction update + stencil + dots.  One wave owns a strip of 64*V columns and walks `rows_per_wave` rows
-// keeping three rows of the NEW direction in registers; x-neighbours come from lane shuffles, strip-edge columns from
-// two extra scalar loads.  Tiles are dealt to blocks XCD-contiguously so halo rows hit the same L2.
-//   mode NORMAL: p_new = r + beta p_old, beta from K2's partials          (pressure_solve_op.cu.cc:345-354)
-//        INIT  : p_new = r                                                  (initVariablesWithGuess, :104-114)
-//        RESET : apply the operator to x (no direction update; z' = L x, partial sum(x))   (:260-274)
-//   do_check : this launch is the first of iteration k and evaluates the stopping test of iteration k-1 (:312-335)
+// Prologue shared by K1 / K2: every block reduces the previous kernel's partial records.  Only wave 0 does the loads,
+// the other waves go straight to their first data loads and meet wave 0 at the barrier, so the L2 round trip of the
+// reduction overlaps the first HBM loads of the body.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int V>
-__global__ __launch_bounds__(kBlock) void cg_k1(CgArgs<T> a, int k, int mode, int sv, int do_check) {
-  __shared__ T smem[16];
-  const CgState st = a.state[sv & 1];
-  const bool writes_state = do_check || mode == MODE_RESET;
-
-  T beta = 0;
-  CgState nst = st;
-  if (do_check && !st.done) {
-    T pb[2];
-    reduce_partials<T, 2>(a.partsB, kMaxPartials, pb, smem);           // r.z', sum r
+template <typename T, int NV, bool WITH_MAX>
+__device__ __forceinline__ void prologue_reduce(const T* __restrict__ parts, int count, T (&sum)[NV], T& mx, T* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave == 0) {
+    T s[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) s[q] = 0;
     T m = 0;
-    for (int b = threadIdx.x; b < kMaxPartials; b += kBlock) m = nanmax(m, a.partsB[2 * kMaxPartials + b]);
-    m = block_max_nan(m, smem);
-    if (k > 0 && (k % 5) == 0) {
-      const int exceeded = !(m < (T)a.accuracy);     // checkResiduum (:94-102) clears the flag if any |r| >= accuracy
-      if (st.flag && !exceeded) { nst.done = 1; nst.iterations = k; }
-      else nst.flag = 1;                             // cudaMemset(threshold_reached, 1) after a failed test (:334)
+    for (int b = lane; b < count; b += 64) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) s[q] += parts[q * kMaxPartials + b];
+      if (WITH_MAX) m = nanmax(m, parts[NV * kMaxPartials + b]);
     }
-    if (mode == MODE_NORMAL) {
-      const T pz = a.scal[SC_PZ], vs = a.scal[SC_VS];
-      beta = -(pb[0] + vs * pb[1]) / pz;             // -r.z / p.z, unguarded as coded (:351-352)
+#pragma unroll
+    for (int q = 0; q < NV; ++q) s[q] = wave_sum(s[q]);
+    if (WITH_MAX) m = wave_max_nan(m);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < NV; ++q) smem[q] = s[q];
+      smem[NV] = m;
     }
   }
-  if (mode == MODE_RESET && !nst.done) nst.flag = 0; // initVariablesWithGuess clears the device flag
-  // the state always moves to the next version slot, also once done (later launches read that slot)
-  if (writes_state && blockIdx.x == 0 && threadIdx.x == 0) a.state[(sv + 1) & 1] = nst;
-  if (nst.done) return;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NV; ++q) sum[q] = smem[q];
+  mx = smem[NV];
+  __syncthreads();          // smem is reused by the epilogue reduction
+}
 
+// ---------------------------------------------------------------------------------------------------------------
+// K1: fused direction update + stencil + dots (+ the x update of the PREVIOUS iteration, whose direction it reads anyway).
+// One wave owns a strip of 64*V columns and walks `rows_per_wave` rows keeping three rows of the NEW direction in
+// registers; x-neighbours come from lane shuffles, strip-edge columns from two extra scalar loads.  Tiles are dealt to
+// blocks XCD-contiguously so halo rows hit the same L2; odd waves walk their rows downwards so that the row shared with
+// the neighbouring wave is touched by both at about the same time.
+//   mode NORMAL: p_new = r + beta p_old (beta from K2's partials), x += alpha_prev p_old   (pressure_solve_op.cu.cc:302-303, 345-354)
+//        INIT  : p_new = r                                                                  (initVariablesWithGuess, :104-114)
+//        RESET : apply the operator to x (z' = L x, partial sum(x)); x was flushed by the host beforehand   (:260-274)
+//   do_check : this launch is the first of iteration k and evaluates the stopping test of iteration k-1 (:312-335)
+//   pending  : a direction of the previous iteration still has to be added to x (false right after INIT / RESET)
+// CT = storage type of the off-diagonals; RECON = the diagonal is recomputed as -(S + N + W + E) (setup verified that this
+// reproduces the stored fp64 diagonal bit for bit) instead of being read.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, typename CT, int V, bool RECON>
+__global__ __launch_bounds__(kBlock) void cg_k1(CgArgs<T> a, int k, int mode, int sv, int do_check, int pending) {
+  __shared__ T smem[16];
+  const bool writes_state = do_check || mode == MODE_RESET;
   const int nx = a.nx, ny = a.ny;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const T* __restrict__ pin = a.p[k & 1];
   T* __restrict__ pout = a.p[(k + 1) & 1];
   const T* __restrict__ src = (mode == MODE_RESET) ? a.x : a.r;
+  const bool use_pin = (mode == MODE_NORMAL);      // RESET reads a fully updated x (the host flushes it first)
 
-  // new direction at (row j, column c); j may be -1 / ny (wrapped or outside), c is a valid column
-  auto pn_at = [&](int j, int c) -> T {
-    if (j < 0) { if (!a.per_y) return (T)0; j = ny - 1; }
-    if (j >= ny) { if (!a.per_y) return (T)0; j = 0; }
-    const size_t i = (size_t)j * nx + c;
-    T v = src[i];
-    if (mode == MODE_NORMAL) v = fma(beta, pin[i], v);
-    return v;
-  };
-  auto pn_row = [&](int j, int c0, bool active) -> Vec<T, V> {
-    Vec<T, V> o;
+  // raw loads of the own columns of row j (rows outside the domain wrap or read as zero); combined later with beta
+  struct Raw { Vec<T, V> s, q; };
+  auto load_raw = [&](int j, int c0, bool active) -> Raw {
+    Raw o;
 #pragma unroll
-    for (int q = 0; q < V; ++q) o.v[q] = 0;
+    for (int e = 0; e < V; ++e) { o.s.v[e] = 0; o.q.v[e] = 0; }
     if (!active) return o;
     if (j < 0) { if (!a.per_y) return o; j = ny - 1; }
     if (j >= ny) { if (!a.per_y) return o; j = 0; }
     const size_t i = (size_t)j * nx + c0;
-    o = ldv<T, V>(src + i);
-    if (mode == MODE_NORMAL) {
-      const Vec<T, V> q = ldv<T, V>(pin + i);
-#pragma unroll
-      for (int e = 0; e < V; ++e) o.v[e] = fma(beta, q.v[e], o.v[e]);
-    }
+    o.s = ldv<T, V>(src + i);
+    if (use_pin) o.q = ldv<T, V>(pin + i);
     return o;
   };
 
-  T acc_p = 0, acc_pr = 0, acc_pz = 0;
+  // ---- everything that does not depend on the scalars is issued first: state, scalars, the first rows of my first tile
+  const CgState st = a.state[sv & 1];
+  const T sc_pz = a.scal[SC_PZ], sc_vs = a.scal[SC_VS], sc_alpha = a.scal[SC_ALPHA];
   const int ntiles = a.ntx * a.nty;
   const XcdRange tr = xcd_range(ntiles);
-  for (int t = tr.begin; t < tr.end; t += tr.step) {
+  const int dir = (wave & 1) ? -1 : 1;
+  auto tile_geom = [&](int t, int& jb, int& je, int& c0, bool& active) {
     const int ty = t / a.ntx, tx = t - ty * a.ntx;
-    const int jb = (ty * 4 + wave) * a.rows_per_wave;
-    const int je = min(jb + a.rows_per_wave, ny);
-    const int c0 = (tx * 64 + lane) * V;
-    const bool active = c0 < nx;                          // nx % V == 0 => all V columns valid together
+    jb = (ty * 4 + wave) * a.rows_per_wave;
+    je = min(jb + a.rows_per_wave, ny);
+    c0 = (tx * 64 + lane) * V;
+    active = c0 < nx;                                 // nx % V == 0 => all V columns valid together
+  };
+  Raw rawB, rawC;
+  {
+    int jb, je, c0; bool active;
+    if (tr.begin < tr.end) {
+      tile_geom(tr.begin, jb, je, c0, active);
+      if (jb < ny) {
+        const int j = (dir > 0) ? jb : je - 1;
+        rawB = load_raw(j - dir, c0, active);
+        rawC = load_raw(j, c0, active);
+      }
+    }
+  }
+
+  T beta = 0;
+  CgState nst = st;
+  if (do_check) {                                     // uniform: every block reduces, also when already done (cheap, rare)
+    T pb[2], m;
+    prologue_reduce<T, 2, true>(a.partsB, a.nB, pb, m, smem);            // r.z', sum r, max |r|
+    if (!st.done) {
+      if (k > 0 && (k % 5) == 0) {
+        const int exceeded = !(m < (T)a.accuracy);   // checkResiduum (:94-102) clears the flag if any |r| >= accuracy
+        if (st.flag && !exceeded) { nst.done = 1; nst.iterations = k; }
+        else nst.flag = 1;                           // cudaMemset(threshold_reached, 1) after a failed test (:334)
+      }
+      if (mode == MODE_NORMAL) beta = -(pb[0] + sc_vs * pb[1]) / sc_pz;   // -r.z / p.z, unguarded as coded (:351-352)
+    }
+  }
+  if (mode == MODE_RESET && !nst.done) nst.flag = 0; // initVariablesWithGuess clears the device flag
+  // the state always moves to the next version slot, also once done (later launches read that slot)
+  if (writes_state && blockIdx.x == 0 && threadIdx.x == 0) a.state[(sv + 1) & 1] = nst;
+  if (st.done) return;
+  const T alpha_prev = pending ? sc_alpha : (T)0;
+  const bool only_flush = nst.done;                  // converged: just add the last direction to x, then stop
+
+  auto combine = [&](const Raw& w) -> Vec<T, V> {
+    Vec<T, V> o = w.s;
+    if (use_pin) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) o.v[e] = fma(beta, w.q.v[e], o.v[e]);
+    }
+    return o;
+  };
+  auto val_at = [&](int j, int c) -> T {             // value at (row j, column c); rows outside wrap or read as zero
+    if (j < 0) { if (!a.per_y) return (T)0; j = ny - 1; }
+    if (j >= ny) { if (!a.per_y) return (T)0; j = 0; }
+    const size_t i = (size_t)j * nx + c;
+    T v = src[i];
+    if (use_pin) v = fma(beta, pin[i], v);
+    return v;
+  };
+
+  T acc_p = 0, acc_pr = 0, acc_pz = 0;
+  for (int t = tr.begin; t < tr.end; t += tr.step) {
+    int jb, je, c0; bool active;
+    tile_geom(t, jb, je, c0, active);
     if (jb >= ny) continue;
-    Vec<T, V> prev = pn_row(jb - 1, c0, active);
-    Vec<T, V> cur = pn_row(jb, c0, active);
-    for (int j = jb; j < je; ++j) {
-      const Vec<T, V> next = pn_row(j + 1, c0, active);
+    if (only_flush) {                                     // x += alpha_prev * p_old on my cells, nothing else
+      if (active && pending && use_pin)
+        for (int j = jb; j < je; ++j) {
+          const size_t i = (size_t)j * nx + c0;
+          Vec<T, V> xv = ldv<T, V>(a.x + i);
+          const Vec<T, V> q = ldv<T, V>(pin + i);
+#pragma unroll
+          for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha_prev, q.v[e], xv.v[e]);
+          stv<T, V>(a.x + i, xv);
+        }
+      continue;
+    }
+    int j = (dir > 0) ? jb : je - 1;
+    if (t != tr.begin) {
+      rawB = load_raw(j - dir, c0, active);
+      rawC = load_raw(j, c0, active);
+    }
+    Vec<T, V> behind = combine(rawB);
+    Vec<T, V> cur = combine(rawC);
+    Vec<T, V> praw = rawC.q;
+    for (int cnt = jb; cnt < je; ++cnt, j += dir) {
+      const Raw rawA = load_raw(j + dir, c0, active);
+      const Vec<T, V> ahead = combine(rawA);
       T left = __shfl_up(cur.v[V - 1], 1, kWave);
       T right = __shfl_down(cur.v[0], 1, kWave);
       if (active) {
         if (lane == 0) {
           const int c = c0 - 1;
-          left = (c >= 0) ? pn_at(j, c) : (a.per_x ? pn_at(j, nx - 1) : (T)0);
+          left = (c >= 0) ? val_at(j, c) : (a.per_x ? val_at(j, nx - 1) : (T)0);
         }
         if (lane == 63 || c0 + V >= nx) {
           const int c = c0 + V;
-          right = (c < nx) ? pn_at(j, c) : (a.per_x ? pn_at(j, 0) : (T)0);
+          right = (c < nx) ? val_at(j, c) : (a.per_x ? val_at(j, 0) : (T)0);
         }
         const size_t i = (size_t)j * nx + c0;
-        const Vec<T, V> kS = ldv<T, V>(a.cS + i), kW = ldv<T, V>(a.cW + i), kC = ldv<T, V>(a.cC + i),
-                        kE = ldv<T, V>(a.cE + i), kN = ldv<T, V>(a.cN + i);
+        const Vec<CT, V> kS = ldc<CT, V>(static_cast<const CT*>(a.oS) + i), kW = ldc<CT, V>(static_cast<const CT*>(a.oW) + i),
+                         kE = ldc<CT, V>(static_cast<const CT*>(a.oE) + i), kN = ldc<CT, V>(static_cast<const CT*>(a.oN) + i);
+        Vec<T, V> kC;
+        if constexpr (RECON) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) {                   // accumulation order of calcPISOLaplaceMatrix (laplace_op.cu.cc:118-135)
+            T d = 0;
+            d -= (T)kS.v[e]; d -= (T)kN.v[e]; d -= (T)kW.v[e]; d -= (T)kE.v[e];
+            kC.v[e] = d;
+          }
+        } else {
+          kC = ldv<T, V>(a.cC + i);
+        }
         Vec<T, V> rr = cur;
-        if (mode == MODE_NORMAL) rr = ldv<T, V>(a.r + i);   // INIT: p == r; RESET: unused
+        if (mode == MODE_NORMAL) rr = rawC.s;               // the residual of my cells (INIT: p == r; RESET: unused)
+        if (pending && use_pin) {                           // x <- x + alpha_prev p_old  (cublasDaxpy :303 of iteration k-1)
+          Vec<T, V> xv = ldv<T, V>(a.x + i);
+#pragma unroll
+          for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha_prev, praw.v[e], xv.v[e]);
+          stv<T, V>(a.x + i, xv);
+        }
         Vec<T, V> zz;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           const T pw = (e == 0) ? left : cur.v[e > 0 ? e - 1 : 0];
           const T pe = (e == V - 1) ? right : cur.v[e < V - 1 ? e + 1 : 0];
+          const T ps = (dir > 0) ? behind.v[e] : ahead.v[e];
+          const T pnn = (dir > 0) ? ahead.v[e] : behind.v[e];
           // summation order of calcZ_v4 (:81-90): -y, -x, diag, +x, +y
           T tmp = 0;
-          tmp = fma(kS.v[e], prev.v[e], tmp);
-          tmp = fma(kW.v[e], pw, tmp);
+          tmp = fma((T)kS.v[e], ps, tmp);
+          tmp = fma((T)kW.v[e], pw, tmp);
           tmp = fma(kC.v[e], cur.v[e], tmp);
-          tmp = fma(kE.v[e], pe, tmp);
-          tmp = fma(kN.v[e], next.v[e], tmp);
+          tmp = fma((T)kE.v[e], pe, tmp);
+          tmp = fma((T)kN.v[e], pnn, tmp);
           zz.v[e] = tmp;
           acc_p += cur.v[e];
           acc_pr = fma(cur.v[e], rr.v[e], acc_pr);
@@ -201,10 +326,13 @@ __global__ __launch_bounds__(kBlock) void cg_k1(CgArgs<T> a, int k, int mode, in
         stv<T, V>(a.z + i, zz);
         if (mode != MODE_RESET) stv<T, V>(pout + i, cur);
       }
-      prev = cur;
-      cur = next;
+      behind = cur;
+      cur = ahead;
+      praw = rawA.q;
+      rawC = rawA;
     }
   }
+  if (only_flush) return;
   T part[3] = {acc_p, acc_pr, acc_pz};
   block_sum<T, 3>(part, smem);
   if (threadIdx.x == 0) {
@@ -214,41 +342,64 @@ __global__ __launch_bounds__(kBlock) void cg_k1(CgArgs<T> a, int k, int mode, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// K2: alpha, x/r update, dots for beta and the stopping test.  Pure stream over flat cells, XCD-chunked like K1.
+// K2: alpha, residual update, dots for beta and the stopping test.  Pure stream over flat cells, XCD-chunked like K1.
+// (x is updated by the next K1, which reads the direction anyway.)
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int V>
 __global__ __launch_bounds__(kBlock) void cg_k2(CgArgs<T> a, int k, int sv) {
   __shared__ T smem[16];
-  const CgState st = a.state[sv & 1];
-  if (st.done) return;
-  T pa[3];
-  reduce_partials<T, 3>(a.partsA, kMaxPartials, pa, smem);
-  const T vs = a.scal[SC_C] * pa[0];                      // vectorSum = c * sum(p)  (:279)
-  const T pz = pa[2] + vs * pa[0];
-  T alpha = 0;
-  if (absval(pz) > 0) alpha = pa[1] / pz;                 // :301-302
-  if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal[SC_PZ] = pz; a.scal[SC_VS] = vs; }
-
-  const T* __restrict__ p = a.p[(k + 1) & 1];
+  constexpr int D = 4;                                    // chunks kept in flight per thread
+  const T* __restrict__ zp = a.z;
+  T* __restrict__ rp = a.r;
   const size_t n = (size_t)a.nx * a.ny;
   const int nchunks = (int)((n / V + kBlock - 1) / kBlock);   // chunks of kBlock * V cells
   const XcdRange cr = xcd_range(nchunks);
-  T acc_rz = 0, acc_r = 0, mx = 0;
-  for (int ch = cr.begin; ch < cr.end; ch += cr.step) {
-    const size_t i = ((size_t)ch * kBlock + threadIdx.x) * V;
-    if (i >= n) continue;
-    const Vec<T, V> pv = ldv<T, V>(p + i), zv = ldv<T, V>(a.z + i);
-    Vec<T, V> xv = ldv<T, V>(a.x + i), rv = ldv<T, V>(a.r + i);
+  // issued before anything depends on the scalars: state, shift, the first D chunks
+  const CgState st = a.state[sv & 1];
+  const T sc_c = a.scal[SC_C];
+  Vec<T, V> zq[D], rq[D];
+  size_t iq[D];
+  bool okq[D];
+  int ch = cr.begin;
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      xv.v[e] = fma(alpha, pv.v[e], xv.v[e]);
-      rv.v[e] = fma(-alpha, zv.v[e] + vs, rv.v[e]);
-      acc_rz = fma(rv.v[e], zv.v[e], acc_rz);
-      acc_r += rv.v[e];
-      mx = nanmax(mx, absval(rv.v[e]));
+  for (int d = 0; d < D; ++d) {
+    const int c = ch + d * cr.step;
+    iq[d] = ((size_t)c * kBlock + threadIdx.x) * V;
+    okq[d] = c < cr.end && iq[d] < n;
+    if (okq[d]) { zq[d] = ldv<T, V>(zp + iq[d]); rq[d] = ldv<T, V>(rp + iq[d]); }
+  }
+
+  T pa[3], unused;
+  prologue_reduce<T, 3, false>(a.partsA, a.nA, pa, unused, smem);
+  if (st.done) return;
+  const T vs = sc_c * pa[0];                              // vectorSum = c * sum(p)  (:279)
+  const T pz = pa[2] + vs * pa[0];
+  T alpha = 0;
+  if (absval(pz) > 0) alpha = pa[1] / pz;                 // :301-302
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.scal[SC_PZ] = pz; a.scal[SC_VS] = vs; a.scal[SC_ALPHA] = alpha; }
+
+  T acc_rz = 0, acc_r = 0, mx = 0;
+  while (ch < cr.end) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      // finish chunk d, then refill its slot with the chunk D steps ahead
+      if (okq[d]) {
+        Vec<T, V> r0 = rq[d];
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          r0.v[e] = fma(-alpha, zq[d].v[e] + vs, r0.v[e]);
+          acc_rz = fma(r0.v[e], zq[d].v[e], acc_rz);
+          acc_r += r0.v[e];
+          mx = nanmax(mx, absval(r0.v[e]));
+        }
+        stv<T, V>(rp + iq[d], r0);
+      }
+      const int c = ch + (d + D) * cr.step;
+      iq[d] = ((size_t)c * kBlock + threadIdx.x) * V;
+      okq[d] = c < cr.end && iq[d] < n;
+      if (okq[d]) { zq[d] = ldv<T, V>(zp + iq[d]); rq[d] = ldv<T, V>(rp + iq[d]); }
     }
-    stv<T, V>(a.x + i, xv);
-    stv<T, V>(a.r + i, rv);
+    ch += D * cr.step;
   }
   T part[2] = {acc_rz, acc_r};
   block_sum<T, 2>(part, smem);
@@ -260,31 +411,58 @@ __global__ __launch_bounds__(kBlock) void cg_k2(CgArgs<T> a, int k, int sv) {
   }
 }
 
+// x <- x + alpha p for the direction of the LAST executed iteration (the loop ended without a following K1)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_flush_x(CgArgs<T> a, int k_last, int sv) {
+  if (a.state[sv & 1].done) return;                       // a converged solve was flushed by the K1 that detected it
+  const T alpha = a.scal[SC_ALPHA];
+  const T* __restrict__ p = a.p[(k_last + 1) & 1];
+  const size_t n = (size_t)a.nx * a.ny;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
+    a.x[i] = fma(alpha, p[i], a.x[i]);
+}
+
 // r <- b - (z' + c sum x) after a MODE_RESET application of K1 to x (pressure_solve_op.cu.cc:260-274)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void cg_reset_residual(CgArgs<T> a, int sv) {
   __shared__ T smem[16];
   if (a.state[sv & 1].done) return;
   T pa[1];
-  reduce_partials<T, 1>(a.partsA, kMaxPartials, pa, smem);
+  reduce_partials<T, 1>(a.partsA, a.nA, pa, smem);
   const T vs = a.scal[SC_C] * pa[0];
   const size_t n = (size_t)a.nx * a.ny;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
     a.r[i] = a.b[i] - (a.z[i] + vs);
 }
 
-// L [N][5] -> SoA coefficients; partial sums of |diag| for the shift (cublasDasum, :165-168)
+// L [N][5] -> SoA coefficients (off-diagonals in T and in float); partial sums of |diag| for the shift (cublasDasum,
+// :165-168); flags[0] is set if some off-diagonal is not exactly representable as float (then the T arrays are used),
+// flags[1] if some diagonal is not bit-for-bit -(S + N + W + E) of the float off-diagonals (then it is read, not recomputed).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void cg_setup_coeffs(const T* __restrict__ L, T* cS, T* cW, T* cC, T* cE, T* cN,
-                                                           T* parts, size_t n) {
+__global__ __launch_bounds__(kBlock) void cg_setup_coeffs(const T* __restrict__ L, T* cC, T* oT, float* oF, T* parts,
+                                                           int* flags, size_t n) {
   __shared__ T smem[16];
   T acc = 0;
+  bool bad = false, bad_recon = false;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const T* row = L + i * 5;
-    const T s = row[0], w = row[1], c = row[2], e = row[3], nn = row[4];
-    cS[i] = s; cW[i] = w; cC[i] = c; cE[i] = e; cN[i] = nn;
-    acc += absval(c);
+    const T o[4] = {row[0], row[1], row[3], row[4]};
+    cC[i] = row[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float f = (float)o[q];
+      oT[q * n + i] = o[q];
+      oF[q * n + i] = f;
+      bad |= !((T)f == o[q]);
+    }
+    // can the diagonal be recomputed from the float off-diagonals exactly as calcPISOLaplaceMatrix accumulated it?
+    T d = 0;
+    d -= (T)(float)o[0]; d -= (T)(float)o[3]; d -= (T)(float)o[1]; d -= (T)(float)o[2];
+    bad_recon |= !(d == row[2]);
+    acc += absval(row[2]);
   }
+  if (bad) flags[0] = 1;
+  if (bad_recon) flags[1] = 1;
   T part[1] = {acc};
   block_sum<T, 1>(part, smem);
   if (threadIdx.x == 0) parts[blockIdx.x] = part[0];
@@ -349,7 +527,8 @@ template <typename T>
 static size_t cg_workspace_bytes(int nx, int ny) {
   const size_t n = (size_t)nx * ny;
   size_t b = 0;
-  b += 9 * align_up(n * sizeof(T), 256);                 // 5 coefficient arrays + r, z, p0, p1
+  b += 9 * align_up(n * sizeof(T), 256);                 // diag + 4 off-diagonal arrays (T) + r, z, p0, p1
+  b += align_up(4 * n * sizeof(float), 256) + 256;        // float copy of the off-diagonals + flag
   b += 3 * align_up(3 * kMaxPartials * sizeof(T), 256);
   b += align_up(SC_COUNT * sizeof(T), 256) + align_up(2 * sizeof(CgState), 256);
   return b + 4096;
@@ -363,7 +542,7 @@ struct EventPool {
 };
 static thread_local EventPool tl_events;
 
-template <typename T, int V>
+template <typename T, typename CT, int V, bool RECON>
 static int cg_run(CgArgs<T> a, float accuracy, int max_iterations, int rank_deficient, int reset, int fixed,
                   int* iterations_out, float* kernel_ms_out, hipStream_t stream) {
   const int nx = a.nx, ny = a.ny;
@@ -371,11 +550,15 @@ static int cg_run(CgArgs<T> a, float accuracy, int max_iterations, int rank_defi
   a.ntx = (nx + 64 * V - 1) / (64 * V);
   int rpw = (int)(((long long)ny * a.ntx) / (4 * 1024));
   rpw = rpw < 2 ? 2 : (rpw > 16 ? 16 : rpw);
+  if (const char* e = getenv("PISO_CG_RPW")) { const int o = atoi(e); if (o > 0) rpw = o; }   // tuning knob
   a.rows_per_wave = rpw;
   a.nty = (ny + 4 * rpw - 1) / (4 * rpw);
   a.accuracy = fixed ? -1.0f : accuracy;                 // fixed-work mode: the test can never succeed
-  const int g1 = grid_for((long long)a.ntx * a.nty, 1);
+  int cap = 1024;
+  if (const char* e = getenv("PISO_CG_MAXBLOCKS")) { const int o = atoi(e); if (o >= 8 && o <= kMaxPartials) cap = o; }
+  const int g1 = grid_for((long long)a.ntx * a.nty, 1, cap);
   const int g2 = grid_for((long long)((n / V + kBlock - 1) / kBlock), 4);
+  a.nA = g1; a.nB = g2;
   const int gflat = grid_for((long long)n, kBlock * 4);
 
   { const int rc = ensure_poll(); if (rc != PISO_OK) return rc; }
@@ -410,19 +593,22 @@ static int cg_run(CgArgs<T> a, float accuracy, int max_iterations, int rank_defi
     if (tl_poll.pinned[slot].done) { stop_it = tl_poll.pinned[slot].iterations; return 1; }
     return 0;
   };
+  bool pending = false;                                  // x still lacks alpha_k p_k of the last executed iteration
+  int k_last = -1;
   for (int k = 0; k < total && !finished; ++k) {
     const bool is_reset = !fixed && ((k + 1) % reset == 0);
     const bool sample = prof && (k % prof_stride == prof_stride - 1) && ep.used[0] < EventPool::kMax && !is_reset && k > 0;
     if (is_reset) {
-      cg_k1<T, V><<<g1, kBlock, 0, stream>>>(a, k, MODE_RESET, sv, k > 0 ? 1 : 0);
+      if (pending) { cg_flush_x<T><<<gflat, kBlock, 0, stream>>>(a, k - 1, sv); pending = false; }
+      cg_k1<T, CT, V, RECON><<<g1, kBlock, 0, stream>>>(a, k, MODE_RESET, sv, k > 0 ? 1 : 0, 0);
       ++sv;
       cg_reset_residual<T><<<gflat, kBlock, 0, stream>>>(a, sv);
-      cg_k1<T, V><<<g1, kBlock, 0, stream>>>(a, k, MODE_INIT, sv, 0);
+      cg_k1<T, CT, V, RECON><<<g1, kBlock, 0, stream>>>(a, k, MODE_INIT, sv, 0, 0);
     } else if (k == 0) {
-      cg_k1<T, V><<<g1, kBlock, 0, stream>>>(a, k, MODE_INIT, sv, 0);
+      cg_k1<T, CT, V, RECON><<<g1, kBlock, 0, stream>>>(a, k, MODE_INIT, sv, 0, 0);
     } else {
       if (sample) PISO_HIP_CHECK(hipEventRecord(ep.start[0][ep.used[0]], stream));
-      cg_k1<T, V><<<g1, kBlock, 0, stream>>>(a, k, MODE_NORMAL, sv, 1);
+      cg_k1<T, CT, V, RECON><<<g1, kBlock, 0, stream>>>(a, k, MODE_NORMAL, sv, 1, pending ? 1 : 0);
       if (sample) PISO_HIP_CHECK(hipEventRecord(ep.stop[0][ep.used[0]++], stream));
       ++sv;
     }
@@ -430,6 +616,8 @@ static int cg_run(CgArgs<T> a, float accuracy, int max_iterations, int rank_defi
     cg_k2<T, V><<<g2, kBlock, 0, stream>>>(a, k, sv);
     if (sample) PISO_HIP_CHECK(hipEventRecord(ep.stop[1][ep.used[1]++], stream));
     PISO_LAUNCH_CHECK();
+    pending = true;
+    k_last = k;
     if (!fixed && ((k + 1) % batch == 0) && k + 1 < total) {
       const int slot = polls & 1;
       PISO_HIP_CHECK(hipMemcpyAsync(&tl_poll.pinned[slot], &a.state[sv & 1], sizeof(CgState), hipMemcpyDeviceToHost, stream));
@@ -442,6 +630,8 @@ static int cg_run(CgArgs<T> a, float accuracy, int max_iterations, int rank_defi
       ++polls;
     }
   }
+  // the direction of the last executed iteration (a converged solve was already flushed by the K1 that detected it)
+  if (pending && k_last >= 0) cg_flush_x<T><<<gflat, kBlock, 0, stream>>>(a, k_last, sv);
   // Final look.  (A success of the test that belongs to the very last iteration is not evaluated: the reference would
   // report iterations == total for it, which is what an unfinished loop reports as well.)
   if (!fixed && !finished) {
@@ -488,27 +678,49 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   const size_t n = (size_t)nx * ny;
   Arena ar(ws, ws_bytes);
   CgArgs<T> a;
-  T* cS = ar.take<T>(n); T* cW = ar.take<T>(n); T* cC = ar.take<T>(n); T* cE = ar.take<T>(n); T* cN = ar.take<T>(n);
-  a.cS = cS; a.cW = cW; a.cC = cC; a.cE = cE; a.cN = cN;
+  T* cC = ar.take<T>(n);
+  T* oT = ar.take<T>(4 * n);
+  float* oF = ar.take<float>(4 * n);
+  int* flags = ar.take<int>(2);
+  a.cC = cC;
   a.b = b; a.x = x_out;
   a.r = ar.take<T>(n); a.z = ar.take<T>(n); a.p[0] = ar.take<T>(n); a.p[1] = ar.take<T>(n);
   a.partsA = ar.take<T>(3 * kMaxPartials); a.partsB = ar.take<T>(3 * kMaxPartials); a.partsS = ar.take<T>(kMaxPartials);
   a.scal = ar.take<T>(SC_COUNT);
   a.state = ar.take<CgState>(2);
   a.nx = nx; a.ny = ny; a.per_x = per_x; a.per_y = per_y;
-  a.ntx = a.nty = a.rows_per_wave = 0; a.accuracy = accuracy;
+  a.ntx = a.nty = a.rows_per_wave = 0; a.nA = a.nB = 0; a.accuracy = accuracy;
   if (!ar.ok()) { set_error_msg("piso_cg_solve: workspace too small"); return PISO_ERR_INVALID_ARG; }
 
+  PISO_HIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int), stream));
   cg_zero_partials<T><<<(3 * kMaxPartials + 255) / 256, 256, 0, stream>>>(a.partsA, a.partsB, a.partsS);
   const int gs = grid_for((long long)n, kBlock * 4);
-  cg_setup_coeffs<T><<<gs, kBlock, 0, stream>>>(L, cS, cW, cC, cE, cN, a.partsS, n);
+  cg_setup_coeffs<T><<<gs, kBlock, 0, stream>>>(L, cC, oT, oF, a.partsS, flags, n);
   PISO_LAUNCH_CHECK();
-
-  constexpr int VMAX = 16 / sizeof(T);
+  // The off-diagonals of the PISO pressure matrix are float32 face coefficients (laplace_op.cu.cc:140-177): stored as
+  // float they are exact and K1 reads 24 instead of 40 coefficient bytes per cell.  Any other input keeps them in T.
+  int hflags[2] = {1, 1};
+  if (sizeof(T) == 8) {
+    PISO_HIP_CHECK(hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  if (getenv("PISO_CG_NO_COMPACT")) hflags[0] = hflags[1] = 1;      // tuning / test knob: plain T coefficients
+  if (getenv("PISO_CG_NO_RECON")) hflags[1] = 1;
+  constexpr int VMID = 16 / sizeof(T);
   const bool aligned = ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(x_out)) & 15) == 0;
-  if (nx % VMAX == 0 && aligned)
-    return cg_run<T, VMAX>(a, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream);
-  return cg_run<T, 1>(a, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream);
+  const bool vec = aligned && (nx % VMID == 0);
+#define PISO_CG_RUN(CT, V, RECON) \
+  return cg_run<T, CT, V, RECON>(a, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream)
+  if (sizeof(T) == 8 && !hflags[0]) {
+    a.oS = oF; a.oW = oF + n; a.oE = oF + 2 * n; a.oN = oF + 3 * n;
+    if (!hflags[1]) { if (vec) PISO_CG_RUN(float, VMID, true); PISO_CG_RUN(float, 1, true); }
+    if (vec) PISO_CG_RUN(float, VMID, false);
+    PISO_CG_RUN(float, 1, false);
+  }
+  a.oS = oT; a.oW = oT + n; a.oE = oT + 2 * n; a.oN = oT + 3 * n;
+  if (vec) PISO_CG_RUN(T, VMID, false);
+  PISO_CG_RUN(T, 1, false);
+#undef PISO_CG_RUN
 }
 
 }  // namespace piso

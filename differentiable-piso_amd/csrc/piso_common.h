@@ -12,7 +12,7 @@ namespace piso {
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kBlock = 256;          // 4 waves, one per SIMD
 constexpr int kXcds = 8;             // MI355X: 8 XCDs, block b is observed on XCD b % 8 (speed only, never correctness)
-constexpr int kMaxPartials = 1024;   // upper bound on the grid of any kernel that publishes per-block partial sums
+constexpr int kMaxPartials = 2048;   // upper bound on the grid of any kernel that publishes per-block partial sums
 
 void set_error(const char* what, hipError_t err);
 void set_error_msg(const char* what);
