@@ -18,6 +18,7 @@ from .solvers import (LinearSolver, LinearSolverCudaMultiBicgstabILU, LinearSolv
 from .stencils import (arrange_rhs_term_tf, calculate_centered_shape, calculate_staggered_shape, convert_to_scipy_csr,
                        custom_padded, finite_volume_divergence, finite_volume_gradient_tensor, flatten_staggered_data,
                        padded_velocity_flat, stagger_flattened_data, vorticity)
+from .setups import compute_mixingLayer_masks, update_dirichlet_values
 from .unroll import run_piso_steps, zero_gradient_op
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -149,3 +149,18 @@ def test_field_shim_matches_phiflow_conventions(golden_dir):
     assert tuple(g.staggered_tensor().shape) == (1, 7, 10, 2)
     assert float(g.staggered_tensor()[0, :, 9, 0].abs().sum()) == 0
     assert np.allclose(dom.dx, [1.0, 1.0])
+
+
+def test_mixing_layer_masks_against_reference_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "mixing_layer_masks.npz"))
+    ny, nx = 6, 9
+    bcy = np.zeros((1, 1, nx + 2, 1), np.float32)
+    m, v, n, act, acc = dp.compute_mixingLayer_masks(d["staggered_shape"], ((True, True), (True, False)),
+                                                     ((bcy, bcy), (d["bcx"], [])))
+    np.testing.assert_array_equal(m, d["dirichlet_mask"])
+    np.testing.assert_array_equal(v, d["dirichlet_values"])
+    np.testing.assert_array_equal(n, d["neumann_mask"])
+    np.testing.assert_array_equal(act, d["active_mask"])
+    np.testing.assert_array_equal(acc, d["accessible_mask"])
+    upd = dp.update_dirichlet_values(d["dirichlet_values"], ((False, False), (True, False)), (([], []), (d["update_in"], [])))
+    np.testing.assert_array_equal(upd, d["updated_values"])
