@@ -125,6 +125,40 @@ def cpu_baseline(P, n, tol, cg_iters_per_step, sample_iters=12):
                         "step observed on the GPU)") % (n, t_asm, t_bicg, its, sample_iters, t_cg_iter, cg_iters_per_step))
 
 
+def slab_self_check(n, device, rank, world, iters=300):
+    """N > 1 only, AFTER the timed region: the slab-decomposed CG (RCCL all-reduce + halo exchange) on one
+    2048^2 pressure system cut into `world` slabs, against the single-GPU solve of the same system on every rank."""
+    import torch
+    import diffpiso._native as N
+    from diffpiso.distributed import SlabCommunicator, cg_solve_slab
+    from diffpiso.solvers import cg_solve_native, laplace_matrix_native
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1234)
+    a0 = (0.5 + torch.rand(n * (n + 1) + (n + 1) * n, generator=g)).to(device)
+    ones = torch.ones((n + 2) * (n + 2), device=device)
+    L = laplace_matrix_native(n, n, ones, ones, a0, torch.float64)
+    b = torch.randn(n * n, generator=g, dtype=torch.float64).to(device)
+    b -= b.mean()
+    comm = SlabCommunicator(rank=rank, world=world, device=device)
+    out = {}
+    try:
+        # un-shifted operator: with the rank-1 shift CG trajectories are not reproducible between summation orders
+        for name, fn in (("single", lambda: cg_solve_native(n, n, True, True, L, b, 1e-30, iters, False, 1000)),
+                         ("slab", lambda: cg_solve_slab(comm, n, n, True, True, L, b, 1e-30, iters, False, 1000))):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            x, it = fn()
+            torch.cuda.synchronize()
+            out[name] = (x, (time.perf_counter() - t0) / iters)
+        diff = float((out["slab"][0] - out["single"][0]).abs().max() / out["single"][0].abs().max())
+        return {"ok": bool(diff < 1e-8), "max_rel_diff_vs_single_gpu": diff, "iterations": iters,
+                "us_per_iteration_single_gpu": 1e6 * out["single"][1], "us_per_iteration_slab": 1e6 * out["slab"][1],
+                "ranks": world}
+    finally:
+        comm.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,7 +250,19 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(P, n, args.tol, per_step)
             except Exception as e:   # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if world > 1 and os.environ.get("PISO_BENCH_SLAB_CHECK", "1") != "0":
+        # not part of the metric: exercise the slab-decomposed CG over RCCL on the real multi-GPU node (stderr only)
+        import threading
+        threading.Timer(180.0, lambda: os._exit(0)).start()      # the result line is out; never hang the driver
+        try:
+            chk = slab_self_check(n, device, rank, world)
+            if rank == 0:
+                print("slab_cg_self_check " + json.dumps(chk), file=sys.stderr, flush=True)
+        except Exception as e:
+            if rank == 0:
+                print("slab_cg_self_check failed: %r" % (e,), file=sys.stderr, flush=True)
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 

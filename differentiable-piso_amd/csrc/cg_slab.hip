@@ -1,0 +1,419 @@
+// Slab-decomposed pressure CG: the grid is cut into 1-D slabs along y (contiguous row blocks), one rank per GPU.
+// SURVEY.md 8(e).  The reference has no multi-GPU path; this is new design.
+//
+// Per CG iteration and rank:  K1  ->  3-double all-reduce  ->  K2  ->  3-double all-reduce + one-row halo exchange of r.
+//   * the kernels are the single-GPU ones (cg_kernels.h) in "halo mode": r, p[2] and x carry one halo row below and above
+//     the owned rows; K1 recomputes the new direction on the halo rows from (r_halo, p_halo) and keeps it, so only r has to
+//     be exchanged (one row = nx * 8 bytes per neighbour and iteration);
+//   * per-block partial sums are collapsed to 3 scalars on the device, all-reduced over RCCL (xGMI), and read back by the
+//     next kernel's prologue -- no host round trip; every rank evaluates the same stopping test on the same numbers;
+//   * the rank-1 shift uses the global sum |diag| and the global cell count.
+// Communication goes through a tiny interface with two implementations: RCCL (librccl is dlopen'ed on first use, so the
+// library has no link-time dependency on it) and an in-process LOOPBACK that runs G virtual ranks on one device in
+// lock-step -- the test harness for the multi-rank index logic on a single-GPU box (tests/test_gpu_slab.py).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <vector>
+
+#include "cg_kernels.h"
+
+namespace piso {
+
+// ------------------------------------------------------------------------------------------------ RCCL (lazy)
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int load_rccl() {
+  if (g_rccl.handle) return PISO_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+  if (!h) { set_error_msg("cannot dlopen librccl"); return PISO_ERR_HIP; }
+#define PISO_SYM(field, sym) \
+  *reinterpret_cast<void**>(&g_rccl.field) = dlsym(h, sym); \
+  if (!g_rccl.field) { set_error_msg("librccl lacks " sym); return PISO_ERR_HIP; }
+  PISO_SYM(GetUniqueId, "ncclGetUniqueId") PISO_SYM(CommInitRank, "ncclCommInitRank") PISO_SYM(CommDestroy, "ncclCommDestroy")
+  PISO_SYM(AllReduce, "ncclAllReduce") PISO_SYM(AllGather, "ncclAllGather") PISO_SYM(Send, "ncclSend") PISO_SYM(Recv, "ncclRecv")
+  PISO_SYM(GroupStart, "ncclGroupStart") PISO_SYM(GroupEnd, "ncclGroupEnd") PISO_SYM(GetErrorString, "ncclGetErrorString")
+#undef PISO_SYM
+  g_rccl.handle = h;
+  return PISO_OK;
+}
+
+#define PISO_NCCL_CHECK(expr)                                                   \
+  do {                                                                          \
+    ncclResult_t _r = (expr);                                                   \
+    if (_r != ncclSuccess) {                                                    \
+      char buf[256];                                                            \
+      snprintf(buf, sizeof(buf), "%s: %s", #expr, g_rccl.GetErrorString(_r));   \
+      set_error_msg(buf);                                                       \
+      return PISO_ERR_HIP;                                                      \
+    }                                                                           \
+  } while (0)
+
+struct PisoComm {
+  ncclComm_t comm;
+  int rank, world;
+};
+
+// ------------------------------------------------------------------------------------------------ per-rank context
+template <typename T>
+struct SlabRank {
+  CgArgs<T> a;          // r, p[], x point at row 0 of buffers that own one halo row below (row -1) and above (row ny)
+  T *rbase, *pbase[2], *xbase;
+  T* g;                 // [12]: gA[0..2], pad, gB[4..6], pad, gS[8..10] (sum |diag|, #not-f32, #not-recon)
+  T* oT; float* oF; T* cC;
+  int* flags;
+  const T* L;
+  T* x_out;             // owned rows of the caller's output
+  int rank;             // position in the slab ring
+};
+
+// collapse per-block partial records into `count` scalars (fixed order)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void slab_collapse(const T* __restrict__ parts, int records, int count, T* __restrict__ out) {
+  __shared__ T smem[16];
+  for (int q = 0; q < count; ++q) {
+    T v[1] = {0};
+    for (int b = threadIdx.x; b < records; b += kBlock) v[0] += parts[q * kMaxPartials + b];
+    block_sum<T, 1>(v, smem);
+    if (threadIdx.x == 0) out[q] = v[0];
+  }
+}
+template <typename T>
+__global__ void slab_flags_to_sums(const int* flags, T* out) {
+  if (threadIdx.x == 0) { out[1] = (T)flags[0]; out[2] = (T)flags[1]; }
+}
+// loopback all-reduce: bufs of the G virtual ranks live `stride` apart; sum in rank order, write to all
+template <typename T>
+__global__ void loop_allreduce(T* base, int G, size_t stride, int count) {
+  const int q = threadIdx.x;
+  if (q >= count) return;
+  T s = 0;
+  for (int r = 0; r < G; ++r) s += base[(size_t)r * stride + q];
+  for (int r = 0; r < G; ++r) base[(size_t)r * stride + q] = s;
+}
+template <typename T>
+__global__ void slab_copy_rows(const T* __restrict__ src, T* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------ communication
+template <typename T>
+struct Comm {
+  int world;              // slabs in the ring
+  bool periodic_y;
+  PisoComm* rccl;         // NULL = loopback over the local ranks
+  size_t g_stride;        // loopback: distance between consecutive ranks' g buffers
+
+  // sum `count` values at offset `off` of every rank's g buffer
+  int allreduce(std::vector<SlabRank<T>>& R, int off, int count, hipStream_t s) {
+    if (rccl) {
+      if (world == 1) return PISO_OK;
+      PISO_NCCL_CHECK(g_rccl.AllReduce(R[0].g + off, R[0].g + off, count, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum,
+                                       rccl->comm, s));
+    } else {
+      loop_allreduce<T><<<1, 64, 0, s>>>(R[0].g + off, world, g_stride, count);
+    }
+    return PISO_OK;
+  }
+  // fill the halo rows (row -1 and row ny) of `which` (0: r, 1: x) from the neighbours' edge rows
+  int exchange(std::vector<SlabRank<T>>& R, int which, hipStream_t s) {
+    const int nx = R[0].a.nx;
+    auto base0 = [&](SlabRank<T>& k) { return which == 0 ? k.a.r : k.a.x; };   // row 0
+    if (rccl) {
+      SlabRank<T>& me = R[0];
+      const int ny = me.a.ny, rank = rccl->rank;
+      const int lo = (rank > 0) ? rank - 1 : (periodic_y ? world - 1 : -1);
+      const int hi = (rank < world - 1) ? rank + 1 : (periodic_y ? 0 : -1);
+      T* row0 = base0(me);
+      const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+      // Sends and receives between one pair of ranks are matched in issue order, and with 1 or 2 ranks the lower and the
+      // upper neighbour are the same peer: every rank issues the UPWARD transfer first, then the DOWNWARD one.
+      PISO_NCCL_CHECK(g_rccl.GroupStart());
+      if (hi >= 0) PISO_NCCL_CHECK(g_rccl.Send(row0 + (size_t)(ny - 1) * nx, nx, dt, hi, rccl->comm, s));   // my top row -> upper's lower halo
+      if (lo >= 0) PISO_NCCL_CHECK(g_rccl.Recv(row0 - nx, nx, dt, lo, rccl->comm, s));                      // lower's top row -> my lower halo
+      if (lo >= 0) PISO_NCCL_CHECK(g_rccl.Send(row0, nx, dt, lo, rccl->comm, s));                           // my bottom row -> lower's upper halo
+      if (hi >= 0) PISO_NCCL_CHECK(g_rccl.Recv(row0 + (size_t)ny * nx, nx, dt, hi, rccl->comm, s));         // upper's bottom row -> my upper halo
+      PISO_NCCL_CHECK(g_rccl.GroupEnd());
+    } else {
+      for (int r = 0; r < world; ++r) {
+        SlabRank<T>& me = R[r];
+        const int ny = me.a.ny;
+        const int lo = (r > 0) ? r - 1 : (periodic_y ? world - 1 : -1);
+        const int hi = (r < world - 1) ? r + 1 : (periodic_y ? 0 : -1);
+        T* row0 = base0(me);
+        if (lo >= 0) slab_copy_rows<T><<<4, 256, 0, s>>>(base0(R[lo]) + (size_t)(R[lo].a.ny - 1) * nx, row0 - nx, nx);
+        if (hi >= 0) slab_copy_rows<T><<<4, 256, 0, s>>>(base0(R[hi]), row0 + (size_t)ny * nx, nx);
+      }
+    }
+    return PISO_OK;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ driver
+template <typename T>
+static size_t slab_rank_bytes(int nx, int nyl) {
+  const size_t n = (size_t)nx * nyl, nh = (size_t)nx * (nyl + 2);
+  size_t b = 0;
+  b += align_up(n * sizeof(T), 256) * (1 + 4 + 1);          // cC, oT(4), z
+  b += align_up(4 * n * sizeof(float), 256);                 // oF
+  b += align_up(nh * sizeof(T), 256) * 4;                    // r, p0, p1, x with halos
+  b += 3 * align_up(3 * kMaxPartials * sizeof(T), 256);
+  b += 4 * 256 + align_up(16 * sizeof(T), 256);
+  return b + 4096;
+}
+
+static thread_local CgState* tl_slab_pinned = nullptr;
+
+template <typename T, typename CT, int V, bool RECON>
+static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accuracy, int max_iterations, int reset,
+                        int* iterations_out, hipStream_t stream) {
+  const int nloc = (int)R.size();
+  std::vector<int> g1(nloc), g2(nloc), gflat(nloc);
+  for (int q = 0; q < nloc; ++q) {
+    CgArgs<T>& a = R[q].a;
+    const size_t n = (size_t)a.nx * a.ny;
+    a.ntx = (a.nx + 64 * V - 1) / (64 * V);
+    int rpw = (int)(((long long)a.ny * a.ntx) / (4 * 1024));
+    rpw = rpw < 2 ? 2 : (rpw > 16 ? 16 : rpw);
+    a.rows_per_wave = rpw;
+    a.nty = (a.ny + 4 * rpw - 1) / (4 * rpw);
+    a.accuracy = accuracy;
+    g1[q] = grid_for((long long)a.ntx * a.nty, 1, 1024);
+    g2[q] = grid_for((long long)((n / V + kBlock - 1) / kBlock), 4);
+    gflat[q] = grid_for((long long)n, kBlock * 4);
+    a.nA = g1[q]; a.nB = g2[q];
+    a.gA = R[q].g; a.gB = R[q].g + 4;
+  }
+  if (!tl_slab_pinned) PISO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&tl_slab_pinned), sizeof(CgState), hipHostMallocDefault));
+
+  auto k1 = [&](int k, int mode, int sv, int chk, int pend) -> int {
+    for (int q = 0; q < nloc; ++q) cg_k1<T, CT, V, RECON><<<g1[q], kBlock, 0, stream>>>(R[q].a, k, mode, sv, chk, pend);
+    for (int q = 0; q < nloc; ++q) slab_collapse<T><<<1, kBlock, 0, stream>>>(R[q].a.partsA, g1[q], 3, R[q].g);
+    return comm.allreduce(R, 0, 3, stream);
+  };
+  auto k2 = [&](int k, int sv) -> int {
+    for (int q = 0; q < nloc; ++q) cg_k2<T, V><<<g2[q], kBlock, 0, stream>>>(R[q].a, k, sv);
+    for (int q = 0; q < nloc; ++q) slab_collapse<T><<<1, kBlock, 0, stream>>>(R[q].a.partsB, g2[q], 3, R[q].g + 4);
+    int rc = comm.allreduce(R, 4, 3, stream);
+    if (rc != PISO_OK) return rc;
+    return comm.exchange(R, 0, stream);                  // halo rows of the new residual
+  };
+
+  int sv = 0, stop_it = -1, k_last = -1;
+  bool pending = false, finished = false;
+  const int batch = 25;
+  for (int k = 0; k < max_iterations && !finished; ++k) {
+    const bool is_reset = ((k + 1) % reset == 0);
+    int rc = PISO_OK;
+    if (is_reset) {
+      if (pending) { for (int q = 0; q < nloc; ++q) cg_flush_x<T><<<gflat[q], kBlock, 0, stream>>>(R[q].a, k - 1, sv); pending = false; }
+      rc = comm.exchange(R, 1, stream);                  // halo rows of x for L x
+      if (rc == PISO_OK) rc = k1(k, MODE_RESET, sv, k > 0 ? 1 : 0, 0);
+      ++sv;
+      for (int q = 0; q < nloc; ++q) cg_reset_residual<T><<<gflat[q], kBlock, 0, stream>>>(R[q].a, sv);
+      if (rc == PISO_OK) rc = comm.exchange(R, 0, stream);
+      if (rc == PISO_OK) rc = k1(k, MODE_INIT, sv, 0, 0);
+    } else if (k == 0) {
+      rc = k1(k, MODE_INIT, sv, 0, 0);
+    } else {
+      rc = k1(k, MODE_NORMAL, sv, 1, pending ? 1 : 0);
+      ++sv;
+    }
+    if (rc == PISO_OK) rc = k2(k, sv);
+    if (rc != PISO_OK) return rc;
+    PISO_LAUNCH_CHECK();
+    pending = true;
+    k_last = k;
+    if ((k + 1) % batch == 0 || k + 1 == max_iterations) {
+      PISO_HIP_CHECK(hipMemcpyAsync(tl_slab_pinned, &R[0].a.state[sv & 1], sizeof(CgState), hipMemcpyDeviceToHost, stream));
+      PISO_HIP_CHECK(hipStreamSynchronize(stream));
+      if (tl_slab_pinned->done) { finished = true; stop_it = tl_slab_pinned->iterations; }
+    }
+  }
+  if (pending && k_last >= 0)
+    for (int q = 0; q < nloc; ++q) cg_flush_x<T><<<gflat[q], kBlock, 0, stream>>>(R[q].a, k_last, sv);
+  for (int q = 0; q < nloc; ++q)
+    slab_copy_rows<T><<<gflat[q], kBlock, 0, stream>>>(R[q].a.x, R[q].x_out, (size_t)R[q].a.nx * R[q].a.ny);
+  PISO_LAUNCH_CHECK();
+  PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  if (iterations_out) *iterations_out = finished ? stop_it : max_iterations;
+  return PISO_OK;
+}
+
+// Set up the ranks found in `R` (L, b, x_out, rank already filled in) inside `ws`, then iterate.
+template <typename T>
+static int slab_solve(std::vector<SlabRank<T>>& R, Comm<T>& comm, int nx, int nyl, int per_x, const T* const* b,
+                      double global_cells, float accuracy, int max_iterations, int rank_deficient, int reset,
+                      int* iterations_out, char* ws, size_t ws_per_rank, hipStream_t stream) {
+  const int nloc = (int)R.size();
+  const size_t n = (size_t)nx * nyl, nh = (size_t)nx * (nyl + 2);
+  // the g buffers of all local ranks are contiguous (loopback all-reduce walks them with a fixed stride)
+  T* gall = reinterpret_cast<T*>(ws);
+  const size_t gbytes = align_up((size_t)nloc * 16 * sizeof(T), 256);
+  comm.g_stride = 16;
+  PISO_HIP_CHECK(hipMemsetAsync(gall, 0, gbytes, stream));
+  for (int q = 0; q < nloc; ++q) {
+    SlabRank<T>& k = R[q];
+    Arena ar(ws + gbytes + (size_t)q * ws_per_rank, ws_per_rank);
+    k.g = gall + (size_t)q * 16;
+    k.cC = ar.take<T>(n); k.oT = ar.take<T>(4 * n); k.oF = ar.take<float>(4 * n);
+    k.flags = ar.take<int>(2);
+    k.rbase = ar.take<T>(nh); k.pbase[0] = ar.take<T>(nh); k.pbase[1] = ar.take<T>(nh); k.xbase = ar.take<T>(nh);
+    CgArgs<T>& a = k.a;
+    a.z = ar.take<T>(n);
+    a.partsA = ar.take<T>(3 * kMaxPartials); a.partsB = ar.take<T>(3 * kMaxPartials); a.partsS = ar.take<T>(kMaxPartials);
+    a.scal = ar.take<T>(SC_COUNT);
+    a.state = ar.take<CgState>(2);
+    if (!ar.ok()) { set_error_msg("piso_cg_solve_slab: workspace too small"); return PISO_ERR_INVALID_ARG; }
+    a.cC = k.cC; a.b = b[q];
+    a.r = k.rbase + nx; a.p[0] = k.pbase[0] + nx; a.p[1] = k.pbase[1] + nx; a.x = k.xbase + nx;
+    a.nx = nx; a.ny = nyl; a.per_x = per_x; a.per_y = 2;
+    a.gA = nullptr; a.gB = nullptr;
+    PISO_HIP_CHECK(hipMemsetAsync(k.flags, 0, 2 * sizeof(int), stream));
+    PISO_HIP_CHECK(hipMemsetAsync(k.rbase, 0, nh * sizeof(T), stream));
+    PISO_HIP_CHECK(hipMemsetAsync(k.pbase[0], 0, nh * sizeof(T), stream));
+    PISO_HIP_CHECK(hipMemsetAsync(k.pbase[1], 0, nh * sizeof(T), stream));
+    PISO_HIP_CHECK(hipMemsetAsync(k.xbase, 0, nh * sizeof(T), stream));
+    cg_zero_partials<T><<<(3 * kMaxPartials + 255) / 256, 256, 0, stream>>>(a.partsA, a.partsB, a.partsS);
+    const int gs = grid_for((long long)n, kBlock * 4);
+    cg_setup_coeffs<T><<<gs, kBlock, 0, stream>>>(k.L, k.cC, k.oT, k.oF, a.partsS, k.flags, n);
+    slab_collapse<T><<<1, kBlock, 0, stream>>>(a.partsS, gs, 1, k.g + 8);
+    slab_flags_to_sums<T><<<1, 64, 0, stream>>>(k.flags, k.g + 8);
+  }
+  PISO_LAUNCH_CHECK();
+  { const int rc = comm.allreduce(R, 8, 3, stream); if (rc != PISO_OK) return rc; }
+  T hg[3];
+  PISO_HIP_CHECK(hipMemcpyAsync(hg, R[0].g + 8, 3 * sizeof(T), hipMemcpyDeviceToHost, stream));
+  PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  const bool f32ok = sizeof(T) == 8 && hg[1] == 0 && !getenv("PISO_CG_NO_COMPACT");
+  const bool recon = f32ok && hg[2] == 0 && !getenv("PISO_CG_NO_RECON");
+  for (int q = 0; q < nloc; ++q) {
+    SlabRank<T>& k = R[q];
+    const int gflat = grid_for((long long)n, kBlock * 4);
+    cg_init<T><<<gflat, kBlock, 0, stream>>>(k.a, rank_deficient, k.g + 8, global_cells);
+    if (f32ok) { k.a.oS = k.oF; k.a.oW = k.oF + n; k.a.oE = k.oF + 2 * n; k.a.oN = k.oF + 3 * n; }
+    else { k.a.oS = k.oT; k.a.oW = k.oT + n; k.a.oE = k.oT + 2 * n; k.a.oN = k.oT + 3 * n; }
+  }
+  { const int rc = comm.exchange(R, 0, stream); if (rc != PISO_OK) return rc; }     // halo rows of r0 = b
+  constexpr int VMID = 16 / sizeof(T);
+  const bool vec = (nx % VMID == 0);
+#define PISO_SLAB_RUN(CT, V, RC) return slab_iterate<T, CT, V, RC>(R, comm, accuracy, max_iterations, reset, iterations_out, stream)
+  if (f32ok) {
+    if (recon) { if (vec) PISO_SLAB_RUN(float, VMID, true); PISO_SLAB_RUN(float, 1, true); }
+    if (vec) PISO_SLAB_RUN(float, VMID, false);
+    PISO_SLAB_RUN(float, 1, false);
+  }
+  if (vec) PISO_SLAB_RUN(T, VMID, false);
+  PISO_SLAB_RUN(T, 1, false);
+#undef PISO_SLAB_RUN
+}
+
+}  // namespace piso
+
+using namespace piso;
+
+extern "C" {
+
+int piso_comm_unique_id(void* id128) {
+  { const int rc = load_rccl(); if (rc != PISO_OK) return rc; }
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  PISO_NCCL_CHECK(g_rccl.GetUniqueId(static_cast<ncclUniqueId*>(id128)));
+  return PISO_OK;
+}
+
+int piso_comm_create(const void* id128, int rank, int world, void** comm_out) {
+  { const int rc = load_rccl(); if (rc != PISO_OK) return rc; }
+  if (!id128 || !comm_out || world < 1 || rank < 0 || rank >= world) { set_error_msg("piso_comm_create: invalid argument"); return PISO_ERR_INVALID_ARG; }
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  PisoComm* c = new PisoComm;
+  c->rank = rank; c->world = world;
+  ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) { set_error_msg(g_rccl.GetErrorString(r)); delete c; return PISO_ERR_HIP; }
+  *comm_out = c;
+  return PISO_OK;
+}
+
+int piso_comm_destroy(void* comm) {
+  if (!comm) return PISO_OK;
+  PisoComm* c = static_cast<PisoComm*>(comm);
+  if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  delete c;
+  return PISO_OK;
+}
+
+size_t piso_cg_slab_workspace_bytes(int nx, int ny_local, int local_ranks) {
+  return (size_t)local_ranks * slab_rank_bytes<double>(nx, ny_local) + align_up((size_t)local_ranks * 16 * sizeof(double), 256) + 4096;
+}
+
+int piso_cg_solve_slab_f64(void* comm, int nx, int ny_local, int periodic_x, int periodic_y, const double* laplace_local,
+                           const double* divergence_local, double* x_out_local, double* x_out_global, float accuracy,
+                           int max_iterations, int rank_deficient, int residual_reset, int* iterations_out, void* workspace,
+                           size_t workspace_bytes, piso_stream_t stream_) {
+  if (!comm || nx < 1 || ny_local < 1 || !laplace_local || !divergence_local || !x_out_local || !workspace || residual_reset < 1) {
+    set_error_msg("piso_cg_solve_slab_f64: invalid argument");
+    return PISO_ERR_INVALID_ARG;
+  }
+  if (workspace_bytes < piso_cg_slab_workspace_bytes(nx, ny_local, 1)) { set_error_msg("piso_cg_solve_slab_f64: workspace too small"); return PISO_ERR_INVALID_ARG; }
+  PisoComm* pc = static_cast<PisoComm*>(comm);
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  std::vector<SlabRank<double>> R(1);
+  R[0].L = laplace_local; R[0].x_out = x_out_local; R[0].rank = pc->rank;
+  Comm<double> cm;
+  cm.world = pc->world; cm.periodic_y = periodic_y != 0; cm.rccl = pc; cm.g_stride = 16;
+  const double* b[1] = {divergence_local};
+  const int rc = slab_solve<double>(R, cm, nx, ny_local, periodic_x, b, (double)nx * ny_local * pc->world, accuracy, max_iterations,
+                                    rank_deficient, residual_reset, iterations_out, static_cast<char*>(workspace),
+                                    slab_rank_bytes<double>(nx, ny_local), stream);
+  if (rc != PISO_OK) return rc;
+  if (x_out_global) {                                       // every rank receives the whole field (replicated PISO step)
+    if (pc->world == 1) {
+      PISO_HIP_CHECK(hipMemcpyAsync(x_out_global, x_out_local, (size_t)nx * ny_local * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    } else {
+      PISO_NCCL_CHECK(g_rccl.AllGather(x_out_local, x_out_global, (size_t)nx * ny_local, ncclDouble, pc->comm, stream));
+    }
+    PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return PISO_OK;
+}
+
+int piso_cg_solve_slab_emulated_f64(int slabs, int nx, int ny, int periodic_x, int periodic_y, const double* laplace,
+                                    const double* divergence, double* x_out, float accuracy, int max_iterations,
+                                    int rank_deficient, int residual_reset, int* iterations_out, void* workspace,
+                                    size_t workspace_bytes, piso_stream_t stream_) {
+  if (slabs < 1 || nx < 1 || ny < slabs || ny % slabs != 0 || !laplace || !divergence || !x_out || !workspace || residual_reset < 1) {
+    set_error_msg("piso_cg_solve_slab_emulated_f64: invalid argument (ny must be a multiple of slabs)");
+    return PISO_ERR_INVALID_ARG;
+  }
+  const int nyl = ny / slabs;
+  if (workspace_bytes < piso_cg_slab_workspace_bytes(nx, nyl, slabs)) { set_error_msg("piso_cg_solve_slab_emulated_f64: workspace too small"); return PISO_ERR_INVALID_ARG; }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  std::vector<SlabRank<double>> R(slabs);
+  std::vector<const double*> b(slabs);
+  for (int r = 0; r < slabs; ++r) {
+    const size_t off = (size_t)r * nyl * nx;
+    R[r].L = laplace + off * 5; R[r].x_out = x_out + off; R[r].rank = r;
+    b[r] = divergence + off;
+  }
+  Comm<double> cm;
+  cm.world = slabs; cm.periodic_y = periodic_y != 0; cm.rccl = nullptr; cm.g_stride = 16;
+  return slab_solve<double>(R, cm, nx, nyl, periodic_x, b.data(), (double)nx * ny, accuracy, max_iterations, rank_deficient,
+                            residual_reset, iterations_out, static_cast<char*>(workspace), slab_rank_bytes<double>(nx, nyl), stream);
+}
+
+}  // extern "C"

@@ -51,6 +51,20 @@ lib.piso_csr_matvec_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]
 lib.piso_csr_matvec_f32.restype = _i
 
 
+lib.piso_comm_unique_id.argtypes = [_vp]
+lib.piso_comm_unique_id.restype = _i
+lib.piso_comm_create.argtypes = [_vp, _i, _i, C.POINTER(_vp)]
+lib.piso_comm_create.restype = _i
+lib.piso_comm_destroy.argtypes = [_vp]
+lib.piso_comm_destroy.restype = _i
+lib.piso_cg_slab_workspace_bytes.argtypes = [_i, _i, _i]
+lib.piso_cg_slab_workspace_bytes.restype = _sz
+lib.piso_cg_solve_slab_f64.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _ip, _vp, _sz, _vp]
+lib.piso_cg_solve_slab_f64.restype = _i
+lib.piso_cg_solve_slab_emulated_f64.argtypes = [_i, _i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _i, _ip, _vp, _sz, _vp]
+lib.piso_cg_solve_slab_emulated_f64.restype = _i
+
+
 class PisoNativeError(RuntimeError):
     pass
 

@@ -168,8 +168,8 @@ class _PressureSolveFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, divergence, L, solver, nx, ny, per_x, per_y, rank_deficient):
-        x, it = cg_solve_native(nx, ny, per_x, per_y, L, divergence, _scalar(solver.accuracy), solver.max_iterations,
-                                rank_deficient, solver.residual_reset)
+        x, it = solver._cg(nx, ny, per_x, per_y, L, divergence, _scalar(solver.accuracy), solver.max_iterations,
+                           rank_deficient, solver.residual_reset)
         solver.last_iterations = it
         ctx.save_for_backward(L)
         ctx.meta = (solver, nx, ny, per_x, per_y, rank_deficient, divergence.shape)
@@ -180,8 +180,8 @@ class _PressureSolveFn(torch.autograd.Function):
     def backward(ctx, dp, di):
         (L,) = ctx.saved_tensors
         solver, nx, ny, per_x, per_y, rank_deficient, shape = ctx.meta
-        g, it = cg_solve_native(nx, ny, per_x, per_y, L, dp.reshape(-1), _scalar(solver.accuracy), solver.max_iterations,
-                                rank_deficient, solver.residual_reset)
+        g, it = solver._cg(nx, ny, per_x, per_y, L, dp.reshape(-1), _scalar(solver.accuracy), solver.max_iterations,
+                           rank_deficient, solver.residual_reset)
         solver.last_adjoint_iterations = it
         return g.reshape(shape).to(torch.float32), None, None, None, None, None, None, None
 
@@ -208,6 +208,14 @@ class PisoPressureSolverCudaCustom(PoissonSolver):
         self.cast_to_double = cast_to_double
         self.last_iterations = None
         self.last_adjoint_iterations = None
+        self.slab_comm = None        # distributed.SlabCommunicator: decompose the CG into y-slabs over the ranks (fp64 only)
+
+    def _cg(self, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient, residual_reset):
+        if self.slab_comm is not None and self.slab_comm.world > 1 and L.dtype == torch.float64:
+            from .distributed import cg_solve_slab
+            return cg_solve_slab(self.slab_comm, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient,
+                                 residual_reset)
+        return cg_solve_native(nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient, residual_reset)
 
     def solve(self, scaling_field, divergence, guess, enable_backprop, simulation_physics, offset=0, unrolling_step=0):
         # `guess` is ignored exactly like in the reference (init_with_zeros=True, piso_cuda_pressure_solver.py:95)

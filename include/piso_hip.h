@@ -123,6 +123,35 @@ int piso_cg_fixed_iterations_f64(int nx, int ny, int periodic_x, int periodic_y,
                                  const double* divergence, double* x_out, int rank_deficient, int iterations,
                                  float* kernel_ms_out, void* workspace, size_t workspace_bytes, piso_stream_t stream);
 
+/* Sampling of K1 / K2 launch durations with HIP events on the launch stream (every `stride`-th iteration); used by
+ * bench.py for roofline.achieved.  ms_sum / count: [2] = K1, K2. */
+void piso_cg_profile_enable(int enable, int stride);
+void piso_cg_profile_read(double* ms_sum, long long* count);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Slab-decomposed pressure CG (no counterpart in the reference, which is single-GPU).
+ * The grid is cut along y into `world` slabs of ny_local rows, one rank per GPU.  Per iteration: K1, a 3-double all-reduce,
+ * K2, a 3-double all-reduce and a one-row halo exchange of the residual -- all stream-ordered RCCL calls, no host sync.
+ * The communicator wraps an RCCL communicator (librccl is dlopen'ed on first use); the 128-byte unique id is created on one
+ * rank and distributed by the caller (e.g. torch.distributed broadcast).
+ *   laplace_local [ny_local*nx][5], divergence_local / x_out_local [ny_local*nx]: this rank's rows;
+ *   x_out_global  [world*ny_local*nx] or NULL: if given, every rank receives the full solution (all-gather).
+ * piso_cg_solve_slab_emulated_f64 runs `slabs` virtual ranks on ONE device in lock-step with an in-process loopback
+ * instead of RCCL: same kernels, same halo / partial-sum logic; it exists to test the multi-rank index logic on one GPU.
+ * ------------------------------------------------------------------------------------------------------------- */
+int piso_comm_unique_id(void* id128);
+int piso_comm_create(const void* id128, int rank, int world, void** comm_out);
+int piso_comm_destroy(void* comm);
+size_t piso_cg_slab_workspace_bytes(int nx, int ny_local, int local_ranks);
+int piso_cg_solve_slab_f64(void* comm, int nx, int ny_local, int periodic_x, int periodic_y, const double* laplace_local,
+                           const double* divergence_local, double* x_out_local, double* x_out_global, float accuracy,
+                           int max_iterations, int rank_deficient, int residual_reset, int* iterations_out, void* workspace,
+                           size_t workspace_bytes, piso_stream_t stream);
+int piso_cg_solve_slab_emulated_f64(int slabs, int nx, int ny, int periodic_x, int periodic_y, const double* laplace,
+                                    const double* divergence, double* x_out, float accuracy, int max_iterations,
+                                    int rank_deficient, int residual_reset, int* iterations_out, void* workspace,
+                                    size_t workspace_bytes, piso_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,68 @@
+"""Slab-decomposed CG on a single GPU: G virtual ranks in lock-step (loopback) and the real RCCL code path
+with a 1-rank communicator, against the single-GPU solver and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import native as O
+from tests.test_gpu_kernels import _laplace_case, dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["periodic", "xper_ywall", "spatial_ml"])
+@pytest.mark.parametrize("slabs", [1, 2, 4, 8])
+@pytest.mark.parametrize("reset", [1000, 40])
+def test_emulated_slabs_match_single_gpu(name, slabs, reset):
+    from diffpiso.distributed import cg_solve_slab_emulated
+    from diffpiso.solvers import cg_solve_native
+    ny, nx = 64, 48
+    s, L, b = _laplace_case(name, ny, nx, seed=3)
+    px, py = s.periodic_yx[1], s.periodic_yx[0]
+    tol = 1e-9
+    Ld, bd = dev(L), dev(b)
+    x1, it1 = cg_solve_native(nx, ny, px, py, Ld, bd, tol, 3000, False, reset)
+    xs, its = cg_solve_slab_emulated(slabs, nx, ny, px, py, Ld, bd, tol, 3000, False, reset)
+    xo, ito = O.cg_solve(nx, ny, px, py, L, b, tol, 3000, False, reset)
+    assert ito < 3000 and abs(its - it1) <= 5 and abs(its - ito) <= max(5, 0.05 * ito), (its, it1, ito)
+    scale = np.abs(xo).max()
+    assert np.abs(xs.cpu().numpy() - xo).max() <= 1e-6 * scale
+    assert np.abs(xs.cpu().numpy() - x1.cpu().numpy()).max() <= 1e-6 * scale
+    # fixed short runs: round-off level agreement of the trajectories (different partial-sum grouping only)
+    for nit in (1, 2, 7, 45):
+        xa, _ = cg_solve_native(nx, ny, px, py, Ld, bd, 1e-30, nit, False, reset)
+        xb, itb = cg_solve_slab_emulated(slabs, nx, ny, px, py, Ld, bd, 1e-30, nit, False, reset)
+        assert itb == nit
+        assert np.abs(xa.cpu().numpy() - xb.cpu().numpy()).max() <= 1e-9 * np.abs(xa.cpu().numpy()).max()
+
+
+@pytest.mark.parametrize("slabs", [2, 8])
+def test_emulated_slabs_rank_deficient_shift(slabs):
+    from diffpiso.distributed import cg_solve_slab_emulated
+    ny, nx = 64, 64
+    s, L, b = _laplace_case("periodic", ny, nx, seed=5)
+    xs, its = cg_solve_slab_emulated(slabs, nx, ny, True, True, dev(L), dev(b), 1e-9, 6000, True, 1000)
+    xo, ito = O.cg_solve(nx, ny, True, True, L, b, 1e-9, 6000, True, 1000)
+    assert its < 6000 and ito < 6000
+    assert np.abs(xs.cpu().numpy() - xo).max() <= 1e-6 * np.abs(xo).max()
+    for nit in (1, 2, 3):      # global shift c and global sum(p) are used (not per-slab ones)
+        xa, _ = cg_solve_slab_emulated(slabs, nx, ny, True, True, dev(L), dev(b), 1e-30, nit, True, 1000)
+        xb, _ = O.cg_solve(nx, ny, True, True, L, b, 1e-30, nit, True, 1000)
+        assert np.abs(xa.cpu().numpy() - xb).max() <= 1e-9 * np.abs(xb).max()
+
+
+def test_rccl_path_with_one_rank():
+    """The real RCCL driver (dlopen, communicator, grouped send/recv to self for the periodic wrap, all-gather)."""
+    from diffpiso.distributed import SlabCommunicator, cg_solve_slab
+    from diffpiso.solvers import cg_solve_native
+    ny, nx = 64, 48
+    s, L, b = _laplace_case("periodic", ny, nx, seed=3)
+    comm = SlabCommunicator(rank=0, world=1)
+    try:
+        Ld, bd = dev(L), dev(b)
+        x1, it1 = cg_solve_native(nx, ny, True, True, Ld, bd, 1e-9, 3000, False, 1000)
+        xs, its = cg_solve_slab(comm, nx, ny, True, True, Ld, bd, 1e-9, 3000, False, 1000)
+        assert abs(its - it1) <= 5
+        assert np.abs(xs.cpu().numpy() - x1.cpu().numpy()).max() <= 1e-6 * np.abs(x1.cpu().numpy()).max()
+    finally:
+        comm.close()
