@@ -12,6 +12,42 @@ import torch
 from . import _native as N
 
 
+def slab_rows(rank, world, ny):
+    """Rows [begin, end) of the cell grid owned by `rank` (contiguous y-slabs; ny must be divisible by world)."""
+    if ny % world != 0:
+        raise ValueError("slab decomposition needs ny (%d) divisible by the number of ranks (%d)" % (ny, world))
+    nyl = ny // world
+    return rank * nyl, (rank + 1) * nyl
+
+
+def exchange_unique_id(rank, world, device, make_id=None):
+    """Rank 0 creates the 128-byte RCCL unique id, everybody receives it through torch.distributed (any backend)."""
+    import torch.distributed as dist
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        if make_id is None:
+            buf = (C.c_ubyte * 128)()
+            N.check(N.lib.piso_comm_unique_id(buf), "piso_comm_unique_id")
+            uid = torch.tensor(list(buf), dtype=torch.uint8)
+        else:
+            uid = make_id()
+    if world > 1:
+        uid_dev = uid.to(device)
+        dist.broadcast(uid_dev, src=0)
+        uid = uid_dev.cpu()
+    return uid
+
+
+def max_over_ranks(value, device):
+    """The bench contract's timing rule: every rank reports the slowest rank's time."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 class SlabCommunicator(object):
     def __init__(self, rank=None, world=None, device=None):
         import torch.distributed as dist
@@ -19,15 +55,7 @@ class SlabCommunicator(object):
             rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
         self.rank, self.world = rank, world
         device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = (C.c_ubyte * 128)()
-            N.check(N.lib.piso_comm_unique_id(buf), "piso_comm_unique_id")
-            uid = torch.tensor(list(buf), dtype=torch.uint8)
-        if world > 1:
-            uid_dev = uid.to(device)
-            dist.broadcast(uid_dev, src=0)
-            uid = uid_dev.cpu()
+        uid = exchange_unique_id(rank, world, device)
         raw = (C.c_ubyte * 128)(*[int(v) for v in uid.tolist()])
         handle = C.c_void_p()
         N.check(N.lib.piso_comm_create(raw, rank, world, C.byref(handle)), "piso_comm_create")
@@ -43,8 +71,9 @@ def cg_solve_slab(comm, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, 
     """Distributed counterpart of solvers.cg_solve_native: L [ny*nx*5] and div [ny*nx] are the FULL (replicated) arrays;
     this rank solves its slab and every rank returns the full solution."""
     assert L.dtype == torch.float64 and ny % comm.world == 0, "slab CG: fp64, ny divisible by the number of ranks"
-    nyl = ny // comm.world
-    off = comm.rank * nyl * nx
+    j0, j1 = slab_rows(comm.rank, comm.world, ny)
+    nyl = j1 - j0
+    off = j0 * nx
     L_loc = L[off * 5:(off + nyl * nx) * 5].contiguous()
     d_loc = div.reshape(-1).to(torch.float64)[off:off + nyl * nx].contiguous()
     x_loc = torch.empty_like(d_loc)

@@ -1,0 +1,67 @@
+"""World-size-2 gloo test (CPU) of the host side of the N > 1 path: unique-id distribution, slab partition, max-over-ranks
+timing.  The GPU side (RCCL all-reduce + halo exchange inside the library) is covered on the GPU box by tests/test_gpu_slab.py."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diffpiso.distributed import exchange_unique_id, max_over_ranks, slab_rows
+        uid = exchange_unique_id(rank, world, torch.device("cpu"),
+                                 make_id=lambda: torch.arange(128, dtype=torch.uint8) * 3 + 1)
+        rows = slab_rows(rank, world, 64)
+        slow = max_over_ranks(1.0 + rank, torch.device("cpu"))
+        # emulate what the slab solver exchanges per iteration with plain tensors: partial sums and one halo row
+        part = torch.tensor([float(rank + 1), 2.0 * (rank + 1), 0.5], dtype=torch.float64)
+        dist.all_reduce(part)
+        top = torch.full((8,), float(rank))                     # my top row -> upper neighbour's lower halo (ring)
+        lower_halo = torch.empty(8)
+        hi, lo = (rank + 1) % world, (rank - 1) % world
+        ops = [dist.P2POp(dist.isend, top, hi), dist.P2POp(dist.irecv, lower_halo, lo)]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        q.put((rank, uid.tolist(), rows, slow, part.tolist(), lower_halo.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_host_logic():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, uid0, rows0, slow0, part0, halo0), (r1, uid1, rows1, slow1, part1, halo1) = res
+    assert uid0 == uid1 == [(3 * i + 1) % 256 for i in range(128)]
+    assert rows0 == (0, 32) and rows1 == (32, 64)
+    assert slow0 == slow1 == 2.0
+    assert part0 == part1 == [3.0, 6.0, 1.0]
+    assert halo0 == [1.0] * 8 and halo1 == [0.0] * 8
+
+
+def test_slab_rows_rejects_uneven_split():
+    sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
+    from diffpiso.distributed import slab_rows
+    with pytest.raises(ValueError):
+        slab_rows(0, 3, 64)
