@@ -9,6 +9,8 @@ import numpy as np  # noqa: F401  (the reference's star-import exports np as wel
 import torch  # noqa: F401
 
 from . import _native  # noqa: F401  (raises ImportError if the HIP library is missing)
+from .closure import (FullyConvNetwork, centered_gradient, centered_to_staggered, initialise_fullyconv_network,
+                      make_forcing_fn, network_input)
 from .grids import (AABox, CLOSED, NO_SLIP, NO_STICK, OPEN, PERIODIC, SLIPPERY, STICKY, CenteredGrid, Domain, Material,
                     StaggeredGrid, as_tensor, box, default_device, placeholder, stack_staggered_components,
                     unstack_staggered_tensor)

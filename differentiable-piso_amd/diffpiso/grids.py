@@ -198,7 +198,7 @@ class CenteredGrid(object):
 
     def padded(self, widths):
         """grid.py:188-194 with the pad modes of :257-281: 'constant' -> zeros, 'boundary' -> replicate, 'periodic' -> wrap."""
-        from .stencils import pad_axis
+        from .stencils import pad_axis_sides
         if isinstance(widths, int):
             widths = [[widths, widths]] * self.rank
         ext = axis_extrapolation(self.extrapolation, self.rank)
@@ -206,8 +206,7 @@ class CenteredGrid(object):
         for axis, (lo, hi) in enumerate(widths):
             e = ext[axis]
             lo_mode, hi_mode = (e, e) if isinstance(e, str) else e
-            d = pad_axis(d, axis + 1, lo, 0, lo_mode)
-            d = pad_axis(d, axis + 1, 0, hi, hi_mode)
+            d = pad_axis_sides(d, axis + 1, lo, hi, lo_mode, hi_mode)
         w_lo = np.array([w[0] for w in widths])
         w_hi = np.array([w[1] for w in widths])
         return CenteredGrid(d, AABox(self.box.lower - w_lo * self.dx, self.box.upper + w_hi * self.dx), self.extrapolation)

@@ -48,6 +48,16 @@ def pad_axis(t, dim, lo, hi, mode):
     return torch.cat(parts, dim=dim)
 
 
+def pad_axis_sides(t, dim, lo, hi, lo_mode, hi_mode):
+    """Pad both sides of one axis with possibly different modes; both pads are taken from the ORIGINAL tensor."""
+    if lo_mode == hi_mode:
+        return pad_axis(t, dim, lo, hi, lo_mode)
+    n = t.shape[dim]
+    left = pad_axis(t, dim, lo, 0, lo_mode).narrow(dim, 0, lo) if lo else None
+    right = pad_axis(t, dim, 0, hi, hi_mode).narrow(dim, n, hi) if hi else None
+    return torch.cat([x for x in (left, t, right) if x is not None], dim=dim)
+
+
 def custom_padded(staggered_field, widths=1):
     """diffpiso/piso_helpers.py:35-55 (width 1).  Returns (v_pad [1,Ny+3,Nx+2,1], u_pad [1,Ny+2,Nx+3,1]):
     non-periodic axes replicate the edge ('boundary' -> replicate, 'constant' -> symmetric == replicate at width 1, :16-25);

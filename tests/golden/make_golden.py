@@ -84,6 +84,8 @@ CASES = {
     "open": ((4, 7), (1.0, 3.5), pf.OPEN),
     "spatial_ml": ((6, 9), (6.0, 9.0), ((pf.OPEN, pf.OPEN), (pf.OPEN, pf.CLOSED))),
     "closed": ((7, 4), (7.0, 4.0), pf.CLOSED),
+    "periodic_cubic": ((6, 5), (3.0, 2.5), pf.PERIODIC),
+    "xper_ywall_cubic": ((5, 8), (5.0, 8.0), (pf.CLOSED, pf.PERIODIC)),
 }
 
 
@@ -121,7 +123,7 @@ def make_case(name, res, size, boundaries, rng):
 
     # masks: realistic ring + a random interior obstacle pattern for the accessible mask
     accessible = np.ones((1, ny + 2, nx + 2, 1), np.float32)
-    if name in ("xper_ywall", "closed", "spatial_ml"):
+    if name in ("xper_ywall", "xper_ywall_cubic", "closed", "spatial_ml"):
         accessible[0, 0], accessible[0, -1] = 0, 0
     if name in ("closed", "spatial_ml"):
         accessible[0, :, 0] = 0
@@ -162,6 +164,17 @@ def make_case(name, res, size, boundaries, rng):
     rhs = rng.standard_normal(st_shape).astype(np.float32)
     out["rhs_in"], out["dirichlet_mask"], out["dirichlet_values"] = rhs, dmask, dvals
     out["rhs_arranged"] = H.arrange_rhs_term_tf(rhs, dmask.astype(np.float32), dvals, 1.0, coord_flip=True)
+
+    # coupling pieces of the CNN closure (combined_training_integrated.py:399-411): cell-centred velocity, central pressure
+    # gradient, centred -> staggered resampling of a 2-channel field (PhiFlow field algebra, cubic cells only)
+    if abs(domain.dx[0] - domain.dx[1]) < 1e-12:
+        out["at_centers"] = np.asarray(vel.at_centers().data)
+        out["pressure_gradient"] = np.asarray(pressure.gradient().data)
+        nn_out = rng.standard_normal((1, ny, nx, 2)).astype(np.float32)
+        out["nn_out"] = nn_out
+        forcing = pf.StaggeredGrid([pf.CenteredGrid(nn_out[..., 0:1], vel.box).at(vel.data[0]).data,
+                                    pf.CenteredGrid(nn_out[..., 1:2], vel.box).at(vel.data[1]).data], vel.box).staggered_tensor()
+        out["nn_forcing"] = np.asarray(forcing)
     return out
 
 

@@ -1,0 +1,130 @@
+"""Full-size (BASELINE.json) checks on the GPU through size-independent properties -- the oracle is too slow at 2048^2:
+manufactured solutions, true residuals, transpose identities, CSR invariants, discrete incompressibility."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N = 2048
+
+
+@pytest.fixture(scope="module")
+def problem():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.build_problem(N, torch.device("cuda"), 1e-6, 10000, 1000)
+
+
+def test_cg_manufactured_solution_2048():
+    """b = (L + c 11^T) x_true  ->  the solver must return x_true (the shift pins the mean)."""
+    from diffpiso.solvers import cg_solve_native, laplace_matrix_native
+    import diffpiso._native as Nn
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu")
+    g.manual_seed(7)
+    a0 = (0.5 + torch.rand(N * (N + 1) + (N + 1) * N, generator=g)).to(dev)
+    a0v = a0[:N * (N + 1)].view(N + 1, N)
+    a0u = a0[N * (N + 1):].view(N, N + 1)
+    a0v[N] = a0v[0]
+    a0u[:, N] = a0u[:, 0]                                  # periodic duplicate faces carry the same coefficient
+    ones = torch.ones((N + 2) * (N + 2), device=dev)
+    L = laplace_matrix_native(N, N, ones, ones, a0, torch.float64)
+    Lr = L.view(N, N, 5)
+    # smooth manufactured solution with zero mean (a few low modes: converges in O(10^3) iterations)
+    yy, xx = torch.meshgrid(torch.arange(N, device=dev, dtype=torch.float64), torch.arange(N, device=dev, dtype=torch.float64), indexing="ij")
+    xt = torch.sin(2 * np.pi * 3 * xx / N) * torch.cos(2 * np.pi * 2 * yy / N) + 0.3 * torch.sin(2 * np.pi * 5 * (xx + yy) / N)
+    xt -= xt.mean()
+    b = Lr[..., 0] * torch.roll(xt, 1, 0) + Lr[..., 1] * torch.roll(xt, 1, 1) + Lr[..., 2] * xt + \
+        Lr[..., 3] * torch.roll(xt, -1, 1) + Lr[..., 4] * torch.roll(xt, -1, 0)
+    assert float(b.sum().abs()) < 1e-6 * float(b.abs().sum())          # symmetric operator with zero row sums
+    x, it = cg_solve_native(N, N, True, True, L, b, 1e-10, 20000, True, 1000)
+    assert it < 20000 and it % 5 == 0
+    err = float((x.view(N, N) - xt).abs().max())
+    assert err < 1e-5, (err, it)
+    # true residual of the returned solution, max-norm (the reference's stopping measure)
+    xr = x.view(N, N)
+    res = b - (Lr[..., 0] * torch.roll(xr, 1, 0) + Lr[..., 1] * torch.roll(xr, 1, 1) + Lr[..., 2] * xr +
+               Lr[..., 3] * torch.roll(xr, -1, 1) + Lr[..., 4] * torch.roll(xr, -1, 0)) - 0.1 * Lr[..., 2].abs().mean() * xr.sum()
+    assert float(res.abs().max()) < 1e-7
+    # linearity of the solve: solve(2 b) == 2 solve(b) to solver tolerance
+    x2, _ = cg_solve_native(N, N, True, True, L, 2 * b, 1e-10, 20000, True, 1000)
+    assert float((x2 - 2 * x).abs().max()) < 1e-5
+
+
+def test_assembly_invariants_and_transpose_identities_2048(problem):
+    import diffpiso as dp
+    import diffpiso._native as Nn
+    P = problem
+    ext = dp.Material.extrapolation_mode(P["domain"].boundaries)
+    vel = dp.StaggeredGrid(P["vel_t"], P["domain"].box, extrapolation=ext)
+    dev = P["vel_t"].device
+    sim = P["sim"]
+    beta = (2 * np.pi / N) ** 2 / P["dt"]
+    val, rp, col, A, nnz, diag = dp.advection_matrix_cuda(vel, sim.dirichlet_mask_flat(dev), 1e-3, beta=beta, no_slip_wall_mask=None,
+                                                          bool_periodic=(True, True), active_mask=sim.active_mask_tensor(dev),
+                                                          accessible_mask=sim.accessible_mask_tensor(dev))
+    n_u = (N + 1) * N
+    assert list(nnz) == [5 * n_u, 5 * n_u] and int(rp[n_u]) == 5 * n_u and int(rp[-1]) == 5 * n_u   # fully periodic: 5 per row
+    ru = rp[:n_u + 1].long()
+    assert bool((ru[1:] - ru[:-1] == 5).all())
+    cu = col[:5 * n_u].view(n_u, 5).long()
+    assert bool((cu[:, 1:] > cu[:, :-1]).all())                           # columns strictly ascending in every row
+    assert bool(((cu >= 0) & (cu < n_u)).all())
+    # discrete conservation: row sums of M + beta I vanish for this (discretely solenoidal) field
+    rs = val[:5 * n_u].view(n_u, 5).double().sum(1) + beta
+    assert float(rs.abs().max()) < 2e-3 * float(val[:5 * n_u].abs().max())
+    # <A x, y> == <x, A^T y>
+    g = torch.Generator(device="cpu")
+    g.manual_seed(3)
+    x = torch.randn(2 * n_u, generator=g).to(dev)
+    y = torch.randn(2 * n_u, generator=g).to(dev)
+    Ax, ATy = torch.empty_like(x), torch.empty_like(y)
+    Nn.check(Nn.lib.piso_csr_matvec_f32(Nn.ptr(val), Nn.ptr(rp), Nn.ptr(col), Nn.ptr(x), Nn.ptr(Ax), N, N, 0, Nn.stream_ptr()), "mv")
+    Nn.check(Nn.lib.piso_csr_matvec_f32(Nn.ptr(val), Nn.ptr(rp), Nn.ptr(col), Nn.ptr(y), Nn.ptr(ATy), N, N, 1, Nn.stream_ptr()), "mvT")
+    lhs, rhs = float((Ax.double() * y.double()).sum()), float((x.double() * ATy.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), float(Ax.double().norm() * y.double().norm()))
+    # BiCGStab: true residual, and <A^-1 b1, b2> == <b1, A^-T b2>
+    from diffpiso.solvers import multi_bicgstab_ilu_native
+    warn = torch.zeros(1, dtype=torch.uint8, device=dev)
+    mval = (-val).contiguous()
+    s1, its1 = multi_bicgstab_ilu_native(mval, rp, col, x, torch.zeros_like(x), N, N, 1e-4, 200, False, 0, warn)
+    s2, its2 = multi_bicgstab_ilu_native(mval, rp, col, y, torch.zeros_like(y), N, N, 1e-4, 200, True, 0, warn)
+    assert int(warn.item()) == 0 and max(its1) < 50 and max(its2) < 50
+    r = torch.empty_like(x)
+    Nn.check(Nn.lib.piso_csr_matvec_f32(Nn.ptr(mval), Nn.ptr(rp), Nn.ptr(col), Nn.ptr(s1), Nn.ptr(r), N, N, 0, Nn.stream_ptr()), "mv")
+    for c0, c1 in ((0, n_u), (n_u, 2 * n_u)):
+        assert float((r[c0:c1] - x[c0:c1]).double().norm()) < 5e-4 * max(1.0, float(x[c0:c1].double().norm()) * 1e-3 + 1)
+    lhs, rhs = float((s1.double() * y.double()).sum()), float((x.double() * s2.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * float(s1.double().norm() * y.double().norm())
+
+
+def test_piso_step_projects_to_discretely_divergence_free_2048(problem):
+    import diffpiso as dp
+    P = problem
+    ext = dp.Material.extrapolation_mode(P["domain"].boundaries)
+    t = P["vel_t"].clone()
+    # add a divergent perturbation so the correctors have work to do
+    g = torch.Generator(device="cpu")
+    g.manual_seed(11)
+    pert = 0.05 * torch.randn(t.shape, generator=g).to(t.device)
+    pert[0, :, N, 0] = 0
+    pert[0, N, :, 1] = 0
+    pert[0, :N, N, 1] = pert[0, :N, 0, 1]
+    pert[0, N, :N, 0] = pert[0, 0, :N, 0]
+    vel = dp.StaggeredGrid(t + pert, P["domain"].box, extrapolation=ext)
+    prs = dp.CenteredGrid(P["p_t"], P["domain"].box, dp.pressure_extrapolation(P["domain"].boundaries))
+    inc = dp.CenteredGrid(torch.zeros_like(P["p_t"]), prs.box, prs.extrapolation)
+    div0 = dp.finite_volume_divergence(vel).abs().max()
+    with torch.no_grad():
+        v3, pn, warn = dp.piso_step(vel, prs, inc, inc, P["dt"], P["sim"], P["sim"].dirichlet_values)
+    div3 = dp.finite_volume_divergence(v3).abs().max()
+    assert float(warn.sum()) == 0
+    assert float(div3) < 2e-3 * float(div0), (float(div0), float(div3))
+    tt = v3.staggered_tensor()
+    assert torch.isfinite(tt).all() and torch.isfinite(pn.data).all()
+    # periodic duplicate faces stay consistent
+    assert float((tt[0, :N, N, 1] - tt[0, :N, 0, 1]).abs().max()) < 1e-4
+    assert float((tt[0, N, :N, 0] - tt[0, 0, :N, 0]).abs().max()) < 1e-4

@@ -164,3 +164,27 @@ def test_mixing_layer_masks_against_reference_golden(golden_dir):
     np.testing.assert_array_equal(acc, d["accessible_mask"])
     upd = dp.update_dirichlet_values(d["dirichlet_values"], ((False, False), (True, False)), (([], []), (d["update_in"], [])))
     np.testing.assert_array_equal(upd, d["updated_values"])
+
+
+@pytest.mark.parametrize("name", ["periodic_cubic", "xper_ywall_cubic", "spatial_ml", "closed"])
+def test_closure_coupling_against_reference_golden(golden_dir, name):
+    d, vel, p = _load(golden_dir, name)
+    np.testing.assert_allclose(vel.at_centers().data.numpy(), d["at_centers"], **TOL)
+    np.testing.assert_allclose(dp.centered_gradient(p).numpy(), d["pressure_gradient"], **TOL)
+    np.testing.assert_allclose(dp.centered_to_staggered(torch.tensor(d["nn_out"])).numpy(), d["nn_forcing"], **TOL)
+
+
+def test_closure_network_shapes_and_gradients():
+    net, weights, rbw = dp.initialise_fullyconv_network(None, padding="SAME", seed=0)
+    assert [tuple(w.shape) for w in weights] == [(16, 4, 7, 7), (16, 16, 5, 5), (32, 16, 5, 5), (64, 32, 3, 3), (64, 64, 3, 3),
+                                                 (64, 64, 1, 1), (2, 64, 1, 1)] and rbw == 9
+    x = torch.randn(1, 20, 24, 4)
+    y = net(x)
+    assert tuple(y.shape) == (1, 20, 24, 2)
+    y.sum().backward()
+    assert all(w.grad is not None and torch.isfinite(w.grad).all() for w in weights)
+    netv, _, rbwv = dp.initialise_fullyconv_network([[2, 2], [1, 3]], padding="VALID", restore_shape=True, seed=0)
+    x = torch.randn(1, 40, 44, 4)
+    assert tuple(netv(x).shape) == (1, 40, 44, 2) and rbwv == [[11, 11], [10, 12]]
+    z = netv(x)
+    assert float(z[:, :2].abs().sum()) == 0 and float(z[:, :, :1].abs().sum()) == 0      # buffer zones are zero padded
