@@ -209,8 +209,8 @@ def main():
     grad, loss, warn = run_unrolled(P, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    ms_sum = (C.c_double * 2)()
-    cnt = (C.c_longlong * 2)()
+    ms_sum = (C.c_double * 3)()
+    cnt = (C.c_longlong * 3)()
     N.lib.piso_cg_profile_read(ms_sum, cnt)
     N.lib.piso_cg_profile_enable(0, 16)
     from diffpiso.distributed import max_over_ranks

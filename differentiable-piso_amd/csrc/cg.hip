@@ -1,5 +1,8 @@
 // Host driver of the single-GPU pressure CG (kernels: cg_kernels.h).  See cg_kernels.h for the design.
 #include "cg_kernels.h"
+#include "cg_persist.h"
+#include <cstdio>
+#include <vector>
 
 namespace piso {
 
@@ -8,8 +11,8 @@ namespace piso {
 // ---------------------------------------------------------------------------------------------------------------
 struct CgProfile {
   int enabled = 0, stride = 8;
-  double ms[2] = {0, 0};
-  long long count[2] = {0, 0};
+  double ms[3] = {0, 0, 0};          // K1, K2, persistent segments
+  long long count[3] = {0, 0, 0};    // launches of K1, K2; ITERATIONS executed inside persistent segments
 };
 static CgProfile g_prof;
 
@@ -35,7 +38,7 @@ static size_t cg_workspace_bytes(int nx, int ny) {
   b += 9 * align_up(n * sizeof(T), 256);                 // diag + 4 off-diagonal arrays (T) + r, z, p0, p1
   b += align_up(4 * n * sizeof(float), 256) + 256;        // float copy of the off-diagonals + flag
   b += 3 * align_up(3 * kMaxPartials * sizeof(T), 256);
-  b += align_up(SC_COUNT * sizeof(T), 256) + align_up(2 * sizeof(CgState), 256);
+  b += align_up(SC_COUNT * sizeof(T), 256) + align_up(2 * sizeof(CgState), 256) + 512;
   return b + 4096;
 }
 
@@ -48,7 +51,7 @@ struct EventPool {
 static thread_local EventPool tl_events;
 
 template <typename T, typename CT, int V, bool RECON>
-static int cg_run(CgArgs<T> a, float accuracy, int max_iterations, int rank_deficient, int reset, int fixed,
+static int cg_run(CgArgs<T> a, unsigned* persist_ws, float accuracy, int max_iterations, int rank_deficient, int reset, int fixed,
                   int* iterations_out, float* kernel_ms_out, hipStream_t stream) {
   const int nx = a.nx, ny = a.ny;
   const size_t n = (size_t)nx * ny;
@@ -100,8 +103,75 @@ static int cg_run(CgArgs<T> a, float accuracy, int max_iterations, int rank_defi
   };
   bool pending = false;                                  // x still lacks alpha_k p_k of the last executed iteration
   int k_last = -1;
+  // ---- persistent segments (cg_persist.h): applicable when every wave's region fits on chip
+  int persist_R = 0, persist_grid = 0;
+  PersistCtl pc;
+  pc.bar = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr;
+  if (V == 16 / (int)sizeof(T) && a.per_y != 2 && !getenv("PISO_CG_NO_PERSIST")) {
+    int dev = 0, cus = 0;
+    PISO_HIP_CHECK(hipGetDevice(&dev));
+    PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int ntx = nx / (64 * V);
+    if (nx % (64 * V) == 0)                               // every lane of a strip has cells
+      for (int R : {2, 4, 8}) {
+        if (ny % R != 0) continue;                        // every region has R rows
+        const long long nreg = (long long)ntx * (ny / R);
+        if (nreg <= (long long)cus * kPersistRegionsPerWg) {
+          persist_R = R; pc.nreg = (int)nreg; pc.ntx = ntx;
+          persist_grid = (int)((nreg + kPersistRegionsPerWg - 1) / kPersistRegionsPerWg);
+          break;
+        }
+      }
+    const char* force = getenv("PISO_CG_PERSIST");
+    if (persist_R && n < 500000 && !(force && atoi(force) == 1)) persist_R = 0;   // small grids: two-kernel path
+    if (force && atoi(force) == 0) persist_R = 0;
+  }
+  if (persist_R) {
+    pc.bar = persist_ws;
+    pc.err = reinterpret_cast<int*>(persist_ws + 16);
+    PISO_HIP_CHECK(hipMemsetAsync(persist_ws, 0, 128, stream));
+    if (getenv("PISO_CG_PERSIST_TIMING")) {               // diagnostics only: per-phase clocks of every workgroup
+      PISO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&pc.timing), 4 * persist_grid * sizeof(unsigned long long)));
+      PISO_HIP_CHECK(hipMemsetAsync(pc.timing, 0, 4 * persist_grid * sizeof(unsigned long long), stream));
+    }
+  }
+  auto launch_segment = [&](int kb, int ke) -> int {
+    PISO_HIP_CHECK(hipMemsetAsync(pc.bar, 0, sizeof(unsigned), stream));
+    if (persist_R == 2) cg_persist<T, CT, 2, RECON><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+    else if (persist_R == 4) cg_persist<T, CT, 4, RECON><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+    else cg_persist<T, CT, 8, RECON><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+    PISO_LAUNCH_CHECK();
+    return PISO_OK;
+  };
+  int seg_len = (int)(20000.0 / t_iter_us);               // ~20 ms of work per segment (one host look per segment)
+  seg_len = seg_len < 50 ? 50 : (seg_len > 2000 ? 2000 : seg_len);
+  if (const char* e = getenv("PISO_CG_SEGMENT")) { const int o = atoi(e); if (o > 0) seg_len = o; }
+  hipEvent_t seg_ev[2] = {nullptr, nullptr};
+  if (persist_R && prof) { PISO_HIP_CHECK(hipEventCreate(&seg_ev[0])); PISO_HIP_CHECK(hipEventCreate(&seg_ev[1])); }
+  double seg_ms = 0; long long seg_iters = 0;
   for (int k = 0; k < total && !finished; ++k) {
     const bool is_reset = !fixed && ((k + 1) % reset == 0);
+    if (persist_R && k > 0 && !is_reset && pending) {
+      // run NORMAL iterations [k, ke) in one launch: up to the next reset iteration / the end / one segment length
+      int ke = total;
+      if (!fixed) { const int next_reset = ((k + 1 + reset - 1) / reset) * reset - 1; if (next_reset < ke) ke = next_reset; }
+      if (ke > k + seg_len) ke = k + seg_len;
+      if (ke > k) {
+        if (prof) PISO_HIP_CHECK(hipEventRecord(seg_ev[0], stream));
+        { const int rc = launch_segment(k, ke); if (rc != PISO_OK) return rc; }
+        if (prof) PISO_HIP_CHECK(hipEventRecord(seg_ev[1], stream));
+        PISO_HIP_CHECK(hipMemcpyAsync(&tl_poll.pinned[0], &a.state[0], sizeof(CgState), hipMemcpyDeviceToHost, stream));
+        int herr = 0;
+        PISO_HIP_CHECK(hipMemcpyAsync(&herr, pc.err, sizeof(int), hipMemcpyDeviceToHost, stream));
+        PISO_HIP_CHECK(hipStreamSynchronize(stream));
+        if (herr) { set_error_msg("piso_cg_solve: grid barrier of the persistent CG kernel timed out"); return PISO_ERR_HIP; }
+        if (prof) { float t = 0; PISO_HIP_CHECK(hipEventElapsedTime(&t, seg_ev[0], seg_ev[1])); seg_ms += t; seg_iters += ke - k; }
+        if (tl_poll.pinned[0].done) { finished = true; stop_it = tl_poll.pinned[0].iterations; }
+        k_last = ke - 1;
+        k = ke - 1;                                        // the loop increment moves to ke
+        continue;
+      }
+    }
     const bool sample = prof && (k % prof_stride == prof_stride - 1) && ep.used[0] < EventPool::kMax && !is_reset && k > 0;
     if (is_reset) {
       if (pending) { cg_flush_x<T><<<gflat, kBlock, 0, stream>>>(a, k - 1, sv); pending = false; }
@@ -148,6 +218,18 @@ static int cg_run(CgArgs<T> a, float accuracy, int max_iterations, int rank_defi
     if (r > 0) finished = true;
   }
   PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  if (pc.timing) {
+    std::vector<unsigned long long> h(4 * persist_grid);
+    PISO_HIP_CHECK(hipMemcpy(h.data(), pc.timing, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    PISO_HIP_CHECK(hipFree(pc.timing));
+    const char* names[4] = {"phaseA", "barrierA", "phaseB", "barrierB"};
+    for (int q = 0; q < 4; ++q) {
+      double s = 0, mn = 1e300, mx = 0;
+      for (int b = 0; b < persist_grid; ++b) { const double v = (double)h[q * persist_grid + b]; s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+      fprintf(stderr, "cg_persist %s: avg %.2f us/iter  min %.2f  max %.2f\n", names[q], 0.01 * s / persist_grid / (double)(k_last > 0 ? k_last : 1),
+              0.01 * mn / (double)(k_last > 0 ? k_last : 1), 0.01 * mx / (double)(k_last > 0 ? k_last : 1));
+    }
+  }
   if (iterations_out) *iterations_out = finished ? stop_it : total;
   if (prof) {
     double ms[2] = {0, 0};
@@ -161,8 +243,11 @@ static int cg_run(CgArgs<T> a, float accuracy, int max_iterations, int rank_defi
       kernel_ms_out[0] = ep.used[0] ? (float)(ms[0] / ep.used[0]) : 0.f;
       kernel_ms_out[1] = ep.used[1] ? (float)(ms[1] / ep.used[1]) : 0.f;
     }
-    if (g_prof.enabled)
+    if (g_prof.enabled) {
       for (int q = 0; q < 2; ++q) { g_prof.ms[q] += ms[q]; g_prof.count[q] += ep.used[q]; }
+      g_prof.ms[2] += seg_ms; g_prof.count[2] += seg_iters;
+    }
+    if (kernel_ms_out && seg_iters > 0) { kernel_ms_out[0] = (float)(seg_ms / seg_iters); kernel_ms_out[1] = 0.f; }
   }
   return PISO_OK;
 }
@@ -193,9 +278,12 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   a.partsA = ar.take<T>(3 * kMaxPartials); a.partsB = ar.take<T>(3 * kMaxPartials); a.partsS = ar.take<T>(kMaxPartials);
   a.scal = ar.take<T>(SC_COUNT);
   a.state = ar.take<CgState>(2);
+  unsigned* persist_ws = ar.take<unsigned>(64);
   a.nx = nx; a.ny = ny; a.per_x = per_x; a.per_y = per_y;
   a.ntx = a.nty = a.rows_per_wave = 0; a.nA = a.nB = 0; a.accuracy = accuracy;
   a.gA = nullptr; a.gB = nullptr;
+  a.nt = 0;
+  if (const char* e = getenv("PISO_CG_NT")) a.nt = atoi(e);
   if (!ar.ok()) { set_error_msg("piso_cg_solve: workspace too small"); return PISO_ERR_INVALID_ARG; }
 
   PISO_HIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int), stream));
@@ -216,7 +304,7 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   const bool aligned = ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(x_out)) & 15) == 0;
   const bool vec = aligned && (nx % VMID == 0);
 #define PISO_CG_RUN(CT, V, RECON) \
-  return cg_run<T, CT, V, RECON>(a, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream)
+  return cg_run<T, CT, V, RECON>(a, persist_ws, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream)
   if (sizeof(T) == 8 && !hflags[0]) {
     a.oS = oF; a.oW = oF + n; a.oE = oF + 2 * n; a.oN = oF + 3 * n;
     if (!hflags[1]) { if (vec) PISO_CG_RUN(float, VMID, true); PISO_CG_RUN(float, 1, true); }
@@ -264,12 +352,11 @@ int piso_cg_fixed_iterations_f64(int nx, int ny, int periodic_x, int periodic_y,
 void piso_cg_profile_enable(int enable, int stride) {
   g_prof.enabled = enable;
   if (stride > 0) g_prof.stride = stride;
-  g_prof.ms[0] = g_prof.ms[1] = 0;
-  g_prof.count[0] = g_prof.count[1] = 0;
+  for (int q = 0; q < 3; ++q) { g_prof.ms[q] = 0; g_prof.count[q] = 0; }
 }
 
 void piso_cg_profile_read(double* ms_sum, long long* count) {
-  for (int q = 0; q < 2; ++q) { ms_sum[q] = g_prof.ms[q]; count[q] = g_prof.count[q]; }
+  for (int q = 0; q < 3; ++q) { ms_sum[q] = g_prof.ms[q]; count[q] = g_prof.count[q]; }
 }
 
 }  // extern "C"

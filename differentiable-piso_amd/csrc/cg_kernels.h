@@ -55,6 +55,7 @@ struct CgArgs {
   int ntx, nty, rows_per_wave;
   int nA, nB;                        // blocks (= partial records) of K1 / K2
   float accuracy;
+  int nt;                            // tuning bits: 1 K2 stores, 2 K2 loads, 4 K1 stores, 8 K1 loads non-temporal
 };
 
 template <typename T, int V>
@@ -86,6 +87,48 @@ __device__ __forceinline__ Vec<S, V> ldc(const S* __restrict__ p) {
 }
 template <typename T, int V>
 __device__ __forceinline__ Vec<T, V> ldv(const T* __restrict__ p) { return ldc<T, V>(p); }
+
+// non-temporal (streaming) flavours: the data is not re-used before it leaves the caches anyway
+template <typename S, int V>
+__device__ __forceinline__ Vec<S, V> ldc_nt(const S* __restrict__ p) {
+  Vec<S, V> o;
+  constexpr int B = sizeof(S) * V;
+  using raw4 = __attribute__((ext_vector_type(4))) unsigned int;
+  using raw2 = __attribute__((ext_vector_type(2))) unsigned int;
+  if constexpr (B % 16 == 0) {
+#pragma unroll
+    for (int q = 0; q < B / 16; ++q) {
+      const raw4 t = __builtin_nontemporal_load(reinterpret_cast<const raw4*>(p) + q);
+      __builtin_memcpy(reinterpret_cast<char*>(&o) + 16 * q, &t, 16);
+    }
+  } else if constexpr (B == 8) {
+    const raw2 t = __builtin_nontemporal_load(reinterpret_cast<const raw2*>(p));
+    __builtin_memcpy(&o, &t, 8);
+  } else {
+    o.v[0] = __builtin_nontemporal_load(p);
+  }
+  return o;
+}
+template <typename T, int V>
+__device__ __forceinline__ void stv_nt(T* __restrict__ p, const Vec<T, V>& o) {
+  constexpr int B = sizeof(T) * V;
+  using raw4 = __attribute__((ext_vector_type(4))) unsigned int;
+  using raw2 = __attribute__((ext_vector_type(2))) unsigned int;
+  if constexpr (B % 16 == 0) {
+#pragma unroll
+    for (int q = 0; q < B / 16; ++q) {
+      raw4 t;
+      __builtin_memcpy(&t, reinterpret_cast<const char*>(&o) + 16 * q, 16);
+      __builtin_nontemporal_store(t, reinterpret_cast<raw4*>(p) + q);
+    }
+  } else if constexpr (B == 8) {
+    raw2 t;
+    __builtin_memcpy(&t, &o, 8);
+    __builtin_nontemporal_store(t, reinterpret_cast<raw2*>(p));
+  } else {
+    __builtin_nontemporal_store(o.v[0], p);
+  }
+}
 template <typename T, int V>
 __device__ __forceinline__ void stv(T* __restrict__ p, const Vec<T, V>& o) {
   constexpr int B = sizeof(T) * V;
@@ -299,8 +342,14 @@ __global__ __launch_bounds__(kBlock) void cg_k1(CgArgs<T> a, int k, int mode, in
           right = (c < nx) ? val_at(j, c) : (a.per_x ? val_at(j, 0) : (T)0);
         }
         const size_t i = (size_t)j * nx + c0;
-        const Vec<CT, V> kS = ldc<CT, V>(static_cast<const CT*>(a.oS) + i), kW = ldc<CT, V>(static_cast<const CT*>(a.oW) + i),
-                         kE = ldc<CT, V>(static_cast<const CT*>(a.oE) + i), kN = ldc<CT, V>(static_cast<const CT*>(a.oN) + i);
+        Vec<CT, V> kS, kW, kE, kN;
+        if (a.nt & 8) {
+          kS = ldc_nt<CT, V>(static_cast<const CT*>(a.oS) + i); kW = ldc_nt<CT, V>(static_cast<const CT*>(a.oW) + i);
+          kE = ldc_nt<CT, V>(static_cast<const CT*>(a.oE) + i); kN = ldc_nt<CT, V>(static_cast<const CT*>(a.oN) + i);
+        } else {
+          kS = ldc<CT, V>(static_cast<const CT*>(a.oS) + i); kW = ldc<CT, V>(static_cast<const CT*>(a.oW) + i);
+          kE = ldc<CT, V>(static_cast<const CT*>(a.oE) + i); kN = ldc<CT, V>(static_cast<const CT*>(a.oN) + i);
+        }
         Vec<T, V> kC;
         if constexpr (RECON) {
 #pragma unroll
@@ -339,8 +388,8 @@ __global__ __launch_bounds__(kBlock) void cg_k1(CgArgs<T> a, int k, int mode, in
           acc_pr = fma(cur.v[e], rr.v[e], acc_pr);
           acc_pz = fma(cur.v[e], tmp, acc_pz);
         }
-        stv<T, V>(a.z + i, zz);
-        if (mode != MODE_RESET) stv<T, V>(pout + i, cur);
+        if (a.nt & 4) { stv_nt<T, V>(a.z + i, zz); if (mode != MODE_RESET) stv_nt<T, V>(pout + i, cur); }
+        else { stv<T, V>(a.z + i, zz); if (mode != MODE_RESET) stv<T, V>(pout + i, cur); }
       }
       behind = cur;
       cur = ahead;
@@ -382,7 +431,10 @@ __global__ __launch_bounds__(kBlock) void cg_k2(CgArgs<T> a, int k, int sv) {
     const int c = ch + d * cr.step;
     iq[d] = ((size_t)c * kBlock + threadIdx.x) * V;
     okq[d] = c < cr.end && iq[d] < n;
-    if (okq[d]) { zq[d] = ldv<T, V>(zp + iq[d]); rq[d] = ldv<T, V>(rp + iq[d]); }
+    if (okq[d]) {
+      if (a.nt & 2) { zq[d] = ldc_nt<T, V>(zp + iq[d]); rq[d] = ldc_nt<T, V>(rp + iq[d]); }
+      else { zq[d] = ldv<T, V>(zp + iq[d]); rq[d] = ldv<T, V>(rp + iq[d]); }
+    }
   }
 
   T pa[3];
@@ -409,12 +461,15 @@ __global__ __launch_bounds__(kBlock) void cg_k2(CgArgs<T> a, int k, int sv) {
           acc_r += r0.v[e];
           acc_ex += (absval(r0.v[e]) < accuracy) ? (T)0 : (T)1;     // NaN counts as exceeding
         }
-        stv<T, V>(rp + iq[d], r0);
+        if (a.nt & 1) stv_nt<T, V>(rp + iq[d], r0); else stv<T, V>(rp + iq[d], r0);
       }
       const int c = ch + (d + D) * cr.step;
       iq[d] = ((size_t)c * kBlock + threadIdx.x) * V;
       okq[d] = c < cr.end && iq[d] < n;
-      if (okq[d]) { zq[d] = ldv<T, V>(zp + iq[d]); rq[d] = ldv<T, V>(rp + iq[d]); }
+      if (okq[d]) {
+        if (a.nt & 2) { zq[d] = ldc_nt<T, V>(zp + iq[d]); rq[d] = ldc_nt<T, V>(rp + iq[d]); }
+        else { zq[d] = ldv<T, V>(zp + iq[d]); rq[d] = ldv<T, V>(rp + iq[d]); }
+      }
     }
     ch += D * cr.step;
   }

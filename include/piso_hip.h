@@ -124,7 +124,8 @@ int piso_cg_fixed_iterations_f64(int nx, int ny, int periodic_x, int periodic_y,
                                  float* kernel_ms_out, void* workspace, size_t workspace_bytes, piso_stream_t stream);
 
 /* Sampling of K1 / K2 launch durations with HIP events on the launch stream (every `stride`-th iteration); used by
- * bench.py for roofline.achieved.  ms_sum / count: [2] = K1, K2. */
+ * bench.py for roofline.achieved.  ms_sum / count: [3] = K1 launches, K2 launches, persistent segments (count[2] = CG
+ * ITERATIONS executed inside persistent segments, ms_sum[2] = their total duration). */
 void piso_cg_profile_enable(int enable, int stride);
 void piso_cg_profile_read(double* ms_sum, long long* count);
 

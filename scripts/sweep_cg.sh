@@ -1,2 +1,3 @@
 #!/bin/bash
-for mb in 1024 2048; do for v in 2; do for r in 2 4 8; do echo "MAXBLOCKS=$mb V=$v RPW=$r"; PISO_CG_MAXBLOCKS=$mb PISO_CG_V=$v PISO_CG_RPW=$r python scripts/bench_cg.py 2048 2>&1 | grep grid; done; done; done
+for p in 0 1; do echo "PERSIST=$p"; PISO_CG_PERSIST=$p python scripts/bench_cg.py 2048 1024 512 2>&1 | grep grid; done
+for seg in 50 1000; do echo "SEGMENT=$seg"; PISO_CG_SEGMENT=$seg python scripts/bench_cg.py 2048 2>&1 | grep grid; done
