@@ -15,6 +15,7 @@ struct CgProfile {
   long long count[3] = {0, 0, 0};    // launches of K1, K2; ITERATIONS executed inside persistent segments
 };
 static CgProfile g_prof;
+constexpr size_t kPersistWsWords = (size_t)2 * kPersistMaxGrid * 16 + 64;   // records (2 x grid x 64 B) + error flag
 
 struct HostPoll {
   CgState* pinned = nullptr;   // [2]
@@ -39,6 +40,7 @@ static size_t cg_workspace_bytes(int nx, int ny) {
   b += align_up(4 * n * sizeof(float), 256) + 256;        // float copy of the off-diagonals + flag
   b += 3 * align_up(3 * kMaxPartials * sizeof(T), 256);
   b += align_up(SC_COUNT * sizeof(T), 256) + align_up(2 * sizeof(CgState), 256) + 512;
+  b += align_up(kPersistWsWords * sizeof(unsigned), 256);  // exchange records of the persistent kernel
   return b + 4096;
 }
 
@@ -106,7 +108,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, float accuracy, int max_ite
   // ---- persistent segments (cg_persist.h): applicable when every wave's region fits on chip
   int persist_R = 0, persist_grid = 0;
   PersistCtl pc;
-  pc.bar = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr;
+  pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr;
   if (V == 16 / (int)sizeof(T) && a.per_y != 2 && !getenv("PISO_CG_NO_PERSIST")) {
     int dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
@@ -114,9 +116,10 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, float accuracy, int max_ite
     const int ntx = nx / (64 * V);
     if (nx % (64 * V) == 0)                               // every lane of a strip has cells
       for (int R : {2, 4, 8}) {
+        if (const char* e = getenv("PISO_CG_PERSIST_R")) { if (atoi(e) != R) continue; }   // tests: force the region height
         if (ny % R != 0) continue;                        // every region has R rows
         const long long nreg = (long long)ntx * (ny / R);
-        if (nreg <= (long long)cus * kPersistRegionsPerWg) {
+        if (nreg % kPersistRegions == 0 && nreg <= (long long)cus * kPersistRegionsPerWg) {   // a wave owns 2 regions or none
           persist_R = R; pc.nreg = (int)nreg; pc.ntx = ntx;
           persist_grid = (int)((nreg + kPersistRegionsPerWg - 1) / kPersistRegionsPerWg);
           break;
@@ -127,16 +130,17 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, float accuracy, int max_ite
     if (force && atoi(force) == 0) persist_R = 0;
   }
   if (persist_R) {
-    pc.bar = persist_ws;
-    pc.err = reinterpret_cast<int*>(persist_ws + 16);
-    PISO_HIP_CHECK(hipMemsetAsync(persist_ws, 0, 128, stream));
+    pc.rec = reinterpret_cast<unsigned long long*>(persist_ws);
+    pc.err = reinterpret_cast<int*>(persist_ws + kPersistWsWords - 16);
+    PISO_HIP_CHECK(hipMemsetAsync(persist_ws, 0, kPersistWsWords * sizeof(unsigned), stream));
+    if (persist_grid > kPersistMaxGrid) persist_R = 0;
     if (getenv("PISO_CG_PERSIST_TIMING")) {               // diagnostics only: per-phase clocks of every workgroup
       PISO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&pc.timing), 4 * persist_grid * sizeof(unsigned long long)));
       PISO_HIP_CHECK(hipMemsetAsync(pc.timing, 0, 4 * persist_grid * sizeof(unsigned long long), stream));
     }
   }
   auto launch_segment = [&](int kb, int ke) -> int {
-    PISO_HIP_CHECK(hipMemsetAsync(pc.bar, 0, sizeof(unsigned), stream));
+    PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 64, stream));   // epochs restart at 1 in every launch
     if (persist_R == 2) cg_persist<T, CT, 2, RECON><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
     else if (persist_R == 4) cg_persist<T, CT, 4, RECON><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
     else cg_persist<T, CT, 8, RECON><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
@@ -278,7 +282,7 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   a.partsA = ar.take<T>(3 * kMaxPartials); a.partsB = ar.take<T>(3 * kMaxPartials); a.partsS = ar.take<T>(kMaxPartials);
   a.scal = ar.take<T>(SC_COUNT);
   a.state = ar.take<CgState>(2);
-  unsigned* persist_ws = ar.take<unsigned>(64);
+  unsigned* persist_ws = ar.take<unsigned>(kPersistWsWords);
   a.nx = nx; a.ny = ny; a.per_x = per_x; a.per_y = per_y;
   a.ntx = a.nty = a.rows_per_wave = 0; a.nA = a.nB = 0; a.accuracy = accuracy;
   a.gA = nullptr; a.gB = nullptr;

@@ -22,67 +22,85 @@ constexpr int kPersistRegions = 2;              // regions per wave
 constexpr int kPersistRegionsPerWg = kPersistWaves * kPersistRegions;
 
 struct PersistCtl {
-  unsigned* bar;        // monotonic arrival counter (zeroed before every launch)
+  unsigned long long* rec;   // exchange records: [2 (parity)][kPersistMaxGrid][8] 8-byte words, zeroed before every launch
   int* err;             // set to 1 if a spin gave up
   int nreg, ntx;        // regions (= waves with work), strips per row
   unsigned long long* timing;   // diagnostics (PISO_CG_PERSIST_TIMING): [4][grid] 100 MHz ticks in phase A / barrier A / phase B / barrier B
 };
+constexpr int kPersistMaxGrid = 512;
 
-// barrier + exchange of 3 partial sums per workgroup; returns the totals (fixed summation order) in every thread
+// Grid-wide exchange of 3 partial sums per workgroup that doubles as the grid barrier (measured 4.4 us for 256 workgroups
+// against 11.3 us for "atomic counter + fence + read the partials", scripts/barrier_bench.hip).
+//   * every workgroup publishes one 64-byte record: each double travels as two 8-byte words {32 payload bits | 32-bit epoch},
+//     written and read with relaxed agent-scope atomics (single-copy atomic, coherent across the 8 XCDs' L2s);
+//   * wave 0 of every workgroup polls all records until they carry the current epoch and adds them in a fixed order, so every
+//     workgroup obtains bitwise the same totals - no counter, no fence, one memory round trip;
+//   * records alternate between two arrays (epoch parity): a fast workgroup may publish epoch e+1 while a slow one still
+//     reads epoch e, and nobody can reach e+2 before everybody has published e+1.
+// DATA written before the exchange (p, the perimeter of r) is stored write-through at agent scope (sc1) and drained
+// (s_waitcnt vmcnt(0)) by every wave before the workgroup publishes; readers load it at agent scope as well.
 template <typename T>
-__device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T* __restrict__ gparts, T (&v)[3], unsigned target,
-                                              T* smem) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // workgroup partial: wave sums -> LDS -> thread 0
+__device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], unsigned epoch, T* smem) {
+  typedef unsigned long long u64;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  T* sm = smem + (epoch & 1) * 32;                          // parity double buffer: two __syncthreads per exchange
 #pragma unroll
   for (int q = 0; q < 3; ++q) v[q] = wave_sum(v[q]);
-  __syncthreads();
   if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) smem[q * kPersistWaves + wave] = v[q];
+    for (int q = 0; q < 3; ++q) sm[q * kPersistWaves + wave] = v[q];
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its stores before the barrier
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have completed
   __syncthreads();
-  bool ok = true;
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      T s = 0;
-      for (int w = 0; w < kPersistWaves; ++w) s += smem[q * kPersistWaves + w];
-      gparts[q * kMaxPartials + blockIdx.x] = s;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    while (__hip_atomic_load(c.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 24)) { *c.err = 1; ok = false; break; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  // every wave-0 lane sums a slice of the records, then the wave combines (same order in every workgroup)
   if (wave == 0) {
-    T s[3] = {0, 0, 0};
-    for (int b = lane; b < (int)gridDim.x; b += 64) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q) s[q] += gparts[q * kMaxPartials + b];
-    }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) s[q] = wave_sum(s[q]);
+    u64* rec = c.rec + (size_t)(epoch & 1) * kPersistMaxGrid * 8;
     if (lane == 0) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) smem[3 * kPersistWaves + q] = s[q];
-      smem[3 * kPersistWaves + 3] = ok ? (T)0 : (T)1;
+      for (int q = 0; q < 3; ++q) {
+        T s = 0;
+        for (int w = 0; w < kPersistWaves; ++w) s += sm[q * kPersistWaves + w];
+        const u64 bits = (u64)__double_as_longlong((double)s);
+        __hip_atomic_store(rec + (size_t)blockIdx.x * 8 + 2 * q, ((bits & 0xffffffffull) << 32) | epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + (size_t)blockIdx.x * 8 + 2 * q + 1, (bits & 0xffffffff00000000ull) | epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    double tot[3] = {0, 0, 0};
+    bool good = true;
+    for (int m = 0; m < ((int)gridDim.x + 63) / 64; ++m) {
+      const int b = m * 64 + lane;
+      const bool active = b < (int)gridDim.x;
+      u64 w[6] = {0, 0, 0, 0, 0, 0};
+      bool ok = !active;
+      unsigned spins = 0;
+      while (true) {
+        if (!ok) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) w[q] = __hip_atomic_load(rec + (size_t)b * 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = true;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) ok = ok && ((unsigned)(w[q] & 0xffffffffull) == epoch);
+        }
+        if (__all(ok)) break;
+        if (++spins > (1u << 22)) { good = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        tot[q] += active ? __longlong_as_double((long long)((w[2 * q] >> 32) | (w[2 * q + 1] & 0xffffffff00000000ull))) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) tot[q] = wave_sum(tot[q]);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) sm[24 + q] = (T)tot[q];
+      sm[27] = good ? (T)0 : (T)1;
+      if (!good) *c.err = 1;
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 3; ++q) v[q] = smem[3 * kPersistWaves + q];
-  const bool all_ok = smem[3 * kPersistWaves + 3] == (T)0;
-  __syncthreads();
-  return all_ok;
+  for (int q = 0; q < 3; ++q) v[q] = sm[24 + q];
+  return sm[27] == (T)0;
 }
 
 // ---- buffer addressing: a 128-bit descriptor per array in SGPRs, one per-lane byte offset in a VGPR, the row offset in an
@@ -91,49 +109,77 @@ using rsrc_t = __amdgpu_buffer_rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
 }
-template <typename S, int V>
+// cache policy of a buffer access (gfx940+ encoding of the intrinsics' aux operand): kAgent = sc1, the scope at which the
+// L2s of the 8 XCDs are coherent - used for everything one workgroup writes and another reads inside a launch.
+constexpr int kPlain = 0, kAgent = 16;
+template <typename S, int V, int AUX = kPlain>
 __device__ __forceinline__ Vec<S, V> bld(rsrc_t r, unsigned voff, unsigned soff) {
   Vec<S, V> o;
   constexpr int B = sizeof(S) * V;
   static_assert(B == 16 || B == 8, "16- or 8-byte lane accesses");
   if constexpr (B == 16) {
-    const auto t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    const auto t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, AUX);
     __builtin_memcpy(&o, &t, 16);
   } else {
-    const auto t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    const auto t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
     __builtin_memcpy(&o, &t, 8);
   }
   return o;
 }
-template <typename S>
+template <typename S, int AUX = kPlain>
 __device__ __forceinline__ S bld1(rsrc_t r, unsigned voff, unsigned soff) {
   S o;
   if constexpr (sizeof(S) == 8) {
-    const auto t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    const auto t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, AUX);
     __builtin_memcpy(&o, &t, 8);
   } else {
-    const auto t = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+    const auto t = __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX);
     __builtin_memcpy(&o, &t, 4);
   }
   return o;
 }
-template <typename S, int V>
+template <typename S, int V, int AUX = kPlain>
 __device__ __forceinline__ void bst(rsrc_t r, unsigned voff, unsigned soff, const Vec<S, V>& v) {
   static_assert(sizeof(S) * V == 16, "16-byte lane stores");
   __attribute__((ext_vector_type(4))) unsigned int t;
   __builtin_memcpy(&t, &v, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, soff, AUX);
 }
-template <typename S>
+template <typename S, int AUX = kPlain>
 __device__ __forceinline__ void bst1(rsrc_t r, unsigned voff, unsigned soff, S v) {
   if constexpr (sizeof(S) == 8) {
     __attribute__((ext_vector_type(2))) unsigned int t;
     __builtin_memcpy(&t, &v, 8);
-    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, soff, AUX);
   } else {
     unsigned int t;
     __builtin_memcpy(&t, &v, 4);
-    __builtin_amdgcn_raw_buffer_store_b32(t, r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(t, r, voff, soff, AUX);
+  }
+}
+
+// value of lane `src` (compile-time constant after unrolling) as a wave-uniform scalar
+template <typename S>
+__device__ __forceinline__ S read_lane(S v, int src) {
+  if constexpr (sizeof(S) == 8) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+    return (S)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  } else {
+    return (S)__int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)v), src));
+  }
+}
+// lane l receives `v` of lane l - 1 (UP) or l + 1 (!UP) through the DPP wavefront shifts; the lane without a source keeps `edge`
+template <bool UP, typename S>
+__device__ __forceinline__ S shift_lane(S v, S edge) {
+  constexpr int ctrl = UP ? 0x138 /* wave_shr:1 */ : 0x130 /* wave_shl:1 */;
+  if constexpr (sizeof(S) == 8) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong((double)v), e = (unsigned long long)__double_as_longlong((double)edge);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)e, (int)(unsigned)b, ctrl, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(e >> 32), (int)(unsigned)(b >> 32), ctrl, 0xf, 0xf, false);
+    return (S)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  } else {
+    return (S)__int_as_float(__builtin_amdgcn_update_dpp(__float_as_int((float)edge), __float_as_int((float)v), ctrl, 0xf, 0xf, false));
   }
 }
 
@@ -143,7 +189,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   constexpr int V = 16 / sizeof(T);                        // 16-byte lane accesses
   constexpr int NQ = kPersistRegions;
   __shared__ T xs[kPersistRegionsPerWg * R * 64 * V];      // the solution of my regions (128 KB at R = 8, fp64)
-  __shared__ T smem[4 * kPersistWaves];
+  __shared__ T smem[64];
   const int nx = a.nx, ny = a.ny;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar branches, SGPRs
@@ -237,7 +283,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
 #pragma unroll
           for (int jj = 0; jj < R; ++jj) {
             Vec<T, V> xv = ldv<T, V>(xl + jj * 64 * V);
-            const Vec<T, V> pq = bld<T, V>(Rpin, vT, (unsigned)(j0[q] + jj) * rowT);
+            const Vec<T, V> pq = bld<T, V, kAgent>(Rpin, vT, (unsigned)(j0[q] + jj) * rowT);
 #pragma unroll
             for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha, pq.v[e], xv.v[e]);
             stv<T, V>(xl + jj * 64 * V, xv);
@@ -250,96 +296,121 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
 
     // ---- phase A: x += alpha_prev p_old ; p_new = r + beta p_old (own rows from registers, halo from HBM) ; z' = L p_new
     T sA[3] = {0, 0, 0};                                   // sum p, p.r, p.z'
+    if (has[0]) {                                          // the host makes nreg a multiple of NQ: a wave owns NQ regions or none
+      // The rows of both regions form ONE software pipeline of NT steps: the loads of step t + D (p_old and the four
+      // coefficient rows; with the first / last row of a region also its edge columns and halo rows) are issued before step t
+      // computes, so ~D rows x 48 B per lane are in flight instead of one (the kernel runs 2 waves per SIMD: latency must be
+      // hidden inside the wave).  sched_barrier pins that order; the compiler derives exact s_waitcnt vmcnt(N) from it.
+      constexpr int row_regs = (16 + 4 * (int)sizeof(CT) * V + (RECON ? 0 : 16)) / 4;      // VGPRs of one row in flight
+      constexpr int Dw = 48 / row_regs < 2 ? 2 : (48 / row_regs > 4 ? 4 : 48 / row_regs);
+      constexpr int NT = NQ * R, D = (R >= Dw) ? Dw : R;
+      Vec<T, V> Pq[NT], hbR[NQ], hbP[NQ], haR[NQ], haP[NQ];
+      Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT];
+      Vec<T, V> cD[NT];
+      T eP[NQ], eR[NQ];
+      unsigned vT[NQ], vC[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      if (!has[q]) continue;
-      const int cq = (tx0[q] * 64 + lane) * V;
-      const unsigned vT = (unsigned)(cq * sizeof(T)), vC = (unsigned)(cq * sizeof(CT));
-      T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
-      // p_new of one cell of another region's column (strip-edge neighbours), row j of MY region
-      auto edge_val = [&](int j, int cc) __attribute__((always_inline)) -> T {
-        const unsigned vo = (unsigned)(cc * sizeof(T)), so = (unsigned)j * rowT;
-        return fma(beta, bld1<T>(Rpin, vo, so), bld1<T>(Rr, vo, so));
+      for (int q = 0; q < NQ; ++q) {
+        const int cq = (tx0[q] * 64 + lane) * V;
+        vT[q] = (unsigned)(cq * sizeof(T)); vC[q] = (unsigned)(cq * sizeof(CT));
+      }
+      auto issue = [&](int t) __attribute__((always_inline)) {
+        const int q = t / R, jj = t - q * R;
+        const unsigned sT = (unsigned)(j0[q] + jj) * rowT, sC = (unsigned)(j0[q] + jj) * rowC;
+        if (jj == 0) {
+          // p_new on the two columns next to the strip, all R rows with ONE pair of loads: lane l < R holds the left
+          // neighbour of row l, lane R + l the right neighbour; lanes without a cell (and walls) read out of range -> 0
+          const int side = lane / R, er = lane - side * R;
+          int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
+          if (cc < 0) cc = a.per_x ? nx - 1 : -1;
+          else if (cc >= nx) cc = a.per_x ? 0 : -1;
+          const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
+          eP[q] = bld1<T, kAgent>(Rpin, vo, 0);
+          eR[q] = bld1<T, kAgent>(Rr, vo, 0);
+          bool valid;
+          const int jw = row_wrap(j0[q] - 1, valid);
+          const unsigned vh = valid ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
+          hbR[q] = bld<T, V, kAgent>(Rr, vh, (unsigned)jw * rowT);
+          hbP[q] = bld<T, V, kAgent>(Rpin, vh, (unsigned)jw * rowT);
+        }
+        Pq[t] = bld<T, V, kAgent>(Rpin, vT[q], sT);
+        cS[t] = bld<CT, V>(RoS, vC[q], sC); cW[t] = bld<CT, V>(RoW, vC[q], sC);
+        cE[t] = bld<CT, V>(RoE, vC[q], sC); cN[t] = bld<CT, V>(RoN, vC[q], sC);
+        if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
+        if (jj == R - 1) {
+          bool valid;
+          const int jw = row_wrap(j0[q] + R, valid);
+          const unsigned vh = valid ? vT[q] : 0xffffffffu;
+          haR[q] = bld<T, V, kAgent>(Rr, vh, (unsigned)jw * rowT);
+          haP[q] = bld<T, V, kAgent>(Rpin, vh, (unsigned)jw * rowT);
+        }
       };
-      auto halo_row = [&](int j) __attribute__((always_inline)) -> Vec<T, V> {   // p_new on a row owned by another region
-        Vec<T, V> o;
+      // own row t of the new direction; also performs x <- x + alpha_prev p_old (the axpy of iteration k-1, :303)
+      auto own_row = [&](int t) __attribute__((always_inline)) -> Vec<T, V> {
+        const int q = t / R, jj = t - q * R;
+        T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V + jj * 64 * V;
+        Vec<T, V> o, xv = ldv<T, V>(xl);
 #pragma unroll
-        for (int e = 0; e < V; ++e) o.v[e] = 0;
-        bool valid;
-        const int jw = row_wrap(j, valid);
-        if (!valid) return o;
-        o = bld<T, V>(Rr, vT, (unsigned)jw * rowT);
-        const Vec<T, V> pq = bld<T, V>(Rpin, vT, (unsigned)jw * rowT);
-#pragma unroll
-        for (int e = 0; e < V; ++e) o.v[e] = fma(beta, pq.v[e], o.v[e]);
+        for (int e = 0; e < V; ++e) { o.v[e] = fma(beta, Pq[t].v[e], rr[q][jj].v[e]); xv.v[e] = fma(alpha_prev, Pq[t].v[e], xv.v[e]); }
+        stv<T, V>(xl, xv);
         return o;
       };
-      // own row jj of the new direction; also performs x <- x + alpha_prev p_old (the axpy of iteration k-1, :303)
-      auto own_row = [&](int jj, const Vec<T, V>& rreg) __attribute__((always_inline)) -> Vec<T, V> {
-        Vec<T, V> o;
-        const Vec<T, V> pq = bld<T, V>(Rpin, vT, (unsigned)(j0[q] + jj) * rowT);
-        Vec<T, V> xv = ldv<T, V>(xl + jj * 64 * V);
 #pragma unroll
-        for (int e = 0; e < V; ++e) { o.v[e] = fma(beta, pq.v[e], rreg.v[e]); xv.v[e] = fma(alpha_prev, pq.v[e], xv.v[e]); }
-        stv<T, V>(xl + jj * 64 * V, xv);
-        return o;
-      };
-      Vec<T, V> behind = halo_row(j0[q] - 1);
-      Vec<T, V> cur = own_row(0, rr[q][0]);
+      for (int t = 0; t < D; ++t) issue(t);
+      Vec<T, V> behind, cur, ahead;
+      T edge = 0;
 #pragma unroll
-      for (int jj = 0; jj < R; ++jj) {
-        const int j = j0[q] + jj;
-        const unsigned sT = (unsigned)j * rowT, sC = (unsigned)j * rowC;
-        Vec<T, V> ahead;
-        if (jj + 1 < R) ahead = own_row(jj + 1 < R ? jj + 1 : jj, rr[q][jj + 1 < R ? jj + 1 : jj]);
-        else ahead = halo_row(j0[q] + R);
-        T left = __shfl_up(cur.v[V - 1], 1, kWave);
-        T right = __shfl_down(cur.v[0], 1, kWave);
-        if (lane == 0) {
-          const int cc = cq - 1;
-          left = (cc >= 0) ? edge_val(j, cc) : (a.per_x ? edge_val(j, nx - 1) : (T)0);
+      for (int t = 0; t < NT; ++t) {
+        const int q = t / R, jj = t - q * R;
+        if (t + D < NT) issue(t + D < NT ? t + D : t);
+        if (jj == 0) {
+          edge = fma(beta, eP[q], eR[q]);
+#pragma unroll
+          for (int e = 0; e < V; ++e) behind.v[e] = fma(beta, hbP[q].v[e], hbR[q].v[e]);
+          cur = own_row(t);
         }
-        if (lane == 63) {
-          const int cc = cq + V;
-          right = (cc < nx) ? edge_val(j, cc) : (a.per_x ? edge_val(j, 0) : (T)0);
+        if (jj + 1 < R) ahead = own_row(t + 1 < NT ? t + 1 : t);
+        else {
+#pragma unroll
+          for (int e = 0; e < V; ++e) ahead.v[e] = fma(beta, haP[q].v[e], haR[q].v[e]);
         }
-        const Vec<CT, V> kS = bld<CT, V>(RoS, vC, sC), kW = bld<CT, V>(RoW, vC, sC), kE = bld<CT, V>(RoE, vC, sC),
-                         kN = bld<CT, V>(RoN, vC, sC);
+        const T left = shift_lane<true, T>(cur.v[V - 1], read_lane<T>(edge, jj));
+        const T right = shift_lane<false, T>(cur.v[0], read_lane<T>(edge, R + jj));
         Vec<T, V> kC;
         if constexpr (RECON) {
 #pragma unroll
           for (int e = 0; e < V; ++e) {
             T d = 0;
-            d -= (T)kS.v[e]; d -= (T)kN.v[e]; d -= (T)kW.v[e]; d -= (T)kE.v[e];
+            d -= (T)cS[t].v[e]; d -= (T)cN[t].v[e]; d -= (T)cW[t].v[e]; d -= (T)cE[t].v[e];
             kC.v[e] = d;
           }
         } else {
-          kC = bld<T, V>(RcC, vT, sT);
+          kC = cD[t];
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           const T pw = (e == 0) ? left : cur.v[e > 0 ? e - 1 : 0];
           const T pe = (e == V - 1) ? right : cur.v[e < V - 1 ? e + 1 : 0];
           T tmp = 0;                                        // summation order of calcZ_v4 (:81-90)
-          tmp = fma((T)kS.v[e], behind.v[e], tmp);
-          tmp = fma((T)kW.v[e], pw, tmp);
+          tmp = fma((T)cS[t].v[e], behind.v[e], tmp);
+          tmp = fma((T)cW[t].v[e], pw, tmp);
           tmp = fma(kC.v[e], cur.v[e], tmp);
-          tmp = fma((T)kE.v[e], pe, tmp);
-          tmp = fma((T)kN.v[e], ahead.v[e], tmp);
+          tmp = fma((T)cE[t].v[e], pe, tmp);
+          tmp = fma((T)cN[t].v[e], ahead.v[e], tmp);
           zz[q][jj].v[e] = tmp;
           sA[0] += cur.v[e];
           sA[1] = fma(cur.v[e], rr[q][jj].v[e], sA[1]);
           sA[2] = fma(cur.v[e], tmp, sA[2]);
         }
-        bst<T, V>(Rpout, vT, sT, cur);
+        bst<T, V, kAgent>(Rpout, vT[q], (unsigned)(j0[q] + jj) * rowT, cur);
         behind = cur;
         cur = ahead;
-        if (jj & 1) __builtin_amdgcn_sched_barrier(0);       // at most two rows of loads in flight per region: bounds the VGPR pressure
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     ++epoch;
     tick(0);
-    healthy = grid_exchange<T>(c, a.partsA, sA, epoch * gridDim.x, smem);
+    healthy = grid_exchange<T>(c, sA, epoch, smem);
     tick(1);
     if (!healthy) break;
     // ---- alpha (:301-302), then phase B: r -= alpha (z' + vs), partial sums, publish the perimeter of r
@@ -364,16 +435,16 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
         }
         const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
         if (jj == 0 || jj == R - 1) {
-          bst<T, V>(Rr, vT, sT, rr[q][jj]);                   // edge rows: whole row
+          bst<T, V, kAgent>(Rr, vT, sT, rr[q][jj]);           // edge rows: whole row
         } else {
-          if (lane == 0) bst1<T>(Rr, vT, sT, rr[q][jj].v[0]);                                   // edge columns
-          if (lane == 63) bst1<T>(Rr, vT + (unsigned)((V - 1) * sizeof(T)), sT, rr[q][jj].v[V - 1]);
+          if (lane == 0) bst1<T, kAgent>(Rr, vT, sT, rr[q][jj].v[0]);                           // edge columns
+          if (lane == 63) bst1<T, kAgent>(Rr, vT + (unsigned)((V - 1) * sizeof(T)), sT, rr[q][jj].v[V - 1]);
         }
       }
     }
     ++epoch;
     tick(2);
-    healthy = grid_exchange<T>(c, a.partsB, sB, epoch * gridDim.x, smem);
+    healthy = grid_exchange<T>(c, sB, epoch, smem);
     tick(3);
 #pragma unroll
     for (int q = 0; q < 3; ++q) tB[q] = sB[q];

@@ -1,0 +1,295 @@
+// Micro-benchmark of grid-wide "barrier + 3 sums" exchanges on MI355X (diagnostics for cg_persist.h; not part of the library).
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/barrier_bench scripts/barrier_bench.hip && /tmp/barrier_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); exit(1); } } while (0)
+
+constexpr int kThreads = 512, kWaves = 8, kMaxG = 256;
+typedef unsigned long long u64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double sum16(double v) {
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+struct Ctl {
+  unsigned* bar; double* parts;       // V0
+  u64* rec;                           // V1/V2: [G][8] tagged words (6 used), 64-byte records
+  u64* grp;                           // V2: [G/16][8]
+  u64* loc;                           // V3: XCC-local
+  int* xcc;                           // out: XCC id per block
+};
+
+// ---------------- V0: counter + fence + partials (what cg_persist.h does today)
+__device__ void exch_v0(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = 0; q < 3; ++q) v[q] = wave_sum(v[q]);
+  __syncthreads();
+  if (lane == 0) for (int q = 0; q < 3; ++q) smem[q * kWaves + wave] = v[q];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 3; ++q) { double s = 0; for (int w = 0; w < kWaves; ++w) s += smem[q * kWaves + w]; c.parts[q * kMaxG + blockIdx.x] = s; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(c.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(c.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * gridDim.x) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (wave == 0) {
+    double s[3] = {0, 0, 0};
+    for (int b = lane; b < (int)gridDim.x; b += 64) for (int q = 0; q < 3; ++q) s[q] += c.parts[q * kMaxG + b];
+    for (int q = 0; q < 3; ++q) s[q] = wave_sum(s[q]);
+    if (lane == 0) for (int q = 0; q < 3; ++q) smem[3 * kWaves + q] = s[q];
+  }
+  __syncthreads();
+  for (int q = 0; q < 3; ++q) v[q] = smem[3 * kWaves + q];
+  __syncthreads();
+}
+
+// tagged words: a double travels as two 8-byte words {32 payload bits, 32-bit epoch}; 8-byte accesses are single-copy atomic
+__device__ __forceinline__ void put_tagged(u64* rec, const double (&s)[3], unsigned epoch) {
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const u64 bits = __double_as_longlong(s[q]);
+    __hip_atomic_store(rec + 2 * q, ((bits & 0xffffffffull) << 32) | epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(rec + 2 * q + 1, (bits & 0xffffffff00000000ull) | epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// poll one record until all six words carry `epoch`; `active` lanes only; returns the three doubles
+__device__ __forceinline__ void get_tagged(const u64* rec, bool active, unsigned epoch, double (&s)[3]) {
+  u64 w[6];
+  bool ok = !active;
+  for (int q = 0; q < 6; ++q) w[q] = 0;
+  while (true) {
+    if (!ok) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) w[q] = __hip_atomic_load(rec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ok = true;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) ok = ok && ((unsigned)(w[q] & 0xffffffffull) == epoch);
+    }
+    if (__all(ok)) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) s[q] = active ? __longlong_as_double((w[2 * q] >> 32) | (w[2 * q + 1] & 0xffffffff00000000ull)) : 0.0;
+}
+
+// workgroup partial with two __syncthreads (parity double-buffered LDS); result valid in wave 0
+__device__ __forceinline__ void wg_partial(double (&v)[3], double* smem, unsigned epoch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sm = smem + (epoch & 1) * 32;
+  for (int q = 0; q < 3; ++q) v[q] = wave_sum(v[q]);
+  if (lane == 0) for (int q = 0; q < 3; ++q) sm[q * kWaves + wave] = v[q];
+  __syncthreads();
+  if (wave == 0) for (int q = 0; q < 3; ++q) { double s = 0; for (int w = 0; w < kWaves; ++w) s += sm[q * kWaves + w]; v[q] = s; }
+}
+__device__ __forceinline__ void wg_broadcast(double (&v)[3], double* smem, unsigned epoch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sm = smem + (epoch & 1) * 32 + 24;
+  if (wave == 0 && lane == 0) for (int q = 0; q < 3; ++q) sm[q] = v[q];
+  __syncthreads();
+  for (int q = 0; q < 3; ++q) v[q] = sm[q];
+}
+
+// ---------------- V1: flat all-to-all of tagged records
+__device__ void exch_v1(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wg_partial(v, smem, epoch);
+  if (wave == 0) {
+    if (lane == 0) put_tagged(c.rec + (size_t)blockIdx.x * 8, v, epoch);
+    double tot[3] = {0, 0, 0};
+    for (int m = 0; m < ((int)gridDim.x + 63) / 64; ++m) {
+      const int b = m * 64 + lane;
+      double s[3];
+      get_tagged(c.rec + (size_t)b * 8, b < (int)gridDim.x, epoch, s);
+      for (int q = 0; q < 3; ++q) tot[q] += s[q];
+    }
+    for (int q = 0; q < 3; ++q) v[q] = wave_sum(tot[q]);
+  }
+  wg_broadcast(v, smem, epoch);
+}
+
+// ---------------- V3: flat all-to-all, every lane polls its (up to) NR records concurrently
+template <int NR>
+__device__ void exch_v3(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wg_partial(v, smem, epoch);
+  if (wave == 0) {
+    if (lane == 0) put_tagged(c.rec + (size_t)blockIdx.x * 8, v, epoch);
+    u64 w[NR][6];
+    bool ok[NR];
+#pragma unroll
+    for (int m = 0; m < NR; ++m) ok[m] = (m * 64 + lane) >= (int)gridDim.x;
+    while (true) {
+      bool all = true;
+#pragma unroll
+      for (int m = 0; m < NR; ++m) {
+        if (!ok[m]) {
+          const u64* rec = c.rec + (size_t)(m * 64 + lane) * 8;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) w[m][q] = __hip_atomic_load(rec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < NR; ++m) {
+        if (!ok[m]) {
+          bool o = true;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) o = o && ((unsigned)(w[m][q] & 0xffffffffull) == epoch);
+          ok[m] = o;
+        }
+        all = all && ok[m];
+      }
+      if (__all(all)) break;
+    }
+    double tot[3] = {0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+      const bool act = (m * 64 + lane) < (int)gridDim.x;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) tot[q] += act ? __longlong_as_double((w[m][2 * q] >> 32) | (w[m][2 * q + 1] & 0xffffffff00000000ull)) : 0.0;
+    }
+    for (int q = 0; q < 3; ++q) v[q] = wave_sum(tot[q]);
+  }
+  wg_broadcast(v, smem, epoch);
+}
+
+// ---------------- V4: as V3 but word-major layout: word q of workgroup b at rec[q * kMaxG + b] (coalesced polls)
+template <int NR, int SLEEP>
+__device__ void exch_v4(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wg_partial(v, smem, epoch);
+  if (wave == 0) {
+    if (lane < 6) {
+      const u64 bits = __double_as_longlong(v[lane >> 1 == 0 ? 0 : (lane >> 1 == 1 ? 1 : 2)]);
+      const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+      __hip_atomic_store(c.rec + (size_t)lane * kMaxG + blockIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    u64 w[NR][6];
+    bool ok[NR];
+#pragma unroll
+    for (int m = 0; m < NR; ++m) ok[m] = (m * 64 + lane) >= (int)gridDim.x;
+    while (true) {
+      bool all = true;
+#pragma unroll
+      for (int m = 0; m < NR; ++m) {
+        if (!ok[m]) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) w[m][q] = __hip_atomic_load(c.rec + (size_t)q * kMaxG + m * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < NR; ++m) {
+        if (!ok[m]) {
+          bool o = true;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) o = o && ((unsigned)(w[m][q] & 0xffffffffull) == epoch);
+          ok[m] = o;
+        }
+        all = all && ok[m];
+      }
+      if (__all(all)) break;
+      if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
+    }
+    double tot[3] = {0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+      const bool act = (m * 64 + lane) < (int)gridDim.x;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) tot[q] += act ? __longlong_as_double((w[m][2 * q] >> 32) | (w[m][2 * q + 1] & 0xffffffff00000000ull)) : 0.0;
+    }
+    for (int q = 0; q < 3; ++q) v[q] = wave_sum(tot[q]);
+  }
+  wg_broadcast(v, smem, epoch);
+}
+
+// ---------------- V2: two levels of 16 (leader = first workgroup of each group of 16)
+__device__ void exch_v2(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int G = gridDim.x, ngrp = (G + 15) / 16, g = blockIdx.x / 16;
+  wg_partial(v, smem, epoch);
+  if (wave == 0) {
+    if (lane == 0) put_tagged(c.rec + (size_t)blockIdx.x * 8, v, epoch);
+    if ((blockIdx.x & 15) == 0) {
+      const int b = g * 16 + lane;
+      double s[3];
+      get_tagged(c.rec + (size_t)b * 8, lane < 16 && b < G, epoch, s);
+      for (int q = 0; q < 3; ++q) s[q] = sum16(s[q]);
+      if (lane == 0) put_tagged(c.grp + (size_t)g * 8, s, epoch);
+    }
+    double s[3];
+    get_tagged(c.grp + (size_t)lane * 8, lane < ngrp, epoch, s);
+    for (int q = 0; q < 3; ++q) v[q] = sum16(s[q]);
+  }
+  wg_broadcast(v, smem, epoch);
+}
+
+template <int VAR>
+__global__ __launch_bounds__(kThreads) void bench(Ctl c, int iters, double* out, u64* ticks) {
+  __shared__ double smem[64];
+  double acc = 0;
+  if (threadIdx.x == 0) {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    c.xcc[blockIdx.x] = (int)(x & 0xf);
+  }
+  const u64 t0 = wall_clock64();
+  for (int it = 1; it <= iters; ++it) {
+    double v[3] = {1.0, (double)(threadIdx.x & 3), (double)it * 1e-3};
+    if (VAR == 0) exch_v0(c, v, (unsigned)it, smem);
+    if (VAR == 1) exch_v1(c, v, (unsigned)it, smem);
+    if (VAR == 2) exch_v2(c, v, (unsigned)it, smem);
+    if (VAR == 3) exch_v3<4>(c, v, (unsigned)it, smem);
+    if (VAR == 4) exch_v4<4, 0>(c, v, (unsigned)it, smem);
+    if (VAR == 5) exch_v4<4, 1>(c, v, (unsigned)it, smem);
+    if (VAR == 6) exch_v4<4, 4>(c, v, (unsigned)it, smem);
+    acc += v[0] + v[1] + v[2];
+  }
+  const u64 t1 = wall_clock64();
+  if (threadIdx.x == 0) { out[blockIdx.x] = acc; ticks[blockIdx.x] = t1 - t0; }
+}
+
+int main(int argc, char** argv) {
+  const int G = argc > 1 ? atoi(argv[1]) : 256, iters = argc > 2 ? atoi(argv[2]) : 2000;
+  Ctl c;
+  CK(hipMalloc((void**)&c.bar, 256)); CK(hipMalloc((void**)&c.parts, 3 * kMaxG * 8));
+  CK(hipMalloc((void**)&c.rec, kMaxG * 64)); CK(hipMalloc((void**)&c.grp, 16 * 64)); CK(hipMalloc((void**)&c.loc, kMaxG * 64));
+  CK(hipMalloc((void**)&c.xcc, kMaxG * 4));
+  double* out; u64* ticks;
+  CK(hipMalloc((void**)&out, kMaxG * 8)); CK(hipMalloc((void**)&ticks, kMaxG * 8));
+  const double expect = (double)G * kThreads * 1.0 + (double)G * (kThreads / 4) * 6.0;
+  for (int var = 0; var < 7; ++var) {
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipMemset(c.bar, 0, 256)); CK(hipMemset(c.rec, 0, kMaxG * 64)); CK(hipMemset(c.grp, 0, 16 * 64));
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      CK(hipEventRecord(e0));
+      if (var == 0) bench<0><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 1) bench<1><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 2) bench<2><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 3) bench<3><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 4) bench<4><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 5) bench<5><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 6) bench<6><<<G, kThreads>>>(c, iters, out, ticks);
+      CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      std::vector<double> h(G); CK(hipMemcpy(h.data(), out, G * 8, hipMemcpyDeviceToHost));
+      double want = 0; for (int it = 1; it <= iters; ++it) want += expect + (double)G * kThreads * it * 1e-3;
+      bool same = true; for (int b = 1; b < G; ++b) same = same && (h[b] == h[0]);
+      printf("variant %d G=%d: %.3f us per exchange; acc[0]=%.6e want %.6e identical across workgroups: %d\n", var, G, 1e3 * ms / iters, h[0], want, (int)same);
+    }
+  }
+  std::vector<int> xc(G); CK(hipMemcpy(xc.data(), c.xcc, G * 4, hipMemcpyDeviceToHost));
+  printf("XCC id of blocks 0..31:"); for (int b = 0; b < 32 && b < G; ++b) printf(" %d", xc[b]); printf("\n");
+  int mism = 0; for (int b = 0; b < G; ++b) mism += (xc[b] != xc[b % 8]); printf("blocks whose XCC differs from block (b %% 8): %d\n", mism);
+  return 0;
+}

@@ -144,6 +144,84 @@ def test_cg_rank_deficient_shift(name, shape, reset):
         assert np.abs(x.cpu().numpy() - xo).max() <= 1e-9 * np.abs(xo).max()
 
 
+def _persist_iterations():
+    """Iterations executed inside persistent segments since the profile was enabled (piso_cg_profile_read, entry 2)."""
+    import ctypes as C
+    from diffpiso import _native as N
+    ms, cnt = (C.c_double * 3)(), (C.c_longlong * 3)()
+    N.lib.piso_cg_profile_read(ms, cnt)
+    return int(cnt[2])
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("shape,reset,segment,rows", [((16, 128), 1000, 7, 2), ((64, 256), 200, 16, 8), ((36, 384), 1000, 1000, 2),
+                                                      ((32, 128), 1000, 30, 4), ((16, 256), 25, 1000, 8)])
+def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, monkeypatch):
+    """The persistent segment kernel (cg_persist.h: r / z' in registers, x in LDS, grid-wide exchanges instead of launches)
+    is the path the 2048^2 benchmark runs; force it on small grids and hold it to the same bar as the two-kernel path:
+    round-off level agreement with the oracle along the trajectory, across segment boundaries and residual resets, and the
+    same stopping cadence."""
+    from diffpiso.solvers import cg_solve_native
+    from diffpiso import _native as N
+    s, L, b = _laplace_case(name, shape[0], shape[1], seed=5)
+    px, py = s.periodic_yx[1], s.periodic_yx[0]
+    monkeypatch.setenv("PISO_CG_PERSIST", "1")
+    monkeypatch.setenv("PISO_CG_SEGMENT", str(segment))
+    monkeypatch.setenv("PISO_CG_PERSIST_R", str(rows))     # region height (2 / 4 / 8 rows): three kernel instantiations
+    N.lib.piso_cg_profile_enable(1, 8)
+    try:
+        for nit in (2, 3, 9, 23, 47):
+            x, it = cg_solve_native(s.nx, s.ny, px, py, dev(L), dev(b), 1e-30, nit, False, reset)
+            xo, ito = O.cg_solve(s.nx, s.ny, px, py, L, b, 1e-30, nit, False, reset)
+            assert it == ito == nit
+            # (beyond ~25 iterations the small grids are converged to round-off and the trajectories start to separate)
+            assert np.abs(x.cpu().numpy() - xo).max() <= (1e-9 if nit <= 23 else 1e-6) * np.abs(xo).max(), nit
+        assert _persist_iterations() >= 70, "the persistent kernel did not run"
+        tol = 1e-9
+        x, it = cg_solve_native(s.nx, s.ny, px, py, dev(L), dev(b), tol, 6000, False, reset)
+        xo, ito = O.cg_solve(s.nx, s.ny, px, py, L, b, tol, 6000, False, reset)
+        if ito < 6000:                                     # (frequent resets can keep the wall-bounded cases from getting there)
+            assert abs(it - ito) <= max(5, 0.1 * ito), (it, ito)      # (restarts make long solves sensitive to round-off)
+            assert it % 5 == 0 and it >= 10 and it % reset != 0
+            assert np.abs(x.cpu().numpy() - xo).max() <= 1e-6 * np.abs(xo).max()
+        else:
+            assert it > 3000
+    finally:
+        N.lib.piso_cg_profile_enable(0, 8)
+
+
+def test_cg_persistent_shift_nan_and_float32(monkeypatch):
+    from diffpiso.solvers import cg_solve_native
+    from diffpiso import _native as N
+    monkeypatch.setenv("PISO_CG_PERSIST", "1")
+    monkeypatch.setenv("PISO_CG_SEGMENT", "25")
+    s, L, b = _laplace_case("periodic", 32, 256, seed=2)
+    N.lib.piso_cg_profile_enable(1, 8)
+    try:
+        # rank-1 shift: converged answer, zero mean (the iteration count is chaotic, see test_cg_rank_deficient_shift)
+        x, it = cg_solve_native(s.nx, s.ny, True, True, dev(L), dev(b), 1e-9, 6000, True, 1000)
+        xo, ito = O.cg_solve(s.nx, s.ny, True, True, L, b, 1e-9, 6000, True, 1000)
+        assert it < 6000 and ito < 6000 and it % 5 == 0
+        assert np.abs(x.cpu().numpy() - xo).max() <= 1e-6 * np.abs(xo).max()
+        assert abs(float(x.mean())) <= 1e-7 * float(x.abs().max())
+        n0 = _persist_iterations()
+        assert n0 > 0
+        # a NaN right-hand side must run to max_iterations and hand the NaN back - never hang in a grid exchange
+        b2 = b.copy()
+        b2[5] = np.nan
+        x, it = cg_solve_native(s.nx, s.ny, True, True, dev(L), dev(b2), 1e-8, 60, True, 1000)
+        assert it == 60 and torch.isnan(x).any()
+        # float32 solver (4 cells per lane: strips of 256 columns)
+        # (un-shifted: at this size the float32 right-hand side is not zero-mean enough for the shifted operator, oracle included)
+        x, it = cg_solve_native(s.nx, s.ny, True, True, dev(L, torch.float32), dev(b, torch.float32), 1e-4, 2000, False, 1000)
+        xo, ito = O.cg_solve(s.nx, s.ny, True, True, L, b, 1e-4, 2000, False, 1000, dtype=np.float32)
+        assert it < 2000 and ito < 2000 and abs(it - ito) <= 0.1 * ito
+        assert np.abs(x.cpu().numpy() - xo).max() < 1e-3 * np.abs(xo).max()
+        assert _persist_iterations() > n0 + 60
+    finally:
+        N.lib.piso_cg_profile_enable(0, 8)
+
+
 @pytest.mark.parametrize("dtype", [np.float32])
 def test_cg_float32_path(dtype):
     from diffpiso.solvers import cg_solve_native
