@@ -32,6 +32,10 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X
 # 128 B per cell per CG iteration = 16 fp64 words: matrix 5, SpMV 2, x update 3, r update 3, p update 3.
 K1_BYTES_PER_CELL = 104.0    # K1 covers matrix 5 + SpMV 2 + p update 3 + x update 3 words (it adds the previous direction to x)
 K2_BYTES_PER_CELL = 24.0     # K2 covers the r update: 3 words
+CG_BYTES_PER_CELL_ITER = 128.0   # 16 fp64 words per cell and CG iteration
+# what cg_persist has to move through HBM per cell and iteration (R = 8 rows per region): p read + write 16 B, 4 float
+# off-diagonals 16 B, halo rows of r and p 2/8 * 16 B, perimeter of r written 2/8 * 8 B, edge columns ~0.4 B
+PERSIST_HBM_BYTES_PER_CELL_ITER = 38.4
 
 
 def turbulence_velocity(n, seed=0, k0=8.0):
@@ -209,8 +213,8 @@ def main():
     grad, loss, warn = run_unrolled(P, args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    ms_sum = (C.c_double * 3)()
-    cnt = (C.c_longlong * 3)()
+    ms_sum = (C.c_double * 4)()
+    cnt = (C.c_longlong * 4)()
     N.lib.piso_cg_profile_read(ms_sum, cnt)
     N.lib.piso_cg_profile_enable(0, 16)
     from diffpiso.distributed import max_over_ranks
@@ -220,14 +224,41 @@ def main():
         ncell = float(n) * n
         k1_ms = ms_sum[0] / max(cnt[0], 1)
         k2_ms = ms_sum[1] / max(cnt[1], 1)
-        achieved = K1_BYTES_PER_CELL * ncell / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
+        k1_gbs = K1_BYTES_PER_CELL * ncell / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         k2_gbs = K2_BYTES_PER_CELL * ncell / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
-        traffic = None
         try:   # measured offline with rocprofv3 PMC passes of this same workload (profiles/traffic.json)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            traffic = tj[str(n)]["cg_k1"]["bytes"]
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[str(n)]
         except Exception:
-            pass
+            tj = {}
+        if cnt[2] > 0:
+            # the CG iterations ran inside persistent segment launches (cg_persist.h): one launch = `its` iterations
+            its = cnt[2] / max(cnt[3], 1)
+            seg_ms = ms_sum[2] / max(cnt[3], 1)
+            it_us = 1e3 * ms_sum[2] / cnt[2]
+            achieved = CG_BYTES_PER_CELL_ITER * ncell * its / (seg_ms * 1e-3) / 1e9
+            streamed = PERSIST_HBM_BYTES_PER_CELL_ITER * ncell * its / (seg_ms * 1e-3) / 1e9
+            traffic = tj.get("cg_persist", {}).get("bytes_per_iteration")
+            traffic = traffic * its if traffic else None
+            roofline = {"bound": "hbm", "kernel": "cg_persist (one launch = %.0f CG iterations: r, z' in registers, x in LDS, "
+                                                  "p + coefficients streamed, 2 grid exchanges per iteration, fp64)" % its,
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": traffic, "avg_launch_ms": seg_ms, "launches_sampled": int(cnt[3]),
+                        "iterations_per_launch": its, "us_per_iteration": it_us,
+                        "algorithmic_bytes_per_launch": CG_BYTES_PER_CELL_ITER * ncell * its,
+                        "note": "algorithmic = SURVEY 8(d): 128 B per cell and iteration (5 matrix words + 11 vector words); the "
+                                "kernel keeps 3 of the 4 vectors on chip, so it only has to stream ~%.0f B per cell and "
+                                "iteration: frac > 1 is traffic avoided, not bandwidth above peak" % PERSIST_HBM_BYTES_PER_CELL_ITER,
+                        "streamed_model": {"bytes_per_cell_iteration": PERSIST_HBM_BYTES_PER_CELL_ITER, "achieved": streamed,
+                                           "frac": streamed / HBM_PEAK_GBS},
+                        "two_kernel_path": {"k1_avg_launch_ms": k1_ms, "k1_achieved": k1_gbs, "k1_launches_sampled": int(cnt[0]),
+                                            "k2_avg_launch_ms": k2_ms, "k2_achieved": k2_gbs}}
+        else:
+            roofline = {"bound": "hbm", "kernel": "cg_k1 (fused x/p update + 5-point stencil + dots, fp64)",
+                        "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS,
+                        "traffic": tj.get("cg_k1", {}).get("bytes"), "avg_launch_ms": k1_ms, "launches_sampled": int(cnt[0]),
+                        "algorithmic_bytes_per_launch": K1_BYTES_PER_CELL * ncell,
+                        "k2": {"achieved": k2_gbs, "avg_launch_ms": k2_ms, "frac": k2_gbs / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_launch": K2_BYTES_PER_CELL * ncell}}
         cg_it = P["ps"].last_iterations or 0
         cg_it_adj = P["ps"].last_adjoint_iterations or 0
         out = {
@@ -244,12 +275,7 @@ def main():
                        "grid": [n, n], "last_cg_iterations_fwd": cg_it, "last_cg_iterations_adjoint": cg_it_adj,
                        "last_bicgstab_iterations": list(P["lin"].last_iterations or ()),
                        "loss": loss, "warn": float(sum(float(w.detach().sum()) for w in warn))},
-            "roofline": {"bound": "hbm", "kernel": "cg_k1 (fused x/p update + 5-point stencil + dots, fp64)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": k1_ms, "launches_sampled": int(cnt[0]),
-                         "algorithmic_bytes_per_launch": K1_BYTES_PER_CELL * ncell,
-                         "k2": {"achieved": k2_gbs, "avg_launch_ms": k2_ms, "frac": k2_gbs / HBM_PEAK_GBS,
-                                "algorithmic_bytes_per_launch": K2_BYTES_PER_CELL * ncell}},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             per_step = 2 * (cg_it + cg_it_adj) if cg_it else 4000

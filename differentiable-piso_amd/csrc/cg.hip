@@ -11,8 +11,8 @@ namespace piso {
 // ---------------------------------------------------------------------------------------------------------------
 struct CgProfile {
   int enabled = 0, stride = 8;
-  double ms[3] = {0, 0, 0};          // K1, K2, persistent segments
-  long long count[3] = {0, 0, 0};    // launches of K1, K2; ITERATIONS executed inside persistent segments
+  double ms[4] = {0, 0, 0, 0};          // K1, K2, persistent segments, (unused)
+  long long count[4] = {0, 0, 0, 0};    // launches of K1, K2; ITERATIONS executed inside persistent segments; segment LAUNCHES
 };
 static CgProfile g_prof;
 constexpr size_t kPersistWsWords = (size_t)2 * kPersistMaxGrid * 16 + 64;   // records (2 x grid x 64 B) + error flag
@@ -147,12 +147,12 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, float accuracy, int max_ite
     PISO_LAUNCH_CHECK();
     return PISO_OK;
   };
-  int seg_len = (int)(20000.0 / t_iter_us);               // ~20 ms of work per segment (one host look per segment)
+  int seg_len = (int)(20000.0 / ((double)n * 8.5e-6 + 4.0));   // ~20 ms of work per segment (one host look per segment)
   seg_len = seg_len < 50 ? 50 : (seg_len > 2000 ? 2000 : seg_len);
   if (const char* e = getenv("PISO_CG_SEGMENT")) { const int o = atoi(e); if (o > 0) seg_len = o; }
   hipEvent_t seg_ev[2] = {nullptr, nullptr};
   if (persist_R && prof) { PISO_HIP_CHECK(hipEventCreate(&seg_ev[0])); PISO_HIP_CHECK(hipEventCreate(&seg_ev[1])); }
-  double seg_ms = 0; long long seg_iters = 0;
+  double seg_ms = 0; long long seg_iters = 0, seg_launches = 0;
   for (int k = 0; k < total && !finished; ++k) {
     const bool is_reset = !fixed && ((k + 1) % reset == 0);
     if (persist_R && k > 0 && !is_reset && pending) {
@@ -169,7 +169,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, float accuracy, int max_ite
         PISO_HIP_CHECK(hipMemcpyAsync(&herr, pc.err, sizeof(int), hipMemcpyDeviceToHost, stream));
         PISO_HIP_CHECK(hipStreamSynchronize(stream));
         if (herr) { set_error_msg("piso_cg_solve: grid barrier of the persistent CG kernel timed out"); return PISO_ERR_HIP; }
-        if (prof) { float t = 0; PISO_HIP_CHECK(hipEventElapsedTime(&t, seg_ev[0], seg_ev[1])); seg_ms += t; seg_iters += ke - k; }
+        if (prof) { float t = 0; PISO_HIP_CHECK(hipEventElapsedTime(&t, seg_ev[0], seg_ev[1])); seg_ms += t; seg_iters += ke - k; ++seg_launches; }
         if (tl_poll.pinned[0].done) { finished = true; stop_it = tl_poll.pinned[0].iterations; }
         k_last = ke - 1;
         k = ke - 1;                                        // the loop increment moves to ke
@@ -249,7 +249,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, float accuracy, int max_ite
     }
     if (g_prof.enabled) {
       for (int q = 0; q < 2; ++q) { g_prof.ms[q] += ms[q]; g_prof.count[q] += ep.used[q]; }
-      g_prof.ms[2] += seg_ms; g_prof.count[2] += seg_iters;
+      g_prof.ms[2] += seg_ms; g_prof.count[2] += seg_iters; g_prof.count[3] += seg_launches;
     }
     if (kernel_ms_out && seg_iters > 0) { kernel_ms_out[0] = (float)(seg_ms / seg_iters); kernel_ms_out[1] = 0.f; }
   }
@@ -356,11 +356,11 @@ int piso_cg_fixed_iterations_f64(int nx, int ny, int periodic_x, int periodic_y,
 void piso_cg_profile_enable(int enable, int stride) {
   g_prof.enabled = enable;
   if (stride > 0) g_prof.stride = stride;
-  for (int q = 0; q < 3; ++q) { g_prof.ms[q] = 0; g_prof.count[q] = 0; }
+  for (int q = 0; q < 4; ++q) { g_prof.ms[q] = 0; g_prof.count[q] = 0; }
 }
 
 void piso_cg_profile_read(double* ms_sum, long long* count) {
-  for (int q = 0; q < 3; ++q) { ms_sum[q] = g_prof.ms[q]; count[q] = g_prof.count[q]; }
+  for (int q = 0; q < 4; ++q) { ms_sum[q] = g_prof.ms[q]; count[q] = g_prof.count[q]; }
 }
 
 }  // extern "C"

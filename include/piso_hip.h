@@ -124,8 +124,9 @@ int piso_cg_fixed_iterations_f64(int nx, int ny, int periodic_x, int periodic_y,
                                  float* kernel_ms_out, void* workspace, size_t workspace_bytes, piso_stream_t stream);
 
 /* Sampling of K1 / K2 launch durations with HIP events on the launch stream (every `stride`-th iteration); used by
- * bench.py for roofline.achieved.  ms_sum / count: [3] = K1 launches, K2 launches, persistent segments (count[2] = CG
- * ITERATIONS executed inside persistent segments, ms_sum[2] = their total duration). */
+ * bench.py for roofline.achieved.  ms_sum / count: host arrays of FOUR entries: [0] K1 launches, [1] K2 launches,
+ * [2] persistent segments (ms_sum[2] = total duration of all segment launches, count[2] = CG ITERATIONS executed inside
+ * them), [3] count[3] = number of segment launches (ms_sum[3] unused). */
 void piso_cg_profile_enable(int enable, int stride);
 void piso_cg_profile_read(double* ms_sum, long long* count);
 

@@ -213,6 +213,199 @@ __device__ void exch_v4(const Ctl& c, double (&v)[3], unsigned epoch, double* sm
   wg_broadcast(v, smem, epoch);
 }
 
+// ---------------- V7: AoS records of 8 words, polled cooperatively: lane l reads word l % 8 of record 8 i + l / 8 (one
+// coalesced 512-byte load per 8 records, all G / 8 loads in flight at once); 6 lanes publish the record with one store
+template <int NI>   // NI = max records / 8
+__device__ void exch_v7(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sm = smem + (epoch & 1) * 32;
+  for (int q = 0; q < 3; ++q) v[q] = wave_sum(v[q]);
+  if (lane == 0) for (int q = 0; q < 3; ++q) sm[q * kWaves + wave] = v[q];
+  __syncthreads();
+  if (wave == 0) {
+    const int wq = lane & 7, grp = lane >> 3;
+    if (lane < 6) {
+      double s = 0;
+      for (int w = 0; w < kWaves; ++w) s += sm[(lane >> 1) * kWaves + w];
+      const u64 bits = __double_as_longlong(s);
+      const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+      __hip_atomic_store(c.rec + (size_t)blockIdx.x * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int ni = ((int)gridDim.x + 7) / 8;
+    u64 w[NI];
+    bool ok[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { w[i] = 0; ok[i] = !(i < ni && wq < 6 && (i * 8 + grp) < (int)gridDim.x); }
+    while (true) {
+      bool all = true;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        if (!ok[i]) w[i] = __hip_atomic_load(c.rec + (size_t)i * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        if (!ok[i]) ok[i] = ((unsigned)(w[i] & 0xffffffffull) == epoch);
+        all = all && ok[i];
+      }
+      if (__all(all)) break;
+    }
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const u64 nxt = __shfl_down(w[i], 1, 64);        // the hi word sits in the next lane
+      const bool act = i < ni && wq < 6 && !(wq & 1) && (i * 8 + grp) < (int)gridDim.x;
+      acc += act ? __longlong_as_double((w[i] >> 32) | (nxt & 0xffffffff00000000ull)) : 0.0;
+    }
+    acc += __shfl_xor(acc, 8, 64); acc += __shfl_xor(acc, 16, 64); acc += __shfl_xor(acc, 32, 64);
+    for (int q = 0; q < 3; ++q) v[q] = __shfl(acc, 2 * q, 64);
+  }
+  wg_broadcast(v, smem, epoch);
+}
+
+// ---------------- V8: flat, every lane re-reads ALL its NR records until all carry the epoch (branch-free inner body)
+template <int NR>
+__device__ void exch_v8(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wg_partial(v, smem, epoch);
+  if (wave == 0) {
+    if (lane == 0) put_tagged(c.rec + (size_t)blockIdx.x * 8, v, epoch);
+    u64 w[NR][6];
+    const u64* rp[NR];
+#pragma unroll
+    for (int m = 0; m < NR; ++m) { const int b = m * 64 + lane; rp[m] = c.rec + (size_t)(b < (int)gridDim.x ? b : blockIdx.x) * 8; }
+    while (true) {
+#pragma unroll
+      for (int m = 0; m < NR; ++m)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) w[m][q] = __hip_atomic_load(rp[m] + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned bad = 0;
+#pragma unroll
+      for (int m = 0; m < NR; ++m)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) bad |= ((unsigned)(w[m][q] & 0xffffffffull)) ^ epoch;
+      if (__all(bad == 0)) break;
+    }
+    double tot[3] = {0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+      const bool act = (m * 64 + lane) < (int)gridDim.x;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) tot[q] += act ? __longlong_as_double((w[m][2 * q] >> 32) | (w[m][2 * q + 1] & 0xffffffff00000000ull)) : 0.0;
+    }
+    for (int q = 0; q < 3; ++q) v[q] = wave_sum(tot[q]);
+  }
+  wg_broadcast(v, smem, epoch);
+}
+
+// ---------------- V10: as V1, but a lane polls ONE word of its record (the last one stored) and reads the other five only
+// once that carries the epoch; SLEEP = back-off between polls
+template <int SLEEP, bool ONEWORD>
+__device__ void exch_v10(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wg_partial(v, smem, epoch);
+  if (wave == 0) {
+    if (lane == 0) put_tagged(c.rec + (size_t)blockIdx.x * 8, v, epoch);
+    double tot[3] = {0, 0, 0};
+    for (int m = 0; m < ((int)gridDim.x + 63) / 64; ++m) {
+      const int b = m * 64 + lane;
+      const bool active = b < (int)gridDim.x;
+      const u64* rec = c.rec + (size_t)(active ? b : 0) * 8;
+      u64 w[6] = {0, 0, 0, 0, 0, 0};
+      bool ok = !active;
+      while (true) {
+        if (!ok) {
+          if (ONEWORD) {
+            w[5] = __hip_atomic_load(rec + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w[5] & 0xffffffffull) == epoch) {
+#pragma unroll
+              for (int q = 0; q < 5; ++q) w[q] = __hip_atomic_load(rec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = true;
+#pragma unroll
+              for (int q = 0; q < 5; ++q) ok = ok && ((unsigned)(w[q] & 0xffffffffull) == epoch);
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) w[q] = __hip_atomic_load(rec + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = true;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ok = ok && ((unsigned)(w[q] & 0xffffffffull) == epoch);
+          }
+        }
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(SLEEP);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) tot[q] += active ? __longlong_as_double((w[2 * q] >> 32) | (w[2 * q + 1] & 0xffffffff00000000ull)) : 0.0;
+    }
+    for (int q = 0; q < 3; ++q) v[q] = wave_sum(tot[q]);
+  }
+  wg_broadcast(v, smem, epoch);
+}
+
+// ---------------- V15: as V1, but wave m polls records [64 m, 64 m + 64) - the rounds run concurrently on different waves
+__device__ void exch_v15(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sm = smem + (epoch & 1) * 48;
+  for (int q = 0; q < 3; ++q) v[q] = wave_sum(v[q]);
+  if (lane == 0) for (int q = 0; q < 3; ++q) sm[q * kWaves + wave] = v[q];
+  __syncthreads();
+  const int nm = ((int)gridDim.x + 63) / 64;
+  if (wave < nm) {
+    if (wave == 0 && lane == 0) {
+      double s[3];
+      for (int q = 0; q < 3; ++q) { s[q] = 0; for (int w = 0; w < kWaves; ++w) s[q] += sm[q * kWaves + w]; }
+      put_tagged(c.rec + (size_t)blockIdx.x * 8, s, epoch);
+    }
+    const int b = wave * 64 + lane;
+    double s[3];
+    get_tagged(c.rec + (size_t)(b < (int)gridDim.x ? b : 0) * 8, b < (int)gridDim.x, epoch, s);
+    for (int q = 0; q < 3; ++q) s[q] = wave_sum(s[q]);
+    if (lane == 0) for (int q = 0; q < 3; ++q) sm[24 + q * 4 + wave] = s[q];
+  }
+  __syncthreads();
+  for (int q = 0; q < 3; ++q) { double t = 0; for (int m = 0; m < nm; ++m) t += sm[24 + q * 4 + m]; v[q] = t; }
+}
+
+// ---------------- V16: V1 (sequential rounds, sleep 1) on the word-major layout rec[q * kMaxG + b]; BLK > 0: blocks of BLK
+// records, word-major inside a block
+template <int BLK>
+__device__ void exch_v16(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wg_partial(v, smem, epoch);
+  auto addr = [&](int b, int q) -> u64* {
+    if (BLK == 0) return c.rec + (size_t)q * kMaxG + b;
+    return c.rec + (size_t)(b / BLK) * (BLK * 8) + q * BLK + (b % BLK);
+  };
+  if (wave == 0) {
+    if (lane < 6) {
+      const u64 bits = __double_as_longlong(v[lane >> 1 == 0 ? 0 : (lane >> 1 == 1 ? 1 : 2)]);
+      const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+      __hip_atomic_store(addr(blockIdx.x, lane), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    double tot[3] = {0, 0, 0};
+    for (int m = 0; m < ((int)gridDim.x + 63) / 64; ++m) {
+      const int b = m * 64 + lane;
+      const bool active = b < (int)gridDim.x;
+      u64 w[6] = {0, 0, 0, 0, 0, 0};
+      bool ok = !active;
+      while (true) {
+        if (!ok) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) w[q] = __hip_atomic_load(addr(active ? b : 0, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = true;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) ok = ok && ((unsigned)(w[q] & 0xffffffffull) == epoch);
+        }
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) tot[q] += active ? __longlong_as_double((w[2 * q] >> 32) | (w[2 * q + 1] & 0xffffffff00000000ull)) : 0.0;
+    }
+    for (int q = 0; q < 3; ++q) v[q] = wave_sum(tot[q]);
+  }
+  wg_broadcast(v, smem, epoch);
+}
+
 // ---------------- V2: two levels of 16 (leader = first workgroup of each group of 16)
 __device__ void exch_v2(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -236,7 +429,7 @@ __device__ void exch_v2(const Ctl& c, double (&v)[3], unsigned epoch, double* sm
 
 template <int VAR>
 __global__ __launch_bounds__(kThreads) void bench(Ctl c, int iters, double* out, u64* ticks) {
-  __shared__ double smem[64];
+  __shared__ double smem[96];
   double acc = 0;
   if (threadIdx.x == 0) {
     unsigned x;
@@ -253,6 +446,18 @@ __global__ __launch_bounds__(kThreads) void bench(Ctl c, int iters, double* out,
     if (VAR == 4) exch_v4<4, 0>(c, v, (unsigned)it, smem);
     if (VAR == 5) exch_v4<4, 1>(c, v, (unsigned)it, smem);
     if (VAR == 6) exch_v4<4, 4>(c, v, (unsigned)it, smem);
+    if (VAR == 7) exch_v7<32>(c, v, (unsigned)it, smem);
+    if (VAR == 8) exch_v8<4>(c, v, (unsigned)it, smem);
+    if (VAR == 15) exch_v15(c, v, (unsigned)it, smem);
+    if (VAR == 16) exch_v16<0>(c, v, (unsigned)it, smem);
+    if (VAR == 17) exch_v16<8>(c, v, (unsigned)it, smem);
+    if (VAR == 18) exch_v16<16>(c, v, (unsigned)it, smem);
+    if (VAR == 10) exch_v10<1, true>(c, v, (unsigned)it, smem);
+    if (VAR == 11) exch_v10<4, true>(c, v, (unsigned)it, smem);
+    if (VAR == 12) exch_v10<12, true>(c, v, (unsigned)it, smem);
+    if (VAR == 13) exch_v10<4, false>(c, v, (unsigned)it, smem);
+    if (VAR == 14) exch_v10<12, false>(c, v, (unsigned)it, smem);
+    if (VAR == 9) exch_v8<1>(c, v, (unsigned)it, smem);
     acc += v[0] + v[1] + v[2];
   }
   const u64 t1 = wall_clock64();
@@ -268,7 +473,7 @@ int main(int argc, char** argv) {
   double* out; u64* ticks;
   CK(hipMalloc((void**)&out, kMaxG * 8)); CK(hipMalloc((void**)&ticks, kMaxG * 8));
   const double expect = (double)G * kThreads * 1.0 + (double)G * (kThreads / 4) * 6.0;
-  for (int var = 0; var < 7; ++var) {
+  for (int var = 0; var < 19; ++var) {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipMemset(c.bar, 0, 256)); CK(hipMemset(c.rec, 0, kMaxG * 64)); CK(hipMemset(c.grp, 0, 16 * 64));
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -280,6 +485,18 @@ int main(int argc, char** argv) {
       if (var == 4) bench<4><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 5) bench<5><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 6) bench<6><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 7) bench<7><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 8) bench<8><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 15) bench<15><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 16) bench<16><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 17) bench<17><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 18) bench<18><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 10) bench<10><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 11) bench<11><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 12) bench<12><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 13) bench<13><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 14) bench<14><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 9 && G <= 64) bench<9><<<G, kThreads>>>(c, iters, out, ticks);
       CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       std::vector<double> h(G); CK(hipMemcpy(h.data(), out, G * 8, hipMemcpyDeviceToHost));

@@ -148,7 +148,7 @@ def _persist_iterations():
     """Iterations executed inside persistent segments since the profile was enabled (piso_cg_profile_read, entry 2)."""
     import ctypes as C
     from diffpiso import _native as N
-    ms, cnt = (C.c_double * 3)(), (C.c_longlong * 3)()
+    ms, cnt = (C.c_double * 4)(), (C.c_longlong * 4)()
     N.lib.piso_cg_profile_read(ms, cnt)
     return int(cnt[2])
 
