@@ -53,7 +53,7 @@ struct EventPool {
 static thread_local EventPool tl_events;
 
 template <typename T, typename CT, int V, bool RECON>
-static int cg_run(CgArgs<T> a, unsigned* persist_ws, float accuracy, int max_iterations, int rank_deficient, int reset, int fixed,
+static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accuracy, int max_iterations, int rank_deficient, int reset, int fixed,
                   int* iterations_out, float* kernel_ms_out, hipStream_t stream) {
   const int nx = a.nx, ny = a.ny;
   const size_t n = (size_t)nx * ny;
@@ -135,15 +135,25 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, float accuracy, int max_ite
     PISO_HIP_CHECK(hipMemsetAsync(persist_ws, 0, kPersistWsWords * sizeof(unsigned), stream));
     if (persist_grid > kPersistMaxGrid) persist_R = 0;
     if (getenv("PISO_CG_PERSIST_TIMING")) {               // diagnostics only: per-phase clocks of every workgroup
-      PISO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&pc.timing), 4 * persist_grid * sizeof(unsigned long long)));
-      PISO_HIP_CHECK(hipMemsetAsync(pc.timing, 0, 4 * persist_grid * sizeof(unsigned long long), stream));
+      PISO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&pc.timing), 12 * persist_grid * sizeof(unsigned long long)));
+      PISO_HIP_CHECK(hipMemsetAsync(pc.timing, 0, 12 * persist_grid * sizeof(unsigned long long), stream));
     }
   }
   auto launch_segment = [&](int kb, int ke) -> int {
     PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 64, stream));   // epochs restart at 1 in every launch
-    if (persist_R == 2) cg_persist<T, CT, 2, RECON><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
-    else if (persist_R == 4) cg_persist<T, CT, 4, RECON><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
-    else cg_persist<T, CT, 8, RECON><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+    constexpr bool kCanSym = RECON && sizeof(CT) == 4;     // the symmetric variant exists for the compact coefficient path
+    if constexpr (kCanSym) {
+      if (symmetric) {
+        if (persist_R == 2) cg_persist<T, CT, 2, RECON, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+        else if (persist_R == 4) cg_persist<T, CT, 4, RECON, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+        else cg_persist<T, CT, 8, RECON, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+        PISO_LAUNCH_CHECK();
+        return PISO_OK;
+      }
+    }
+    if (persist_R == 2) cg_persist<T, CT, 2, RECON, false><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+    else if (persist_R == 4) cg_persist<T, CT, 4, RECON, false><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+    else cg_persist<T, CT, 8, RECON, false><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
     PISO_LAUNCH_CHECK();
     return PISO_OK;
   };
@@ -223,9 +233,14 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, float accuracy, int max_ite
   }
   PISO_HIP_CHECK(hipStreamSynchronize(stream));
   if (pc.timing) {
-    std::vector<unsigned long long> h(4 * persist_grid);
+    std::vector<unsigned long long> h(12 * persist_grid);
     PISO_HIP_CHECK(hipMemcpy(h.data(), pc.timing, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     PISO_HIP_CHECK(hipFree(pc.timing));
+    for (int b : {0, persist_grid / 2, persist_grid - 1}) {
+      fprintf(stderr, "cg_persist phaseA per wave, workgroup %d:", b);
+      for (int w = 0; w < kPersistWaves; ++w) fprintf(stderr, " %.2f", 0.01 * (double)h[4 * persist_grid + b * kPersistWaves + w] / (double)(k_last > 0 ? k_last : 1));
+      fprintf(stderr, " us/iter\n");
+    }
     const char* names[4] = {"phaseA", "barrierA", "phaseB", "barrierB"};
     for (int q = 0; q < 4; ++q) {
       double s = 0, mn = 1e300, mx = 0;
@@ -275,7 +290,7 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   T* cC = ar.take<T>(n);
   T* oT = ar.take<T>(4 * n);
   float* oF = ar.take<float>(4 * n);
-  int* flags = ar.take<int>(2);
+  int* flags = ar.take<int>(4);
   a.cC = cC;
   a.b = b; a.x = x_out;
   a.r = ar.take<T>(n); a.z = ar.take<T>(n); a.p[0] = ar.take<T>(n); a.p[1] = ar.take<T>(n);
@@ -290,25 +305,27 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   if (const char* e = getenv("PISO_CG_NT")) a.nt = atoi(e);
   if (!ar.ok()) { set_error_msg("piso_cg_solve: workspace too small"); return PISO_ERR_INVALID_ARG; }
 
-  PISO_HIP_CHECK(hipMemsetAsync(flags, 0, 2 * sizeof(int), stream));
+  PISO_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(int), stream));
   cg_zero_partials<T><<<(3 * kMaxPartials + 255) / 256, 256, 0, stream>>>(a.partsA, a.partsB, a.partsS);
   const int gs = grid_for((long long)n, kBlock * 4);
-  cg_setup_coeffs<T><<<gs, kBlock, 0, stream>>>(L, cC, oT, oF, a.partsS, flags, n);
+  cg_setup_coeffs<T><<<gs, kBlock, 0, stream>>>(L, cC, oT, oF, a.partsS, flags, n, nx, ny, per_x, per_y);
   PISO_LAUNCH_CHECK();
   // The off-diagonals of the PISO pressure matrix are float32 face coefficients (laplace_op.cu.cc:140-177): stored as
   // float they are exact and K1 reads 24 instead of 40 coefficient bytes per cell.  Any other input keeps them in T.
-  int hflags[2] = {1, 1};
-  if (sizeof(T) == 8) {
-    PISO_HIP_CHECK(hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+  int hflags[3] = {1, 1, 1};
+  {
+    PISO_HIP_CHECK(hipMemcpyAsync(hflags, flags, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
     PISO_HIP_CHECK(hipStreamSynchronize(stream));
   }
   if (getenv("PISO_CG_NO_COMPACT")) hflags[0] = hflags[1] = 1;      // tuning / test knob: plain T coefficients
   if (getenv("PISO_CG_NO_RECON")) hflags[1] = 1;
+  if (getenv("PISO_CG_NO_SYM")) hflags[2] = 1;
+  const bool symmetric = !hflags[2];
   constexpr int VMID = 16 / sizeof(T);
   const bool aligned = ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(x_out)) & 15) == 0;
   const bool vec = aligned && (nx % VMID == 0);
 #define PISO_CG_RUN(CT, V, RECON) \
-  return cg_run<T, CT, V, RECON>(a, persist_ws, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream)
+  return cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream)
   if (sizeof(T) == 8 && !hflags[0]) {
     a.oS = oF; a.oW = oF + n; a.oE = oF + 2 * n; a.oN = oF + 3 * n;
     if (!hflags[1]) { if (vec) PISO_CG_RUN(float, VMID, true); PISO_CG_RUN(float, 1, true); }

@@ -509,14 +509,23 @@ __global__ __launch_bounds__(kBlock) void cg_reset_residual(CgArgs<T> a, int sv)
 // L [N][5] -> SoA coefficients (off-diagonals in T and in float); partial sums of |diag| for the shift (cublasDasum,
 // :165-168); flags[0] is set if some off-diagonal is not exactly representable as float (then the T arrays are used),
 // flags[1] if some diagonal is not bit-for-bit -(S + N + W + E) of the float off-diagonals (then it is read, not recomputed).
+// flags[2] is set unless the matrix is symmetric bit for bit: N of a cell equals S of the cell above, E equals W of the cell to
+// the right (periodic wrap, or 0 at a wall); nx = 0 skips the check and sets the flag (slab solver: the neighbour is remote).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void cg_setup_coeffs(const T* __restrict__ L, T* cC, T* oT, float* oF, T* parts,
-                                                           int* flags, size_t n) {
+                                                           int* flags, size_t n, int nx = 0, int ny = 0, int per_x = 0,
+                                                           int per_y = 0) {
   __shared__ T smem[16];
   T acc = 0;
-  bool bad = false, bad_recon = false;
+  bool bad = false, bad_recon = false, bad_sym = (nx == 0);
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     const T* row = L + i * 5;
+    if (nx > 0) {
+      const int ci = (int)(i % (size_t)nx), cj = (int)(i / (size_t)nx);
+      const T e_nb = (ci + 1 < nx) ? L[(i + 1) * 5 + 1] : (per_x ? L[(i - (size_t)(nx - 1)) * 5 + 1] : (T)0);
+      const T n_nb = (cj + 1 < ny) ? L[(i + (size_t)nx) * 5 + 0] : (per_y ? L[(size_t)ci * 5 + 0] : (T)0);
+      bad_sym |= !(row[3] == e_nb) || !(row[4] == n_nb);
+    }
     const T o[4] = {row[0], row[1], row[3], row[4]};
     cC[i] = row[2];
 #pragma unroll
@@ -534,6 +543,7 @@ __global__ __launch_bounds__(kBlock) void cg_setup_coeffs(const T* __restrict__ 
   }
   if (bad) flags[0] = 1;
   if (bad_recon) flags[1] = 1;
+  if (bad_sym) flags[2] = 1;
   T part[1] = {acc};
   block_sum<T, 1>(part, smem);
   if (threadIdx.x == 0) parts[blockIdx.x] = part[0];

@@ -28,6 +28,7 @@ struct PersistCtl {
   unsigned long long* timing;   // diagnostics (PISO_CG_PERSIST_TIMING): [4][grid] 100 MHz ticks in phase A / barrier A / phase B / barrier B
 };
 constexpr int kPersistMaxGrid = 512;
+constexpr int kPersistMaxDepth = 6;     // rows of loads in flight per wave (register budget permitting)
 
 // Grid-wide exchange of 3 partial sums per workgroup that doubles as the grid barrier (measured 4.4 us for 256 workgroups
 // against 11.3 us for "atomic counter + fence + read the partials", scripts/barrier_bench.hip).
@@ -39,7 +40,9 @@ constexpr int kPersistMaxGrid = 512;
 //     reads epoch e, and nobody can reach e+2 before everybody has published e+1.
 // DATA written before the exchange (p, the perimeter of r) is stored write-through at agent scope (sc1) and drained
 // (s_waitcnt vmcnt(0)) by every wave before the workgroup publishes; readers load it at agent scope as well.
-template <typename T>
+// KEEP = number of vector-memory LOADS this wave issued after its last store and may leave in flight (prefetch for the next
+// phase; vmcnt retires in issue order, so "at most KEEP outstanding" means every store has completed).
+template <typename T, int KEEP = 0>
 __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], unsigned epoch, T* smem) {
   typedef unsigned long long u64;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -50,7 +53,7 @@ __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], un
 #pragma unroll
     for (int q = 0; q < 3; ++q) sm[q * kPersistWaves + wave] = v[q];
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's write-through stores have completed
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");   // this wave's write-through stores have completed
   __syncthreads();
   if (wave == 0) {
     u64* rec = c.rec + (size_t)(epoch & 1) * kPersistMaxGrid * 8;
@@ -184,7 +187,9 @@ __device__ __forceinline__ S shift_lane(S v, S edge) {
 }
 
 // Host guarantees: nx % (64 V) == 0 (every lane of a strip has cells) and ny % R == 0 (every region has R rows).
-template <typename T, typename CT, int R, bool RECON>
+// SYM: the matrix is symmetric (verified bit for bit by cg_setup_coeffs): N of a cell is S of the cell above, E is W of the cell
+// to the right - only the S and W arrays are streamed (8 instead of 16 coefficient bytes per cell).
+template <typename T, typename CT, int R, bool RECON, bool SYM>
 __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, PersistCtl c, int k_begin, int k_end, int sv) {
   constexpr int V = 16 / sizeof(T);                        // 16-byte lane accesses
   constexpr int NQ = kPersistRegions;
@@ -259,6 +264,78 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     __syncthreads();
   }
 
+  // ---- phase-A row pipeline (see phase A below): registers of the rows in flight, carried ACROSS iterations
+  constexpr int row_regs = (16 + (SYM ? 2 : 4) * (int)sizeof(CT) * V + (RECON ? 0 : 16)) / 4;      // VGPRs of one row in flight
+  constexpr int Dw = 48 / row_regs < 2 ? 2 : (48 / row_regs > kPersistMaxDepth ? kPersistMaxDepth : 48 / row_regs);
+  constexpr int NT = NQ * R, D = (R >= Dw) ? Dw : R;
+  // vector loads of the own part of row D - 1, the last one a phase issues (after its last store) for the next iteration
+  constexpr int kRowLoads = (SYM ? 3 + ((D - 1) % R == 0 ? 1 : 0) + ((D - 1) % R == R - 1 ? 1 : 0) : 5) + (RECON ? 0 : 1);
+  Vec<T, V> Pq[NT], hbR[NQ], hbP[NQ], haR[NQ], haP[NQ];
+  Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT], cSh[NQ];
+  Vec<T, V> cD[NT];
+  T eP[NQ], eR[NQ];
+  CT eW[NQ];
+  unsigned vT[NQ], vC[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int cq = (tx0[q] * 64 + lane) * V;
+    vT[q] = (unsigned)(cq * sizeof(T)); vC[q] = (unsigned)(cq * sizeof(CT));
+  }
+  // own part of row t: p_old and the coefficient rows - nothing another workgroup writes inside the launch
+  auto issue_own = [&](int t, rsrc_t Rp) __attribute__((always_inline)) {
+    const int q = t / R, jj = t - q * R;
+    const unsigned sT = (unsigned)(j0[q] + jj) * rowT, sC = (unsigned)(j0[q] + jj) * rowC;
+    Pq[t] = bld<T, V, kAgent>(Rp, vT[q], sT);
+    cS[t] = bld<CT, V>(RoS, vC[q], sC); cW[t] = bld<CT, V>(RoW, vC[q], sC);
+    if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vC[q], sC); cN[t] = bld<CT, V>(RoN, vC[q], sC); }
+    if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
+    if constexpr (SYM) {
+      if (jj == 0) {                                       // W of the first column of the strip to the right: E of my last column
+        const int side = lane / R, er = lane - side * R;
+        int cc = (tx0[q] + 1) * 64 * V;
+        if (cc >= nx) cc = a.per_x ? 0 : -1;
+        const unsigned vo = (side == 1 && cc >= 0) ? (unsigned)(j0[q] + er) * rowC + (unsigned)(cc * sizeof(CT)) : 0xffffffffu;
+        eW[q] = bld1<CT>(RoW, vo, 0);
+      }
+      if (jj == R - 1) {                                   // S of the row above the region: N of my last row
+        bool valid;
+        const int jw = row_wrap(j0[q] + R, valid);
+        cSh[q] = bld<CT, V>(RoS, valid ? vC[q] : 0xffffffffu, (unsigned)jw * rowC);
+      }
+    }
+  };
+  // neighbours' part that comes with row t (first row of a region: edge columns + halo row behind; last row: halo row ahead)
+  auto issue_halo = [&](int t, rsrc_t Rp) __attribute__((always_inline)) {
+    const int q = t / R, jj = t - q * R;
+    if (jj == 0) {
+      // p_new on the two columns next to the strip, all R rows with ONE pair of loads: lane l < R holds the left
+      // neighbour of row l, lane R + l the right neighbour; lanes without a cell (and walls) read out of range -> 0
+      const int side = lane / R, er = lane - side * R;
+      int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
+      if (cc < 0) cc = a.per_x ? nx - 1 : -1;
+      else if (cc >= nx) cc = a.per_x ? 0 : -1;
+      const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
+      eP[q] = bld1<T, kAgent>(Rp, vo, 0);
+      eR[q] = bld1<T, kAgent>(Rr, vo, 0);
+      bool valid;
+      const int jw = row_wrap(j0[q] - 1, valid);
+      const unsigned vh = valid ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
+      hbR[q] = bld<T, V, kAgent>(Rr, vh, (unsigned)jw * rowT);
+      hbP[q] = bld<T, V, kAgent>(Rp, vh, (unsigned)jw * rowT);
+    }
+    if (jj == R - 1) {
+      bool valid;
+      const int jw = row_wrap(j0[q] + R, valid);
+      const unsigned vh = valid ? vT[q] : 0xffffffffu;
+      haR[q] = bld<T, V, kAgent>(Rr, vh, (unsigned)jw * rowT);
+      haP[q] = bld<T, V, kAgent>(Rp, vh, (unsigned)jw * rowT);
+    }
+  };
+  if (has[0]) {
+#pragma unroll
+    for (int t = 0; t < D; ++t) issue_own(t, (k_begin & 1) ? Rp1 : Rp0);
+  }
+
   unsigned epoch = 0;
   bool healthy = true;
   int k = k_begin;
@@ -300,51 +377,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
       // The rows of both regions form ONE software pipeline of NT steps: the loads of step t + D (p_old and the four
       // coefficient rows; with the first / last row of a region also its edge columns and halo rows) are issued before step t
       // computes, so ~D rows x 48 B per lane are in flight instead of one (the kernel runs 2 waves per SIMD: latency must be
-      // hidden inside the wave).  sched_barrier pins that order; the compiler derives exact s_waitcnt vmcnt(N) from it.
-      constexpr int row_regs = (16 + 4 * (int)sizeof(CT) * V + (RECON ? 0 : 16)) / 4;      // VGPRs of one row in flight
-      constexpr int Dw = 48 / row_regs < 2 ? 2 : (48 / row_regs > 4 ? 4 : 48 / row_regs);
-      constexpr int NT = NQ * R, D = (R >= Dw) ? Dw : R;
-      Vec<T, V> Pq[NT], hbR[NQ], hbP[NQ], haR[NQ], haP[NQ];
-      Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT];
-      Vec<T, V> cD[NT];
-      T eP[NQ], eR[NQ];
-      unsigned vT[NQ], vC[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int cq = (tx0[q] * 64 + lane) * V;
-        vT[q] = (unsigned)(cq * sizeof(T)); vC[q] = (unsigned)(cq * sizeof(CT));
-      }
-      auto issue = [&](int t) __attribute__((always_inline)) {
-        const int q = t / R, jj = t - q * R;
-        const unsigned sT = (unsigned)(j0[q] + jj) * rowT, sC = (unsigned)(j0[q] + jj) * rowC;
-        if (jj == 0) {
-          // p_new on the two columns next to the strip, all R rows with ONE pair of loads: lane l < R holds the left
-          // neighbour of row l, lane R + l the right neighbour; lanes without a cell (and walls) read out of range -> 0
-          const int side = lane / R, er = lane - side * R;
-          int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
-          if (cc < 0) cc = a.per_x ? nx - 1 : -1;
-          else if (cc >= nx) cc = a.per_x ? 0 : -1;
-          const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
-          eP[q] = bld1<T, kAgent>(Rpin, vo, 0);
-          eR[q] = bld1<T, kAgent>(Rr, vo, 0);
-          bool valid;
-          const int jw = row_wrap(j0[q] - 1, valid);
-          const unsigned vh = valid ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
-          hbR[q] = bld<T, V, kAgent>(Rr, vh, (unsigned)jw * rowT);
-          hbP[q] = bld<T, V, kAgent>(Rpin, vh, (unsigned)jw * rowT);
-        }
-        Pq[t] = bld<T, V, kAgent>(Rpin, vT[q], sT);
-        cS[t] = bld<CT, V>(RoS, vC[q], sC); cW[t] = bld<CT, V>(RoW, vC[q], sC);
-        cE[t] = bld<CT, V>(RoE, vC[q], sC); cN[t] = bld<CT, V>(RoN, vC[q], sC);
-        if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
-        if (jj == R - 1) {
-          bool valid;
-          const int jw = row_wrap(j0[q] + R, valid);
-          const unsigned vh = valid ? vT[q] : 0xffffffffu;
-          haR[q] = bld<T, V, kAgent>(Rr, vh, (unsigned)jw * rowT);
-          haP[q] = bld<T, V, kAgent>(Rpin, vh, (unsigned)jw * rowT);
-        }
-      };
+      // hidden inside the wave).  The pipeline is CIRCULAR: the last D steps issue the own part of rows 0 .. D-1 of the NEXT
+      // iteration (its p_old is what this phase just stored), so a quarter of the next phase's loads travels while the two
+      // grid exchanges and phase B leave the memory system idle.  sched_barrier pins the order; the compiler derives exact
+      // s_waitcnt vmcnt(N) from it.
       // own row t of the new direction; also performs x <- x + alpha_prev p_old (the axpy of iteration k-1, :303)
       auto own_row = [&](int t) __attribute__((always_inline)) -> Vec<T, V> {
         const int q = t / R, jj = t - q * R;
@@ -356,13 +392,12 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
         return o;
       };
 #pragma unroll
-      for (int t = 0; t < D; ++t) issue(t);
+      for (int t = 0; t < D; ++t) issue_halo(t, Rpin);     // (the own part of these rows was issued before the exchange)
       Vec<T, V> behind, cur, ahead;
       T edge = 0;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int q = t / R, jj = t - q * R;
-        if (t + D < NT) issue(t + D < NT ? t + D : t);
         if (jj == 0) {
           edge = fma(beta, eP[q], eR[q]);
 #pragma unroll
@@ -376,12 +411,21 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
         }
         const T left = shift_lane<true, T>(cur.v[V - 1], read_lane<T>(edge, jj));
         const T right = shift_lane<false, T>(cur.v[0], read_lane<T>(edge, R + jj));
+        Vec<CT, V> kN, kE;
+        if constexpr (SYM) {
+          kN = (jj + 1 < R) ? cS[t + 1 < NT ? t + 1 : t] : cSh[q];
+#pragma unroll
+          for (int e = 0; e + 1 < V; ++e) kE.v[e] = cW[t].v[e + 1];
+          kE.v[V - 1] = shift_lane<false, CT>(cW[t].v[0], read_lane<CT>(eW[q], R + jj));
+        } else {
+          kN = cN[t]; kE = cE[t];
+        }
         Vec<T, V> kC;
         if constexpr (RECON) {
 #pragma unroll
           for (int e = 0; e < V; ++e) {
             T d = 0;
-            d -= (T)cS[t].v[e]; d -= (T)cN[t].v[e]; d -= (T)cW[t].v[e]; d -= (T)cE[t].v[e];
+            d -= (T)cS[t].v[e]; d -= (T)kN.v[e]; d -= (T)cW[t].v[e]; d -= (T)kE.v[e];
             kC.v[e] = d;
           }
         } else {
@@ -395,8 +439,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
           tmp = fma((T)cS[t].v[e], behind.v[e], tmp);
           tmp = fma((T)cW[t].v[e], pw, tmp);
           tmp = fma(kC.v[e], cur.v[e], tmp);
-          tmp = fma((T)cE[t].v[e], pe, tmp);
-          tmp = fma((T)cN[t].v[e], ahead.v[e], tmp);
+          tmp = fma((T)kE.v[e], pe, tmp);
+          tmp = fma((T)kN.v[e], ahead.v[e], tmp);
           zz[q][jj].v[e] = tmp;
           sA[0] += cur.v[e];
           sA[1] = fma(cur.v[e], rr[q][jj].v[e], sA[1]);
@@ -405,12 +449,20 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
         bst<T, V, kAgent>(Rpout, vT[q], (unsigned)(j0[q] + jj) * rowT, cur);
         behind = cur;
         cur = ahead;
+        // refill the pipeline AFTER the store: the exchange below may then leave exactly the last row's loads in flight
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + D < NT) { issue_own(t + D < NT ? t + D : t, Rpin); issue_halo(t + D < NT ? t + D : t, Rpin); }
+        else issue_own(t + D >= NT ? t + D - NT : 0, Rpout);     // row of the next iteration: its p_old is this p_new
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (c.timing && lane == 0) {                           // diagnostics: when does EVERY wave of a workgroup finish phase A?
+      __builtin_amdgcn_s_waitcnt(0);
+      c.timing[4 * gridDim.x + blockIdx.x * kPersistWaves + wave] += wall_clock64() - tlast;
+    }
     ++epoch;
     tick(0);
-    healthy = grid_exchange<T>(c, sA, epoch, smem);
+    healthy = grid_exchange<T, kRowLoads>(c, sA, epoch, smem);
     tick(1);
     if (!healthy) break;
     // ---- alpha (:301-302), then phase B: r -= alpha (z' + vs), partial sums, publish the perimeter of r

@@ -406,6 +406,73 @@ __device__ void exch_v16(const Ctl& c, double (&v)[3], unsigned epoch, double* s
   wg_broadcast(v, smem, epoch);
 }
 
+// ---------------- V19: poll the lane's FIRST record like V1; once that round passes, read the remaining records concurrently
+// (arrivals cluster: they are almost always there) and fall back to polling only for the late ones.  BLK layout as V16.
+template <int BLK, int NR>
+__device__ void exch_v19(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  wg_partial(v, smem, epoch);
+  auto addr = [&](int b, int q) -> u64* {
+    if (BLK == 0) return c.rec + (size_t)b * 8 + q;
+    return c.rec + (size_t)(b / BLK) * (BLK * 8) + q * BLK + (b % BLK);
+  };
+  if (wave == 0) {
+    if (lane < 6) {
+      const u64 bits = __double_as_longlong(v[lane >> 1 == 0 ? 0 : (lane >> 1 == 1 ? 1 : 2)]);
+      const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+      __hip_atomic_store(addr(blockIdx.x, lane), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    u64 w[NR][6];
+    bool ok[NR];
+#pragma unroll
+    for (int m = 0; m < NR; ++m) ok[m] = (m * 64 + lane) >= (int)gridDim.x;
+    // round 0: first record only
+    while (true) {
+      if (!ok[0]) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) w[0][q] = __hip_atomic_load(addr(lane, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool o = true;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o = o && ((unsigned)(w[0][q] & 0xffffffffull) == epoch);
+        ok[0] = o;
+      }
+      if (__all(ok[0])) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    // the rest: all at once, then poll the stragglers
+    while (true) {
+      bool all = true;
+#pragma unroll
+      for (int m = 1; m < NR; ++m)
+        if (!ok[m]) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q) w[m][q] = __hip_atomic_load(addr(m * 64 + lane, q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+      for (int m = 1; m < NR; ++m) {
+        if (!ok[m]) {
+          bool o = true;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) o = o && ((unsigned)(w[m][q] & 0xffffffffull) == epoch);
+          ok[m] = o;
+        }
+        all = all && ok[m];
+      }
+      if (__all(all)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    double tot[3] = {0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < NR; ++m) {
+      const bool act = (m * 64 + lane) < (int)gridDim.x;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) tot[q] += act ? __longlong_as_double((w[m][2 * q] >> 32) | (w[m][2 * q + 1] & 0xffffffff00000000ull)) : 0.0;
+    }
+    for (int q = 0; q < 3; ++q) v[q] = wave_sum(tot[q]);
+  }
+  wg_broadcast(v, smem, epoch);
+}
+
 // ---------------- V2: two levels of 16 (leader = first workgroup of each group of 16)
 __device__ void exch_v2(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -449,6 +516,8 @@ __global__ __launch_bounds__(kThreads) void bench(Ctl c, int iters, double* out,
     if (VAR == 7) exch_v7<32>(c, v, (unsigned)it, smem);
     if (VAR == 8) exch_v8<4>(c, v, (unsigned)it, smem);
     if (VAR == 15) exch_v15(c, v, (unsigned)it, smem);
+    if (VAR == 19) exch_v19<0, 4>(c, v, (unsigned)it, smem);
+    if (VAR == 20) exch_v19<16, 4>(c, v, (unsigned)it, smem);
     if (VAR == 16) exch_v16<0>(c, v, (unsigned)it, smem);
     if (VAR == 17) exch_v16<8>(c, v, (unsigned)it, smem);
     if (VAR == 18) exch_v16<16>(c, v, (unsigned)it, smem);
@@ -473,7 +542,7 @@ int main(int argc, char** argv) {
   double* out; u64* ticks;
   CK(hipMalloc((void**)&out, kMaxG * 8)); CK(hipMalloc((void**)&ticks, kMaxG * 8));
   const double expect = (double)G * kThreads * 1.0 + (double)G * (kThreads / 4) * 6.0;
-  for (int var = 0; var < 19; ++var) {
+  for (int var = 0; var < 21; ++var) {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipMemset(c.bar, 0, 256)); CK(hipMemset(c.rec, 0, kMaxG * 64)); CK(hipMemset(c.grp, 0, 16 * 64));
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -488,6 +557,8 @@ int main(int argc, char** argv) {
       if (var == 7) bench<7><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 8) bench<8><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 15) bench<15><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 19) bench<19><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 20) bench<20><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 16) bench<16><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 17) bench<17><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 18) bench<18><<<G, kThreads>>>(c, iters, out, ticks);

@@ -11,7 +11,10 @@ def run(n, iters=300, periodic=True, ny=None):
     nx = n
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu"); g.manual_seed(0)
-    a0 = (0.5 + torch.rand(nx * (ny + 1) + (nx + 1) * ny, generator=g)).to(dev)
+    a0 = 0.5 + torch.rand(nx * (ny + 1) + (nx + 1) * ny, generator=g)
+    av = a0[:nx * (ny + 1)].view(ny + 1, nx); au = a0[nx * (ny + 1):].view(ny, nx + 1)
+    av[ny] = av[0]; au[:, nx] = au[:, 0]                     # periodic duplicates of the face fields (symmetric matrix)
+    a0 = a0.to(dev)
     ones = torch.ones((ny + 2) * (nx + 2), device=dev)
     L = laplace_matrix_native(nx, ny, ones, ones, a0, torch.float64)
     b = torch.randn(nx * ny, generator=g, dtype=torch.float64).to(dev); b -= b.mean()

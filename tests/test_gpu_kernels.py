@@ -190,6 +190,25 @@ def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, 
         N.lib.piso_cg_profile_enable(0, 8)
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_cg_persistent_symmetric_streaming_is_bitwise_neutral(name, monkeypatch):
+    """For a symmetric matrix (checked bit for bit at set-up) the persistent kernel streams only the S and W coefficient
+    arrays and takes N / E from the neighbouring cell; the arithmetic is the same, so the result must not change by a bit.
+    Matrices that fail the check (one-sided couplings at open boundaries) silently use all four arrays."""
+    from diffpiso.solvers import cg_solve_native
+    s, L, b = _laplace_case(name, 32, 256, seed=9)
+    px, py = s.periodic_yx[1], s.periodic_yx[0]
+    monkeypatch.setenv("PISO_CG_PERSIST", "1")
+    monkeypatch.setenv("PISO_CG_PERSIST_R", "8")
+    x1, it1 = cg_solve_native(s.nx, s.ny, px, py, dev(L), dev(b), 1e-30, 40, False, 1000)
+    monkeypatch.setenv("PISO_CG_NO_SYM", "1")
+    x2, it2 = cg_solve_native(s.nx, s.ny, px, py, dev(L), dev(b), 1e-30, 40, False, 1000)
+    assert it1 == it2 == 40
+    assert torch.equal(x1, x2)
+    xo, _ = O.cg_solve(s.nx, s.ny, px, py, L, b, 1e-30, 40, False, 1000)
+    assert np.abs(x1.cpu().numpy() - xo).max() <= 1e-6 * np.abs(xo).max()
+
+
 def test_cg_persistent_shift_nan_and_float32(monkeypatch):
     from diffpiso.solvers import cg_solve_native
     from diffpiso import _native as N
