@@ -106,7 +106,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   bool pending = false;                                  // x still lacks alpha_k p_k of the last executed iteration
   int k_last = -1;
   // ---- persistent segments (cg_persist.h): applicable when every wave's region fits on chip
-  int persist_R = 0, persist_grid = 0;
+  int persist_R = 0, persist_NQ = 0, persist_grid = 0;
   PersistCtl pc;
   pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr;
   if (V == 16 / (int)sizeof(T) && a.per_y != 2 && !getenv("PISO_CG_NO_PERSIST")) {
@@ -114,17 +114,27 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntx = nx / (64 * V);
-    if (nx % (64 * V) == 0)                               // every lane of a strip has cells
-      for (int R : {2, 4, 8}) {
-        if (const char* e = getenv("PISO_CG_PERSIST_R")) { if (atoi(e) != R) continue; }   // tests: force the region height
-        if (ny % R != 0) continue;                        // every region has R rows
-        const long long nreg = (long long)ntx * (ny / R);
-        if (nreg % kPersistRegions == 0 && nreg <= (long long)cus * kPersistRegionsPerWg) {   // a wave owns 2 regions or none
-          persist_R = R; pc.nreg = (int)nreg; pc.ntx = ntx;
-          persist_grid = (int)((nreg + kPersistRegionsPerWg - 1) / kPersistRegionsPerWg);
-          break;
+    const char* force_r = getenv("PISO_CG_PERSIST_R");       // tests: force the region height
+    if (nx % (64 * V) == 0) {                               // every lane of a strip has cells
+      // one region of 16 rows per wave has the smallest halo overhead; taken when it keeps at least 3/4 of the waves busy
+      if (ny % 16 == 0 && (!force_r || atoi(force_r) == 16)) {
+        const long long nreg = (long long)ntx * (ny / 16);
+        if (nreg <= (long long)cus * kPersistWaves && (force_r || 4 * nreg >= 3LL * cus * kPersistWaves)) {
+          persist_R = 16; persist_NQ = 1; pc.nreg = (int)nreg; pc.ntx = ntx;
+          persist_grid = (int)((nreg + kPersistWaves - 1) / kPersistWaves);
         }
       }
+      for (int R : {2, 4, 8}) {
+        if (persist_R) break;
+        if (force_r && atoi(force_r) != R) continue;
+        if (ny % R != 0) continue;                          // every region has R rows
+        const long long nreg = (long long)ntx * (ny / R);
+        if (nreg % 2 == 0 && nreg <= (long long)cus * kPersistWaves * 2) {   // a wave owns 2 regions or none
+          persist_R = R; persist_NQ = 2; pc.nreg = (int)nreg; pc.ntx = ntx;
+          persist_grid = (int)((nreg + kPersistWaves * 2 - 1) / (kPersistWaves * 2));
+        }
+      }
+    }
     const char* force = getenv("PISO_CG_PERSIST");
     if (persist_R && n < 500000 && !(force && atoi(force) == 1)) persist_R = 0;   // small grids: two-kernel path
     if (force && atoi(force) == 0) persist_R = 0;
@@ -142,18 +152,22 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   auto launch_segment = [&](int kb, int ke) -> int {
     PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 64, stream));   // epochs restart at 1 in every launch
     constexpr bool kCanSym = RECON && sizeof(CT) == 4;     // the symmetric variant exists for the compact coefficient path
+#define PISO_PERSIST_LAUNCH(SYMV)                                                                                            \
+    do {                                                                                                                     \
+      if (persist_R == 2) cg_persist<T, CT, 2, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);        \
+      else if (persist_R == 4) cg_persist<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);   \
+      else if (persist_R == 8) cg_persist<T, CT, 8, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);   \
+      else cg_persist<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);                      \
+    } while (0)
     if constexpr (kCanSym) {
       if (symmetric) {
-        if (persist_R == 2) cg_persist<T, CT, 2, RECON, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
-        else if (persist_R == 4) cg_persist<T, CT, 4, RECON, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
-        else cg_persist<T, CT, 8, RECON, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+        PISO_PERSIST_LAUNCH(true);
         PISO_LAUNCH_CHECK();
         return PISO_OK;
       }
     }
-    if (persist_R == 2) cg_persist<T, CT, 2, RECON, false><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
-    else if (persist_R == 4) cg_persist<T, CT, 4, RECON, false><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
-    else cg_persist<T, CT, 8, RECON, false><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);
+    PISO_PERSIST_LAUNCH(false);
+#undef PISO_PERSIST_LAUNCH
     PISO_LAUNCH_CHECK();
     return PISO_OK;
   };

@@ -18,8 +18,7 @@ namespace piso {
 
 constexpr int kPersistThreads = 512;            // 8 waves per CU = 2 per SIMD -> 256 VGPRs per lane: state in registers without spills
 constexpr int kPersistWaves = kPersistThreads / 64;
-constexpr int kPersistRegions = 2;              // regions per wave
-constexpr int kPersistRegionsPerWg = kPersistWaves * kPersistRegions;
+// region shapes (rows R x regions per wave NQ): 2 x 2, 4 x 2, 8 x 2 and 16 x 1 - at most 16 rows of 128 columns per wave
 
 struct PersistCtl {
   unsigned long long* rec;   // exchange records: [2 (parity)][kPersistMaxGrid][8] 8-byte words, zeroed before every launch
@@ -27,7 +26,7 @@ struct PersistCtl {
   int nreg, ntx;        // regions (= waves with work), strips per row
   unsigned long long* timing;   // diagnostics (PISO_CG_PERSIST_TIMING): [4][grid] 100 MHz ticks in phase A / barrier A / phase B / barrier B
 };
-constexpr int kPersistMaxGrid = 512;
+constexpr int kPersistMaxGrid = 256;   // workgroups (one per CU); the exchange keeps kPersistMaxGrid / 64 records per lane in registers
 constexpr int kPersistMaxDepth = 6;     // rows of loads in flight per wave (register budget permitting)
 
 // Grid-wide exchange of 3 partial sums per workgroup that doubles as the grid barrier (measured 4.4 us for 256 workgroups
@@ -57,24 +56,31 @@ __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], un
   __syncthreads();
   if (wave == 0) {
     u64* rec = c.rec + (size_t)(epoch & 1) * kPersistMaxGrid * 8;
-    if (lane == 0) {
+    {
+      // workgroup partial (every lane, broadcast LDS reads), then lanes 0..5 publish the six tagged words with ONE store
+      T s[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        T s = 0;
-        for (int w = 0; w < kPersistWaves; ++w) s += sm[q * kPersistWaves + w];
-        const u64 bits = (u64)__double_as_longlong((double)s);
-        __hip_atomic_store(rec + (size_t)blockIdx.x * 8 + 2 * q, ((bits & 0xffffffffull) << 32) | epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(rec + (size_t)blockIdx.x * 8 + 2 * q + 1, (bits & 0xffffffff00000000ull) | epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s[q] = 0;
+        for (int w = 0; w < kPersistWaves; ++w) s[q] += sm[q * kPersistWaves + w];
       }
+      const int vq = lane >> 1;
+      const u64 bits = (u64)__double_as_longlong((double)(vq == 0 ? s[0] : (vq == 1 ? s[1] : s[2])));
+      const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+      if (lane < 6) __hip_atomic_store(rec + (size_t)blockIdx.x * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // Lane l owns records l, l + 64, ...: polled one after the other (arrivals cluster: after the first record the others
+    // are almost always there).  Reading all of them at once would be one round trip instead of up to four, but needs
+    // 12 more registers per record than this kernel has to spare, and more pollers slow the publishing stores down
+    // (scripts/barrier_bench.hip, variants 3 / 8 / 15 / 19).
     double tot[3] = {0, 0, 0};
     bool good = true;
+    unsigned spins = 0;
     for (int m = 0; m < ((int)gridDim.x + 63) / 64; ++m) {
       const int b = m * 64 + lane;
       const bool active = b < (int)gridDim.x;
       u64 w[6] = {0, 0, 0, 0, 0, 0};
       bool ok = !active;
-      unsigned spins = 0;
       while (true) {
         if (!ok) {
 #pragma unroll
@@ -189,11 +195,11 @@ __device__ __forceinline__ S shift_lane(S v, S edge) {
 // Host guarantees: nx % (64 V) == 0 (every lane of a strip has cells) and ny % R == 0 (every region has R rows).
 // SYM: the matrix is symmetric (verified bit for bit by cg_setup_coeffs): N of a cell is S of the cell above, E is W of the cell
 // to the right - only the S and W arrays are streamed (8 instead of 16 coefficient bytes per cell).
-template <typename T, typename CT, int R, bool RECON, bool SYM>
+template <typename T, typename CT, int R, int NQ, bool RECON, bool SYM>
 __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, PersistCtl c, int k_begin, int k_end, int sv) {
   constexpr int V = 16 / sizeof(T);                        // 16-byte lane accesses
-  constexpr int NQ = kPersistRegions;
-  __shared__ T xs[kPersistRegionsPerWg * R * 64 * V];      // the solution of my regions (128 KB at R = 8, fp64)
+  static_assert(R * NQ <= 16 && 2 * R <= 64, "at most 16 rows per wave; the edge columns of a region fit one wave-wide load");
+  __shared__ T xs[kPersistWaves * NQ * R * 64 * V];        // the solution of my regions (128 KB at 16 rows per wave, fp64)
   __shared__ T smem[64];
   const int nx = a.nx, ny = a.ny;
   const int lane = threadIdx.x & 63;

@@ -155,7 +155,8 @@ def _persist_iterations():
 
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("shape,reset,segment,rows", [((16, 128), 1000, 7, 2), ((64, 256), 200, 16, 8), ((36, 384), 1000, 1000, 2),
-                                                      ((32, 128), 1000, 30, 4), ((16, 256), 25, 1000, 8)])
+                                                      ((32, 128), 1000, 30, 4), ((16, 256), 25, 1000, 8),
+                                                      ((32, 128), 1000, 9, 16), ((64, 256), 300, 1000, 16)])
 def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, monkeypatch):
     """The persistent segment kernel (cg_persist.h: r / z' in registers, x in LDS, grid-wide exchanges instead of launches)
     is the path the 2048^2 benchmark runs; force it on small grids and hold it to the same bar as the two-kernel path:
@@ -167,7 +168,7 @@ def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, 
     px, py = s.periodic_yx[1], s.periodic_yx[0]
     monkeypatch.setenv("PISO_CG_PERSIST", "1")
     monkeypatch.setenv("PISO_CG_SEGMENT", str(segment))
-    monkeypatch.setenv("PISO_CG_PERSIST_R", str(rows))     # region height (2 / 4 / 8 rows): three kernel instantiations
+    monkeypatch.setenv("PISO_CG_PERSIST_R", str(rows))     # region height (2 / 4 / 8 / 16 rows): four kernel instantiations
     N.lib.piso_cg_profile_enable(1, 8)
     try:
         for nit in (2, 3, 9, 23, 47):
