@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(CSRC, "_obj", os.path.basename(src) + ".o")
         objs.append(obj)
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", 
-               "-ffp-contract=off", "-c", src, "-o", obj]
+               "-ffp-contract=off", "-c", src, "-o", obj] + os.environ.get("PISO_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))

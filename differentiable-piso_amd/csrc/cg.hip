@@ -250,11 +250,6 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     std::vector<unsigned long long> h(12 * persist_grid);
     PISO_HIP_CHECK(hipMemcpy(h.data(), pc.timing, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     PISO_HIP_CHECK(hipFree(pc.timing));
-    for (int b : {0, persist_grid / 2, persist_grid - 1}) {
-      fprintf(stderr, "cg_persist phaseA per wave, workgroup %d:", b);
-      for (int w = 0; w < kPersistWaves; ++w) fprintf(stderr, " %.2f", 0.01 * (double)h[4 * persist_grid + b * kPersistWaves + w] / (double)(k_last > 0 ? k_last : 1));
-      fprintf(stderr, " us/iter\n");
-    }
     const char* names[4] = {"phaseA", "barrierA", "phaseB", "barrierB"};
     for (int q = 0; q < 4; ++q) {
       double s = 0, mn = 1e300, mx = 0;

@@ -26,8 +26,13 @@ struct PersistCtl {
   int nreg, ntx;        // regions (= waves with work), strips per row
   unsigned long long* timing;   // diagnostics (PISO_CG_PERSIST_TIMING): [4][grid] 100 MHz ticks in phase A / barrier A / phase B / barrier B
 };
+#ifdef PISO_PERSIST_DIAG
+constexpr bool kPersistDiag = true;     // per-phase clocks of wave 0 (PISO_CG_PERSIST_TIMING=1); costs a few registers
+#else
+constexpr bool kPersistDiag = false;
+#endif
 constexpr int kPersistMaxGrid = 256;   // workgroups (one per CU); the exchange keeps kPersistMaxGrid / 64 records per lane in registers
-constexpr int kPersistMaxDepth = 6;     // rows of loads in flight per wave (register budget permitting)
+constexpr int kPersistMaxDepth = 4;     // coefficient rows in flight per wave: deeper spills registers, and spills cost more than latency (measured 3..16)
 
 // Grid-wide exchange of 3 partial sums per workgroup that doubles as the grid barrier (measured 4.4 us for 256 workgroups
 // against 11.3 us for "atomic counter + fence + read the partials", scripts/barrier_bench.hip).
@@ -70,9 +75,9 @@ __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], un
       if (lane < 6) __hip_atomic_store(rec + (size_t)blockIdx.x * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // Lane l owns records l, l + 64, ...: polled one after the other (arrivals cluster: after the first record the others
-    // are almost always there).  Reading all of them at once would be one round trip instead of up to four, but needs
-    // 12 more registers per record than this kernel has to spare, and more pollers slow the publishing stores down
-    // (scripts/barrier_bench.hip, variants 3 / 8 / 15 / 19).
+    // are almost always there).  Reading the later ones at once would be two round trips instead of up to four, but needs
+    // 12 more registers per record than this kernel has to spare (spills cost more than the round trips), and more
+    // pollers slow the publishing stores down (scripts/barrier_bench.hip, variants 3 / 8 / 15 / 19).
     double tot[3] = {0, 0, 0};
     bool good = true;
     unsigned spins = 0;
@@ -229,19 +234,25 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     return j;
   };
 
-  // ---- load the state of the two-kernel path: r of my regions into registers, x into LDS
-  Vec<T, V> rr[NQ][R], zz[NQ][R];
+  // ---- load the state of the two-kernel path: r and the search direction p of my regions into registers, x into LDS
+  Vec<T, V> rr[NQ][R], pp[NQ][R];
+  unsigned vT[NQ], vC[NQ];
+  {
+    const rsrc_t Rp = (k_begin & 1) ? Rp1 : Rp0;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const unsigned vT = (unsigned)((tx0[q] * 64 + lane) * V * sizeof(T));
-    T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
+    for (int q = 0; q < NQ; ++q) {
+      const int cq = (tx0[q] * 64 + lane) * V;
+      vT[q] = (unsigned)(cq * sizeof(T)); vC[q] = (unsigned)(cq * sizeof(CT));
+      T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
 #pragma unroll
-    for (int jj = 0; jj < R; ++jj) {
+      for (int jj = 0; jj < R; ++jj) {
 #pragma unroll
-      for (int e = 0; e < V; ++e) { rr[q][jj].v[e] = 0; zz[q][jj].v[e] = 0; }
-      if (has[q]) {
-        rr[q][jj] = bld<T, V>(Rr, vT, (unsigned)(j0[q] + jj) * rowT);
-        stv<T, V>(xl + jj * 64 * V, bld<T, V>(Rx, vT, (unsigned)(j0[q] + jj) * rowT));
+        for (int e = 0; e < V; ++e) { rr[q][jj].v[e] = 0; pp[q][jj].v[e] = 0; }
+        if (has[q]) {
+          rr[q][jj] = bld<T, V>(Rr, vT[q], (unsigned)(j0[q] + jj) * rowT);
+          pp[q][jj] = bld<T, V>(Rp, vT[q], (unsigned)(j0[q] + jj) * rowT);
+          stv<T, V>(xl + jj * 64 * V, bld<T, V>(Rx, vT[q], (unsigned)(j0[q] + jj) * rowT));
+        }
       }
     }
   }
@@ -270,28 +281,20 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     __syncthreads();
   }
 
-  // ---- phase-A row pipeline (see phase A below): registers of the rows in flight, carried ACROSS iterations
-  constexpr int row_regs = (16 + (SYM ? 2 : 4) * (int)sizeof(CT) * V + (RECON ? 0 : 16)) / 4;      // VGPRs of one row in flight
-  constexpr int Dw = 48 / row_regs < 2 ? 2 : (48 / row_regs > kPersistMaxDepth ? kPersistMaxDepth : 48 / row_regs);
-  constexpr int NT = NQ * R, D = (R >= Dw) ? Dw : R;
-  // vector loads of the own part of row D - 1, the last one a phase issues (after its last store) for the next iteration
-  constexpr int kRowLoads = (SYM ? 3 + ((D - 1) % R == 0 ? 1 : 0) + ((D - 1) % R == R - 1 ? 1 : 0) : 5) + (RECON ? 0 : 1);
-  Vec<T, V> Pq[NT], hbR[NQ], hbP[NQ], haR[NQ], haP[NQ];
+  // ---- coefficient pipeline: both phases of an iteration stream the coefficient rows of my regions in the same order;
+  // the loads of row t + D are issued when row t has been consumed, CIRCULARLY (the last D steps of a phase issue rows
+  // 0 .. D-1 for the next phase, which then travel while the grid exchange leaves the memory system idle).
+  constexpr int coef_regs = ((SYM ? 2 : 4) * (int)sizeof(CT) * V + (RECON ? 0 : (int)sizeof(T) * V)) / 4;   // VGPRs of a row in flight
+  constexpr int NT = NQ * R;
+  constexpr int Dw = 64 / coef_regs < 2 ? 2 : (64 / coef_regs > kPersistMaxDepth ? kPersistMaxDepth : 64 / coef_regs);
+  constexpr int D = (NT >= Dw) ? Dw : NT;
+  constexpr int kBaseLoads = (SYM ? 2 : 4) + (RECON ? 0 : 1);          // vector loads every row issues (some rows one or two more)
   Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT], cSh[NQ];
   Vec<T, V> cD[NT];
-  T eP[NQ], eR[NQ];
   CT eW[NQ];
-  unsigned vT[NQ], vC[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int cq = (tx0[q] * 64 + lane) * V;
-    vT[q] = (unsigned)(cq * sizeof(T)); vC[q] = (unsigned)(cq * sizeof(CT));
-  }
-  // own part of row t: p_old and the coefficient rows - nothing another workgroup writes inside the launch
-  auto issue_own = [&](int t, rsrc_t Rp) __attribute__((always_inline)) {
+  auto issue_coef = [&](int t) __attribute__((always_inline)) {
     const int q = t / R, jj = t - q * R;
     const unsigned sT = (unsigned)(j0[q] + jj) * rowT, sC = (unsigned)(j0[q] + jj) * rowC;
-    Pq[t] = bld<T, V, kAgent>(Rp, vT[q], sT);
     cS[t] = bld<CT, V>(RoS, vC[q], sC); cW[t] = bld<CT, V>(RoW, vC[q], sC);
     if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vC[q], sC); cN[t] = bld<CT, V>(RoN, vC[q], sC); }
     if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
@@ -310,44 +313,75 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
       }
     }
   };
-  // neighbours' part that comes with row t (first row of a region: edge columns + halo row behind; last row: halo row ahead)
-  auto issue_halo = [&](int t, rsrc_t Rp) __attribute__((always_inline)) {
+  // p_new on the cells around a region, rebuilt from what the neighbours published (perimeters of r and of the old p):
+  // pnb / pna = the rows below / above, edge = the two columns next to the strip (lane l < R: left neighbour of row l,
+  // lane R + l: right neighbour).  Kept from phase A to phase B.
+  Vec<T, V> pnb[NQ], pna[NQ];
+  T edge[NQ];
+  // z' = L p of row t of my regions: summation order of calcZ_v4 (pressure_solve_op.cu.cc:81-90).  Phase A and phase B
+  // both call this on the same registers, so they see bitwise the same z'.
+  auto zrow = [&](int t) __attribute__((always_inline)) -> Vec<T, V> {
     const int q = t / R, jj = t - q * R;
-    if (jj == 0) {
-      // p_new on the two columns next to the strip, all R rows with ONE pair of loads: lane l < R holds the left
-      // neighbour of row l, lane R + l the right neighbour; lanes without a cell (and walls) read out of range -> 0
-      const int side = lane / R, er = lane - side * R;
-      int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
-      if (cc < 0) cc = a.per_x ? nx - 1 : -1;
-      else if (cc >= nx) cc = a.per_x ? 0 : -1;
-      const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
-      eP[q] = bld1<T, kAgent>(Rp, vo, 0);
-      eR[q] = bld1<T, kAgent>(Rr, vo, 0);
-      bool valid;
-      const int jw = row_wrap(j0[q] - 1, valid);
-      const unsigned vh = valid ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
-      hbR[q] = bld<T, V, kAgent>(Rr, vh, (unsigned)jw * rowT);
-      hbP[q] = bld<T, V, kAgent>(Rp, vh, (unsigned)jw * rowT);
+    const Vec<T, V> behind = (jj > 0) ? pp[q][jj > 0 ? jj - 1 : 0] : pnb[q];
+    const Vec<T, V> cur = pp[q][jj];
+    const Vec<T, V> ahead = (jj + 1 < R) ? pp[q][jj + 1 < R ? jj + 1 : jj] : pna[q];
+    const T left = shift_lane<true, T>(cur.v[V - 1], read_lane<T>(edge[q], jj));
+    const T right = shift_lane<false, T>(cur.v[0], read_lane<T>(edge[q], R + jj));
+    Vec<CT, V> kN, kE;
+    if constexpr (SYM) {
+      kN = (jj + 1 < R) ? cS[t + 1 < NT ? t + 1 : t] : cSh[q];
+#pragma unroll
+      for (int e = 0; e + 1 < V; ++e) kE.v[e] = cW[t].v[e + 1];
+      kE.v[V - 1] = shift_lane<false, CT>(cW[t].v[0], read_lane<CT>(eW[q], R + jj));
+    } else {
+      kN = cN[t]; kE = cE[t];
     }
-    if (jj == R - 1) {
-      bool valid;
-      const int jw = row_wrap(j0[q] + R, valid);
-      const unsigned vh = valid ? vT[q] : 0xffffffffu;
-      haR[q] = bld<T, V, kAgent>(Rr, vh, (unsigned)jw * rowT);
-      haP[q] = bld<T, V, kAgent>(Rp, vh, (unsigned)jw * rowT);
+    Vec<T, V> kC, z;
+    if constexpr (RECON) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        T d = 0;
+        d -= (T)cS[t].v[e]; d -= (T)kN.v[e]; d -= (T)cW[t].v[e]; d -= (T)kE.v[e];
+        kC.v[e] = d;
+      }
+    } else {
+      kC = cD[t];
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const T pw = (e == 0) ? left : cur.v[e > 0 ? e - 1 : 0];
+      const T pe = (e == V - 1) ? right : cur.v[e < V - 1 ? e + 1 : 0];
+      T tmp = 0;
+      tmp = fma((T)cS[t].v[e], behind.v[e], tmp);
+      tmp = fma((T)cW[t].v[e], pw, tmp);
+      tmp = fma(kC.v[e], cur.v[e], tmp);
+      tmp = fma((T)kE.v[e], pe, tmp);
+      tmp = fma((T)kN.v[e], ahead.v[e], tmp);
+      z.v[e] = tmp;
+    }
+    return z;
+  };
+  // perimeter of row jj of region q (what neighbouring regions read): the whole first / last row, else the two end cells
+  auto publish = [&](rsrc_t Rd, int q, int jj, const Vec<T, V>& val) __attribute__((always_inline)) {
+    const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
+    if (jj == 0 || jj == R - 1) {
+      bst<T, V, kAgent>(Rd, vT[q], sT, val);
+    } else {
+      if (lane == 0) bst1<T, kAgent>(Rd, vT[q], sT, val.v[0]);
+      if (lane == 63) bst1<T, kAgent>(Rd, vT[q] + (unsigned)((V - 1) * sizeof(T)), sT, val.v[V - 1]);
     }
   };
   if (has[0]) {
 #pragma unroll
-    for (int t = 0; t < D; ++t) issue_own(t, (k_begin & 1) ? Rp1 : Rp0);
+    for (int t = 0; t < D; ++t) issue_coef(t);
   }
 
   unsigned epoch = 0;
   bool healthy = true;
   int k = k_begin;
-  unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = c.timing ? wall_clock64() : 0;
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = (kPersistDiag && c.timing) ? wall_clock64() : 0;
   auto tick = [&](int slot) __attribute__((always_inline)) {
-    if (c.timing) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t = wall_clock64(); tacc[slot] += t - tlast; tlast = t; }
+    if (kPersistDiag && c.timing) { const unsigned long long t = wall_clock64(); tacc[slot] += t - tlast; tlast = t; }   // (scalar registers only)
   };
   for (; k < k_end && healthy; ++k) {
     // ---- start of iteration k: stopping test of iteration k-1 (pressure_solve_op.cu.cc:312-335), beta (:351-352)
@@ -361,14 +395,12 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         if (has[q]) {
-          const unsigned vT = (unsigned)((tx0[q] * 64 + lane) * V * sizeof(T));
           T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
 #pragma unroll
           for (int jj = 0; jj < R; ++jj) {
             Vec<T, V> xv = ldv<T, V>(xl + jj * 64 * V);
-            const Vec<T, V> pq = bld<T, V, kAgent>(Rpin, vT, (unsigned)(j0[q] + jj) * rowT);
 #pragma unroll
-            for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha, pq.v[e], xv.v[e]);
+            for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha, pp[q][jj].v[e], xv.v[e]);
             stv<T, V>(xl + jj * 64 * V, xv);
           }
         }
@@ -377,154 +409,132 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     const T beta = -(tB[0] + vs * tB[1]) / pz;
     const T alpha_prev = alpha;
 
-    // ---- phase A: x += alpha_prev p_old ; p_new = r + beta p_old (own rows from registers, halo from HBM) ; z' = L p_new
-    T sA[3] = {0, 0, 0};                                   // sum p, p.r, p.z'
+    // ---- phase A: x += alpha_prev p_old ; p_new = r + beta p_old (registers) ; z' = L p_new ; sums p, p.r, p.z'
+    T sA[3] = {0, 0, 0};
     if (has[0]) {                                          // the host makes nreg a multiple of NQ: a wave owns NQ regions or none
-      // The rows of both regions form ONE software pipeline of NT steps: the loads of step t + D (p_old and the four
-      // coefficient rows; with the first / last row of a region also its edge columns and halo rows) are issued before step t
-      // computes, so ~D rows x 48 B per lane are in flight instead of one (the kernel runs 2 waves per SIMD: latency must be
-      // hidden inside the wave).  The pipeline is CIRCULAR: the last D steps issue the own part of rows 0 .. D-1 of the NEXT
-      // iteration (its p_old is what this phase just stored), so a quarter of the next phase's loads travels while the two
-      // grid exchanges and phase B leave the memory system idle.  sched_barrier pins the order; the compiler derives exact
-      // s_waitcnt vmcnt(N) from it.
-      // own row t of the new direction; also performs x <- x + alpha_prev p_old (the axpy of iteration k-1, :303)
-      auto own_row = [&](int t) __attribute__((always_inline)) -> Vec<T, V> {
-        const int q = t / R, jj = t - q * R;
-        T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V + jj * 64 * V;
-        Vec<T, V> o, xv = ldv<T, V>(xl);
+      // what the neighbours published: the columns next to the strip (all R rows with ONE pair of loads; lanes without a cell
+      // and walls read out of range -> 0) and the rows below / above the region
+      T eP[NQ], eR[NQ];
+      Vec<T, V> hbR[NQ], hbP[NQ], haR[NQ], haP[NQ];
 #pragma unroll
-        for (int e = 0; e < V; ++e) { o.v[e] = fma(beta, Pq[t].v[e], rr[q][jj].v[e]); xv.v[e] = fma(alpha_prev, Pq[t].v[e], xv.v[e]); }
-        stv<T, V>(xl, xv);
-        return o;
-      };
+      for (int q = 0; q < NQ; ++q) {
+        const int side = lane / R, er = lane - side * R;
+        int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
+        if (cc < 0) cc = a.per_x ? nx - 1 : -1;
+        else if (cc >= nx) cc = a.per_x ? 0 : -1;
+        const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
+        eP[q] = bld1<T, kAgent>(Rpin, vo, 0);
+        eR[q] = bld1<T, kAgent>(Rr, vo, 0);
+        bool vb, va;
+        const int jb = row_wrap(j0[q] - 1, vb), ja = row_wrap(j0[q] + R, va);
+        const unsigned hb = vb ? vT[q] : 0xffffffffu, ha = va ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
+        hbR[q] = bld<T, V, kAgent>(Rr, hb, (unsigned)jb * rowT);
+        hbP[q] = bld<T, V, kAgent>(Rpin, hb, (unsigned)jb * rowT);
+        haR[q] = bld<T, V, kAgent>(Rr, ha, (unsigned)ja * rowT);
+        haP[q] = bld<T, V, kAgent>(Rpin, ha, (unsigned)ja * rowT);
+      }
+      // meanwhile, on chip: the axpy of iteration k-1 (:303) and the new direction; its perimeter goes out for iteration k+1
 #pragma unroll
-      for (int t = 0; t < D; ++t) issue_halo(t, Rpin);     // (the own part of these rows was issued before the exchange)
-      Vec<T, V> behind, cur, ahead;
-      T edge = 0;
+      for (int q = 0; q < NQ; ++q) {
+        T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) {
+          Vec<T, V> xv = ldv<T, V>(xl + jj * 64 * V);
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            xv.v[e] = fma(alpha_prev, pp[q][jj].v[e], xv.v[e]);
+            pp[q][jj].v[e] = fma(beta, pp[q][jj].v[e], rr[q][jj].v[e]);
+          }
+          stv<T, V>(xl + jj * 64 * V, xv);
+          publish(Rpout, q, jj, pp[q][jj]);
+          if (jj & 1) __builtin_amdgcn_sched_barrier(0);     // two rows of x at a time: bounds the registers of this prelude
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        edge[q] = fma(beta, eP[q], eR[q]);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          pnb[q].v[e] = fma(beta, hbP[q].v[e], hbR[q].v[e]);
+          pna[q].v[e] = fma(beta, haP[q].v[e], haR[q].v[e]);
+        }
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int q = t / R, jj = t - q * R;
-        if (jj == 0) {
-          edge = fma(beta, eP[q], eR[q]);
-#pragma unroll
-          for (int e = 0; e < V; ++e) behind.v[e] = fma(beta, hbP[q].v[e], hbR[q].v[e]);
-          cur = own_row(t);
-        }
-        if (jj + 1 < R) ahead = own_row(t + 1 < NT ? t + 1 : t);
-        else {
-#pragma unroll
-          for (int e = 0; e < V; ++e) ahead.v[e] = fma(beta, haP[q].v[e], haR[q].v[e]);
-        }
-        const T left = shift_lane<true, T>(cur.v[V - 1], read_lane<T>(edge, jj));
-        const T right = shift_lane<false, T>(cur.v[0], read_lane<T>(edge, R + jj));
-        Vec<CT, V> kN, kE;
-        if constexpr (SYM) {
-          kN = (jj + 1 < R) ? cS[t + 1 < NT ? t + 1 : t] : cSh[q];
-#pragma unroll
-          for (int e = 0; e + 1 < V; ++e) kE.v[e] = cW[t].v[e + 1];
-          kE.v[V - 1] = shift_lane<false, CT>(cW[t].v[0], read_lane<CT>(eW[q], R + jj));
-        } else {
-          kN = cN[t]; kE = cE[t];
-        }
-        Vec<T, V> kC;
-        if constexpr (RECON) {
-#pragma unroll
-          for (int e = 0; e < V; ++e) {
-            T d = 0;
-            d -= (T)cS[t].v[e]; d -= (T)kN.v[e]; d -= (T)cW[t].v[e]; d -= (T)kE.v[e];
-            kC.v[e] = d;
-          }
-        } else {
-          kC = cD[t];
-        }
+        const Vec<T, V> z = zrow(t);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const T pw = (e == 0) ? left : cur.v[e > 0 ? e - 1 : 0];
-          const T pe = (e == V - 1) ? right : cur.v[e < V - 1 ? e + 1 : 0];
-          T tmp = 0;                                        // summation order of calcZ_v4 (:81-90)
-          tmp = fma((T)cS[t].v[e], behind.v[e], tmp);
-          tmp = fma((T)cW[t].v[e], pw, tmp);
-          tmp = fma(kC.v[e], cur.v[e], tmp);
-          tmp = fma((T)kE.v[e], pe, tmp);
-          tmp = fma((T)kN.v[e], ahead.v[e], tmp);
-          zz[q][jj].v[e] = tmp;
-          sA[0] += cur.v[e];
-          sA[1] = fma(cur.v[e], rr[q][jj].v[e], sA[1]);
-          sA[2] = fma(cur.v[e], tmp, sA[2]);
+          sA[0] += pp[q][jj].v[e];
+          sA[1] = fma(pp[q][jj].v[e], rr[q][jj].v[e], sA[1]);
+          sA[2] = fma(pp[q][jj].v[e], z.v[e], sA[2]);
         }
-        bst<T, V, kAgent>(Rpout, vT[q], (unsigned)(j0[q] + jj) * rowT, cur);
-        behind = cur;
-        cur = ahead;
-        // refill the pipeline AFTER the store: the exchange below may then leave exactly the last row's loads in flight
         __builtin_amdgcn_sched_barrier(0);
-        if (t + D < NT) { issue_own(t + D < NT ? t + D : t, Rpin); issue_halo(t + D < NT ? t + D : t, Rpin); }
-        else issue_own(t + D >= NT ? t + D - NT : 0, Rpout);     // row of the next iteration: its p_old is this p_new
+        if constexpr (D < NT) issue_coef(t + D < NT ? t + D : t + D - NT);   // wraps: rows 0 .. D-1 again, for phase B
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (c.timing && lane == 0) {                           // diagnostics: when does EVERY wave of a workgroup finish phase A?
-      __builtin_amdgcn_s_waitcnt(0);
-      c.timing[4 * gridDim.x + blockIdx.x * kPersistWaves + wave] += wall_clock64() - tlast;
-    }
     ++epoch;
     tick(0);
-    healthy = grid_exchange<T, kRowLoads>(c, sA, epoch, smem);
+    // (every store of this phase was issued before NT rows of coefficient loads: at most D rows may stay in flight)
+    healthy = grid_exchange<T, (D < NT) ? D * kBaseLoads : 0>(c, sA, epoch, smem);
     tick(1);
     if (!healthy) break;
-    // ---- alpha (:301-302), then phase B: r -= alpha (z' + vs), partial sums, publish the perimeter of r
+    // ---- alpha (:301-302), then phase B: z' again, r -= alpha (z' + vs), sums, publish the perimeter of r
     vs = sc_c * sA[0];
     pz = sA[2] + vs * sA[0];
     alpha = (absval(pz) > 0) ? sA[1] / pz : (T)0;
     T sB[3] = {0, 0, 0};
     const T accuracy = (T)a.accuracy;
+    if (has[0]) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      if (!has[q]) continue;
-      const unsigned vT = (unsigned)((tx0[q] * 64 + lane) * V * sizeof(T));
-#pragma unroll
-      for (int jj = 0; jj < R; ++jj) {
+      for (int t = 0; t < NT; ++t) {
+        const int q = t / R, jj = t - q * R;
+        const Vec<T, V> z = zrow(t);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const T rn = fma(-alpha, zz[q][jj].v[e] + vs, rr[q][jj].v[e]);
+          const T rn = fma(-alpha, z.v[e] + vs, rr[q][jj].v[e]);
           rr[q][jj].v[e] = rn;
-          sB[0] = fma(rn, zz[q][jj].v[e], sB[0]);
+          sB[0] = fma(rn, z.v[e], sB[0]);
           sB[1] += rn;
           sB[2] += (absval(rn) < accuracy) ? (T)0 : (T)1;
         }
-        const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
-        if (jj == 0 || jj == R - 1) {
-          bst<T, V, kAgent>(Rr, vT, sT, rr[q][jj]);           // edge rows: whole row
-        } else {
-          if (lane == 0) bst1<T, kAgent>(Rr, vT, sT, rr[q][jj].v[0]);                           // edge columns
-          if (lane == 63) bst1<T, kAgent>(Rr, vT + (unsigned)((V - 1) * sizeof(T)), sT, rr[q][jj].v[V - 1]);
-        }
+        publish(Rr, q, jj, rr[q][jj]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (D < NT) issue_coef(t + D < NT ? t + D : t + D - NT);   // wraps: rows 0 .. D-1 for phase A of the next iteration
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     ++epoch;
     tick(2);
-    healthy = grid_exchange<T>(c, sB, epoch, smem);
+    // (the last row's perimeter store is followed by exactly one row of coefficient loads)
+    healthy = grid_exchange<T, (D < NT) ? kBaseLoads : 0>(c, sB, epoch, smem);
     tick(3);
 #pragma unroll
     for (int q = 0; q < 3; ++q) tB[q] = sB[q];
   }
-  if (c.timing && threadIdx.x == 0) {
+  if (kPersistDiag && c.timing && threadIdx.x == 0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) c.timing[q * gridDim.x + blockIdx.x] += tacc[q];
   }
 
-  // ---- back to the global-memory state of the two-kernel path
+  // ---- back to the global-memory state of the two-kernel path (iteration k reads its direction from p[k & 1])
+  {
+    const rsrc_t Rp = (k & 1) ? Rp1 : Rp0;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q)
-    if (has[q]) {
-      const unsigned vT = (unsigned)((tx0[q] * 64 + lane) * V * sizeof(T));
-      T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
+    for (int q = 0; q < NQ; ++q)
+      if (has[q]) {
+        T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
 #pragma unroll
-      for (int jj = 0; jj < R; ++jj) {
-        const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
-        bst<T, V>(Rr, vT, sT, rr[q][jj]);
-        bst<T, V>(Rx, vT, sT, ldv<T, V>(xl + jj * 64 * V));
+        for (int jj = 0; jj < R; ++jj) {
+          const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
+          bst<T, V>(Rr, vT[q], sT, rr[q][jj]);
+          bst<T, V>(Rp, vT[q], sT, pp[q][jj]);
+          bst<T, V>(Rx, vT[q], sT, ldv<T, V>(xl + jj * 64 * V));
+        }
       }
-    }
+  }
   if (blockIdx.x == 0) {
     // the next launch (cg_k1 with do_check, or another segment) finds the last K2-totals in record 0 of partsB
     for (int b = threadIdx.x; b < a.nB; b += kPersistThreads) {
