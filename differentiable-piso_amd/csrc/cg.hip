@@ -136,7 +136,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
       }
     }
     const char* force = getenv("PISO_CG_PERSIST");
-    if (persist_R && n < 500000 && !(force && atoi(force) == 1)) persist_R = 0;   // small grids: two-kernel path
+    if (persist_R && n < 16384 && !(force && atoi(force) == 1)) persist_R = 0;    // tiny grids: two-kernel path
     if (force && atoi(force) == 0) persist_R = 0;
   }
   if (persist_R) {
@@ -154,10 +154,10 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     constexpr bool kCanSym = RECON && sizeof(CT) == 4;     // the symmetric variant exists for the compact coefficient path
 #define PISO_PERSIST_LAUNCH(SYMV)                                                                                            \
     do {                                                                                                                     \
-      if (persist_R == 2) cg_persist<T, CT, 2, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);        \
-      else if (persist_R == 4) cg_persist<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);   \
-      else if (persist_R == 8) cg_persist<T, CT, 8, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);   \
-      else cg_persist<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv);                      \
+      if (persist_R == 2) cg_persist<T, CT, 2, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);        \
+      else if (persist_R == 4) cg_persist<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
+      else if (persist_R == 8) cg_persist<T, CT, 8, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
+      else cg_persist<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);                      \
     } while (0)
     if constexpr (kCanSym) {
       if (symmetric) {
@@ -179,7 +179,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   double seg_ms = 0; long long seg_iters = 0, seg_launches = 0;
   for (int k = 0; k < total && !finished; ++k) {
     const bool is_reset = !fixed && ((k + 1) % reset == 0);
-    if (persist_R && k > 0 && !is_reset && pending) {
+    if (persist_R && k > 0 && !is_reset) {
       // run NORMAL iterations [k, ke) in one launch: up to the next reset iteration / the end / one segment length
       int ke = total;
       if (!fixed) { const int next_reset = ((k + 1 + reset - 1) / reset) * reset - 1; if (next_reset < ke) ke = next_reset; }
@@ -196,6 +196,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
         if (prof) { float t = 0; PISO_HIP_CHECK(hipEventElapsedTime(&t, seg_ev[0], seg_ev[1])); seg_ms += t; seg_iters += ke - k; ++seg_launches; }
         if (tl_poll.pinned[0].done) { finished = true; stop_it = tl_poll.pinned[0].iterations; }
         k_last = ke - 1;
+        pending = false;                                   // the segment applies every x += alpha p itself
         k = ke - 1;                                        // the loop increment moves to ke
         continue;
       }

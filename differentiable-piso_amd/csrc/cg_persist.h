@@ -34,6 +34,18 @@ constexpr bool kPersistDiag = false;
 constexpr int kPersistMaxGrid = 256;   // workgroups (one per CU); the exchange keeps kPersistMaxGrid / 64 records per lane in registers
 constexpr int kPersistMaxDepth = 4;     // coefficient rows in flight per wave: deeper spills registers, and spills cost more than latency (measured 3..16)
 
+// a wave-uniform value moved to scalar registers (the VALU results of the reductions / divisions would otherwise occupy
+// vector registers for the whole iteration; every VALU instruction can read one scalar operand directly)
+template <typename S>
+__device__ __forceinline__ S uniform(S v) {
+  if constexpr (sizeof(S) == 8) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return (S)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  } else {
+    return (S)__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)v)));
+  }
+}
 // Grid-wide exchange of 3 partial sums per workgroup that doubles as the grid barrier (measured 4.4 us for 256 workgroups
 // against 11.3 us for "atomic counter + fence + read the partials", scripts/barrier_bench.hip).
 //   * every workgroup publishes one 64-byte record: each double travels as two 8-byte words {32 payload bits | 32-bit epoch},
@@ -46,7 +58,7 @@ constexpr int kPersistMaxDepth = 4;     // coefficient rows in flight per wave: 
 // (s_waitcnt vmcnt(0)) by every wave before the workgroup publishes; readers load it at agent scope as well.
 // KEEP = number of vector-memory LOADS this wave issued after its last store and may leave in flight (prefetch for the next
 // phase; vmcnt retires in issue order, so "at most KEEP outstanding" means every store has completed).
-template <typename T, int KEEP = 0>
+template <typename T, int KEEP, bool HYBRID>
 __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], unsigned epoch, T* smem) {
   typedef unsigned long long u64;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -74,33 +86,91 @@ __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], un
       const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
       if (lane < 6) __hip_atomic_store(rec + (size_t)blockIdx.x * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // Lane l owns records l, l + 64, ...: polled one after the other (arrivals cluster: after the first record the others
-    // are almost always there).  Reading the later ones at once would be two round trips instead of up to four, but needs
-    // 12 more registers per record than this kernel has to spare (spills cost more than the round trips), and more
-    // pollers slow the publishing stores down (scripts/barrier_bench.hip, variants 3 / 8 / 15 / 19).
+    // Lane l owns records l, l + 64, ...  Arrivals cluster: once a lane's first record is there, the others almost always
+    // are too.  HYBRID polls the first record, then reads the remaining ones in one go and re-polls only stragglers (two
+    // memory round trips instead of up to four) - 36 more registers, which the kernels with 16 rows of state per wave
+    // do not have (a spill costs more than a round trip); those poll record after record.  Reading everything from the
+    // start, or polling from several waves, multiplies the polling traffic that slows the publishing stores down
+    // (scripts/barrier_bench.hip, variants 1 / 3 / 8 / 15 / 19).
     double tot[3] = {0, 0, 0};
     bool good = true;
     unsigned spins = 0;
-    for (int m = 0; m < ((int)gridDim.x + 63) / 64; ++m) {
-      const int b = m * 64 + lane;
-      const bool active = b < (int)gridDim.x;
-      u64 w[6] = {0, 0, 0, 0, 0, 0};
-      bool ok = !active;
+    if constexpr (HYBRID) {
+      constexpr int NR = kPersistMaxGrid / 64;
+      u64 w[NR][6];
+      bool ok[NR];
+#pragma unroll
+      for (int m = 0; m < NR; ++m) {
+        ok[m] = (m * 64 + lane) >= (int)gridDim.x;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) w[m][q] = 0;
+      }
       while (true) {
-        if (!ok) {
+        if (!ok[0]) {
 #pragma unroll
-          for (int q = 0; q < 6; ++q) w[q] = __hip_atomic_load(rec + (size_t)b * 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = true;
+          for (int q = 0; q < 6; ++q) w[0][q] = __hip_atomic_load(rec + (size_t)lane * 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bool o = true;
 #pragma unroll
-          for (int q = 0; q < 6; ++q) ok = ok && ((unsigned)(w[q] & 0xffffffffull) == epoch);
+          for (int q = 0; q < 6; ++q) o = o && ((unsigned)(w[0][q] & 0xffffffffull) == epoch);
+          ok[0] = o;
         }
-        if (__all(ok)) break;
+        if (__all(ok[0])) break;
+        if (++spins > (1u << 22)) { good = false; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      while (good) {
+        bool all = true;
+#pragma unroll
+        for (int m = 1; m < NR; ++m)
+          if (!ok[m]) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+              w[m][q] = __hip_atomic_load(rec + (size_t)(m * 64 + lane) * 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+        for (int m = 1; m < NR; ++m) {
+          if (!ok[m]) {
+            bool o = true;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) o = o && ((unsigned)(w[m][q] & 0xffffffffull) == epoch);
+            ok[m] = o;
+          }
+          all = all && ok[m];
+        }
+        if (__all(all)) break;
         if (++spins > (1u << 22)) { good = false; break; }
         __builtin_amdgcn_s_sleep(1);
       }
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
-        tot[q] += active ? __longlong_as_double((long long)((w[2 * q] >> 32) | (w[2 * q + 1] & 0xffffffff00000000ull))) : 0.0;
+      for (int m = 0; m < NR; ++m) {
+        const bool active = (m * 64 + lane) < (int)gridDim.x;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          tot[q] += active ? __longlong_as_double((long long)((w[m][2 * q] >> 32) | (w[m][2 * q + 1] & 0xffffffff00000000ull))) : 0.0;
+      }
+    } else {
+      // sequential rounds: a lane holds one record at a time
+      for (int m = 0; m < ((int)gridDim.x + 63) / 64; ++m) {
+        const int b = m * 64 + lane;
+        const bool active = b < (int)gridDim.x;
+        u64 w[6] = {0, 0, 0, 0, 0, 0};
+        bool ok = !active;
+        while (true) {
+          if (!ok) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) w[q] = __hip_atomic_load(rec + (size_t)b * 8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = true;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ok = ok && ((unsigned)(w[q] & 0xffffffffull) == epoch);
+          }
+          if (__all(ok)) break;
+          if (++spins > (1u << 22)) { good = false; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          tot[q] += active ? __longlong_as_double((long long)((w[2 * q] >> 32) | (w[2 * q + 1] & 0xffffffff00000000ull))) : 0.0;
+      }
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) tot[q] = wave_sum(tot[q]);
@@ -113,8 +183,8 @@ __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], un
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 3; ++q) v[q] = sm[24 + q];
-  return sm[27] == (T)0;
+  for (int q = 0; q < 3; ++q) v[q] = uniform(sm[24 + q]);
+  return uniform(sm[27]) == (T)0;
 }
 
 // ---- buffer addressing: a 128-bit descriptor per array in SGPRs, one per-lane byte offset in a VGPR, the row offset in an
@@ -201,7 +271,7 @@ __device__ __forceinline__ S shift_lane(S v, S edge) {
 // SYM: the matrix is symmetric (verified bit for bit by cg_setup_coeffs): N of a cell is S of the cell above, E is W of the cell
 // to the right - only the S and W arrays are streamed (8 instead of 16 coefficient bytes per cell).
 template <typename T, typename CT, int R, int NQ, bool RECON, bool SYM>
-__global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, PersistCtl c, int k_begin, int k_end, int sv) {
+__global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, PersistCtl c, int k_begin, int k_end, int sv, int pend) {
   constexpr int V = 16 / sizeof(T);                        // 16-byte lane accesses
   static_assert(R * NQ <= 16 && 2 * R <= 64, "at most 16 rows per wave; the edge columns of a region fit one wave-wide load");
   __shared__ T xs[kPersistWaves * NQ * R * 64 * V];        // the solution of my regions (128 KB at 16 rows per wave, fp64)
@@ -235,6 +305,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   };
 
   // ---- load the state of the two-kernel path: r and the search direction p of my regions into registers, x into LDS
+  const T alpha0 = pend ? uniform(a.scal[SC_ALPHA]) : (T)0;   // pend: x still lacks alpha p of the iteration before k_begin
   Vec<T, V> rr[NQ][R], pp[NQ][R];
   unsigned vT[NQ], vC[NQ];
   {
@@ -251,14 +322,18 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
         if (has[q]) {
           rr[q][jj] = bld<T, V>(Rr, vT[q], (unsigned)(j0[q] + jj) * rowT);
           pp[q][jj] = bld<T, V>(Rp, vT[q], (unsigned)(j0[q] + jj) * rowT);
-          stv<T, V>(xl + jj * 64 * V, bld<T, V>(Rx, vT[q], (unsigned)(j0[q] + jj) * rowT));
+          // (the two-kernel path defers x += alpha p of its last iteration to the next K1: applied here, on entry)
+          Vec<T, V> xv = bld<T, V>(Rx, vT[q], (unsigned)(j0[q] + jj) * rowT);
+#pragma unroll
+          for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha0, pp[q][jj].v[e], xv.v[e]);
+          stv<T, V>(xl + jj * 64 * V, xv);
         }
       }
     }
   }
   CgState st = a.state[sv & 1];
-  T pz = a.scal[SC_PZ], vs = a.scal[SC_VS], alpha = a.scal[SC_ALPHA];
-  const T sc_c = a.scal[SC_C];
+  T pz = uniform(a.scal[SC_PZ]), vs = uniform(a.scal[SC_VS]), alpha = uniform(a.scal[SC_ALPHA]);
+  const T sc_c = uniform(a.scal[SC_C]);
   // totals of the previous K2 (or previous segment): r.z', sum r, #cells with |r| >= accuracy
   T tB[3];
   {
@@ -277,7 +352,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 3; ++q) tB[q] = smem[q];
+    for (int q = 0; q < 3; ++q) tB[q] = uniform(smem[q]);
     __syncthreads();
   }
 
@@ -286,8 +361,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   // 0 .. D-1 for the next phase, which then travel while the grid exchange leaves the memory system idle).
   constexpr int coef_regs = ((SYM ? 2 : 4) * (int)sizeof(CT) * V + (RECON ? 0 : (int)sizeof(T) * V)) / 4;   // VGPRs of a row in flight
   constexpr int NT = NQ * R;
-  constexpr int Dw = 64 / coef_regs < 2 ? 2 : (64 / coef_regs > kPersistMaxDepth ? kPersistMaxDepth : 64 / coef_regs);
+  constexpr int budget = (NQ == 1 || NT < 16) ? 16 : 8;    // VGPRs for rows in flight (two regions keep twice the halo state)
+  constexpr int Dw = budget / coef_regs < 2 ? 2 : (budget / coef_regs > kPersistMaxDepth ? kPersistMaxDepth : budget / coef_regs);
   constexpr int D = (NT >= Dw) ? Dw : NT;
+  constexpr bool kHybridPoll = NT <= 8;                                // (see grid_exchange: a question of registers)
   constexpr int kBaseLoads = (SYM ? 2 : 4) + (RECON ? 0 : 1);          // vector loads every row issues (some rows one or two more)
   Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT], cSh[NQ];
   Vec<T, V> cD[NT];
@@ -391,25 +468,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
       else st.flag = 1;
     }
     const rsrc_t Rpin = (k & 1) ? Rp1 : Rp0, Rpout = (k & 1) ? Rp0 : Rp1;
-    if (st.done) {                                          // add the last direction to x and leave
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        if (has[q]) {
-          T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
-#pragma unroll
-          for (int jj = 0; jj < R; ++jj) {
-            Vec<T, V> xv = ldv<T, V>(xl + jj * 64 * V);
-#pragma unroll
-            for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha, pp[q][jj].v[e], xv.v[e]);
-            stv<T, V>(xl + jj * 64 * V, xv);
-          }
-        }
-      break;
-    }
-    const T beta = -(tB[0] + vs * tB[1]) / pz;
-    const T alpha_prev = alpha;
+    if (st.done) break;                                    // (x already holds every direction: phase B adds alpha p at once)
+    const T beta = uniform(-(tB[0] + vs * tB[1]) / pz);
 
-    // ---- phase A: x += alpha_prev p_old ; p_new = r + beta p_old (registers) ; z' = L p_new ; sums p, p.r, p.z'
+    // ---- phase A: p_new = r + beta p_old (registers) ; z' = L p_new ; sums p, p.r, p.z'
     T sA[3] = {0, 0, 0};
     if (has[0]) {                                          // the host makes nreg a multiple of NQ: a wave owns NQ regions or none
       // what the neighbours published: the columns next to the strip (all R rows with ONE pair of loads; lanes without a cell
@@ -433,21 +495,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
         haR[q] = bld<T, V, kAgent>(Rr, ha, (unsigned)ja * rowT);
         haP[q] = bld<T, V, kAgent>(Rpin, ha, (unsigned)ja * rowT);
       }
-      // meanwhile, on chip: the axpy of iteration k-1 (:303) and the new direction; its perimeter goes out for iteration k+1
+      // meanwhile, on chip: the new direction; its perimeter goes out for iteration k+1
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
 #pragma unroll
         for (int jj = 0; jj < R; ++jj) {
-          Vec<T, V> xv = ldv<T, V>(xl + jj * 64 * V);
 #pragma unroll
-          for (int e = 0; e < V; ++e) {
-            xv.v[e] = fma(alpha_prev, pp[q][jj].v[e], xv.v[e]);
-            pp[q][jj].v[e] = fma(beta, pp[q][jj].v[e], rr[q][jj].v[e]);
-          }
-          stv<T, V>(xl + jj * 64 * V, xv);
+          for (int e = 0; e < V; ++e) pp[q][jj].v[e] = fma(beta, pp[q][jj].v[e], rr[q][jj].v[e]);
           publish(Rpout, q, jj, pp[q][jj]);
-          if (jj & 1) __builtin_amdgcn_sched_barrier(0);     // two rows of x at a time: bounds the registers of this prelude
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -478,20 +533,25 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     ++epoch;
     tick(0);
     // (every store of this phase was issued before NT rows of coefficient loads: at most D rows may stay in flight)
-    healthy = grid_exchange<T, (D < NT) ? D * kBaseLoads : 0>(c, sA, epoch, smem);
+    healthy = grid_exchange<T, (D < NT) ? D * kBaseLoads : 0, kHybridPoll>(c, sA, epoch, smem);
     tick(1);
     if (!healthy) break;
-    // ---- alpha (:301-302), then phase B: z' again, r -= alpha (z' + vs), sums, publish the perimeter of r
-    vs = sc_c * sA[0];
-    pz = sA[2] + vs * sA[0];
-    alpha = (absval(pz) > 0) ? sA[1] / pz : (T)0;
+    // ---- alpha (:301-302), then phase B: z' again, x += alpha p, r -= alpha (z' + vs), sums, publish the perimeter of r
+    vs = uniform(sc_c * sA[0]);
+    pz = uniform(sA[2] + vs * sA[0]);
+    alpha = uniform((absval(pz) > 0) ? sA[1] / pz : (T)0);
     T sB[3] = {0, 0, 0};
-    const T accuracy = (T)a.accuracy;
+    const T accuracy = uniform((T)a.accuracy);
     if (has[0]) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int q = t / R, jj = t - q * R;
+        T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V + jj * 64 * V;
+        Vec<T, V> xv = ldv<T, V>(xl);                        // x += alpha p (:303); the LDS latency hides under the stencil
         const Vec<T, V> z = zrow(t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha, pp[q][jj].v[e], xv.v[e]);
+        stv<T, V>(xl, xv);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           const T rn = fma(-alpha, z.v[e] + vs, rr[q][jj].v[e]);
@@ -509,10 +569,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     ++epoch;
     tick(2);
     // (the last row's perimeter store is followed by exactly one row of coefficient loads)
-    healthy = grid_exchange<T, (D < NT) ? kBaseLoads : 0>(c, sB, epoch, smem);
+    healthy = grid_exchange<T, (D < NT) ? kBaseLoads : 0, kHybridPoll>(c, sB, epoch, smem);
     tick(3);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) tB[q] = sB[q];
+    for (int q = 0; q < 3; ++q) tB[q] = uniform(sB[q]);
   }
   if (kPersistDiag && c.timing && threadIdx.x == 0) {
 #pragma unroll

@@ -473,6 +473,38 @@ __device__ void exch_v19(const Ctl& c, double (&v)[3], unsigned epoch, double* s
   wg_broadcast(v, smem, epoch);
 }
 
+// ---------------- V21: NW waves poll disjoint slices of the records (sequential rounds inside a wave, sleep 1), one-store publish
+template <int NW>
+__device__ void exch_v21(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sm = smem + (epoch & 1) * 48;
+  for (int q = 0; q < 3; ++q) v[q] = wave_sum(v[q]);
+  if (lane == 0) for (int q = 0; q < 3; ++q) sm[q * kWaves + wave] = v[q];
+  __syncthreads();
+  const int rounds = ((int)gridDim.x + 63) / 64;
+  if (wave < NW) {
+    if (wave == 0) {
+      double s[3];
+      for (int q = 0; q < 3; ++q) { s[q] = 0; for (int w = 0; w < kWaves; ++w) s[q] += sm[q * kWaves + w]; }
+      const int vq = lane >> 1;
+      const u64 bits = __double_as_longlong(vq == 0 ? s[0] : (vq == 1 ? s[1] : s[2]));
+      const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+      if (lane < 6) __hip_atomic_store(c.rec + (size_t)blockIdx.x * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    double tot[3] = {0, 0, 0};
+    for (int m = wave; m < rounds; m += NW) {
+      const int b = m * 64 + lane;
+      double s[3];
+      get_tagged(c.rec + (size_t)(b < (int)gridDim.x ? b : 0) * 8, b < (int)gridDim.x, epoch, s);
+      for (int q = 0; q < 3; ++q) tot[q] += s[q];
+    }
+    for (int q = 0; q < 3; ++q) tot[q] = wave_sum(tot[q]);
+    if (lane == 0) for (int q = 0; q < 3; ++q) sm[24 + q * 4 + wave] = tot[q];
+  }
+  __syncthreads();
+  for (int q = 0; q < 3; ++q) { double t = 0; for (int m = 0; m < NW; ++m) t += sm[24 + q * 4 + m]; v[q] = t; }
+}
+
 // ---------------- V2: two levels of 16 (leader = first workgroup of each group of 16)
 __device__ void exch_v2(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -516,6 +548,8 @@ __global__ __launch_bounds__(kThreads) void bench(Ctl c, int iters, double* out,
     if (VAR == 7) exch_v7<32>(c, v, (unsigned)it, smem);
     if (VAR == 8) exch_v8<4>(c, v, (unsigned)it, smem);
     if (VAR == 15) exch_v15(c, v, (unsigned)it, smem);
+    if (VAR == 21) exch_v21<1>(c, v, (unsigned)it, smem);
+    if (VAR == 22) exch_v21<2>(c, v, (unsigned)it, smem);
     if (VAR == 19) exch_v19<0, 4>(c, v, (unsigned)it, smem);
     if (VAR == 20) exch_v19<16, 4>(c, v, (unsigned)it, smem);
     if (VAR == 16) exch_v16<0>(c, v, (unsigned)it, smem);
@@ -542,7 +576,7 @@ int main(int argc, char** argv) {
   double* out; u64* ticks;
   CK(hipMalloc((void**)&out, kMaxG * 8)); CK(hipMalloc((void**)&ticks, kMaxG * 8));
   const double expect = (double)G * kThreads * 1.0 + (double)G * (kThreads / 4) * 6.0;
-  for (int var = 0; var < 21; ++var) {
+  for (int var = 0; var < 23; ++var) {
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipMemset(c.bar, 0, 256)); CK(hipMemset(c.rec, 0, kMaxG * 64)); CK(hipMemset(c.grp, 0, 16 * 64));
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -557,6 +591,8 @@ int main(int argc, char** argv) {
       if (var == 7) bench<7><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 8) bench<8><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 15) bench<15><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 21) bench<21><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 22) bench<22><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 19) bench<19><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 20) bench<20><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 16) bench<16><<<G, kThreads>>>(c, iters, out, ticks);
