@@ -33,9 +33,10 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X
 K1_BYTES_PER_CELL = 104.0    # K1 covers matrix 5 + SpMV 2 + p update 3 + x update 3 words (it adds the previous direction to x)
 K2_BYTES_PER_CELL = 24.0     # K2 covers the r update: 3 words
 CG_BYTES_PER_CELL_ITER = 128.0   # 16 fp64 words per cell and CG iteration
-# what cg_persist has to move through HBM per cell and iteration (R = 8 rows per region): p read + write 16 B, 4 float
-# off-diagonals 16 B, halo rows of r and p 2/8 * 16 B, perimeter of r written 2/8 * 8 B, edge columns ~0.4 B
-PERSIST_HBM_BYTES_PER_CELL_ITER = 38.4
+# what cg_persist has to move through HBM per cell and iteration (symmetric matrix, one region of 16 rows x 128 columns per
+# wave): the S and W float off-diagonals in each of the two phases 2 * 8 B, perimeters of r and p written 2 * (2/16 + 2/128)
+# * 8 B and read by the neighbours (the same again), extra coefficient row / column per region ~0.6 B
+PERSIST_HBM_BYTES_PER_CELL_ITER = 21.1
 
 
 def turbulence_velocity(n, seed=0, k0=8.0):
@@ -239,15 +240,16 @@ def main():
             streamed = PERSIST_HBM_BYTES_PER_CELL_ITER * ncell * its / (seg_ms * 1e-3) / 1e9
             traffic = tj.get("cg_persist", {}).get("bytes_per_iteration")
             traffic = traffic * its if traffic else None
-            roofline = {"bound": "hbm", "kernel": "cg_persist (one launch = %.0f CG iterations: r, z' in registers, x in LDS, "
-                                                  "p + coefficients streamed, 2 grid exchanges per iteration, fp64)" % its,
+            roofline = {"bound": "hbm", "kernel": "cg_persist (one launch = %.0f CG iterations: r, p in registers, x in LDS, "
+                                                  "coefficients streamed, 2 grid exchanges per iteration, fp64)" % its,
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "avg_launch_ms": seg_ms, "launches_sampled": int(cnt[3]),
                         "iterations_per_launch": its, "us_per_iteration": it_us,
                         "algorithmic_bytes_per_launch": CG_BYTES_PER_CELL_ITER * ncell * its,
                         "note": "algorithmic = SURVEY 8(d): 128 B per cell and iteration (5 matrix words + 11 vector words); the "
-                                "kernel keeps 3 of the 4 vectors on chip, so it only has to stream ~%.0f B per cell and "
-                                "iteration: frac > 1 is traffic avoided, not bandwidth above peak" % PERSIST_HBM_BYTES_PER_CELL_ITER,
+                                "kernel keeps x, r and p on chip and recomputes z, so it only has to stream ~%.0f B per cell and "
+                                "iteration: frac > 1 is traffic avoided, not bandwidth above peak; the iteration is bound by "
+                                "its two grid-wide exchanges and fp64 issue, not by HBM" % PERSIST_HBM_BYTES_PER_CELL_ITER,
                         "streamed_model": {"bytes_per_cell_iteration": PERSIST_HBM_BYTES_PER_CELL_ITER, "achieved": streamed,
                                            "frac": streamed / HBM_PEAK_GBS},
                         "two_kernel_path": {"k1_avg_launch_ms": k1_ms, "k1_achieved": k1_gbs, "k1_launches_sampled": int(cnt[0]),
