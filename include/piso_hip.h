@@ -106,6 +106,11 @@ int piso_laplace_matrix_f32(int nx, int ny, const float* active, const float* fl
  * every 5th iteration with the reference's flag semantics.
  *   laplace [N][5], divergence [N], x_out [N]; iterations_out: host int* (also the reference's `iterations` output)
  * The call returns when the solve has finished (the host must see the convergence flag, as in the reference).
+ * Grids whose rows are a multiple of 128 cells (fp64; 256 for fp32) and that fit the chip run the iterations inside
+ * persistent launches (csrc/cg_persist.h); a grid-wide exchange that times out fails the call with
+ * PISO_ERR_HIP.  Tuning / test knobs (environment, read per call): PISO_CG_PERSIST=0|1 (forbid / force the persistent
+ * kernel), PISO_CG_PERSIST_R=2|4|8|16 (rows per region), PISO_CG_SEGMENT=n (iterations per launch), PISO_CG_NO_SYM,
+ * PISO_CG_NO_RECON, PISO_CG_NO_COMPACT (disable the symmetric / recomputed-diagonal / float32 coefficient fast paths).
  * ------------------------------------------------------------------------------------------------------------- */
 size_t piso_cg_workspace_bytes(int nx, int ny, int elem_size);
 
@@ -117,8 +122,9 @@ int piso_cg_solve_f32(int nx, int ny, int periodic_x, int periodic_y, const floa
                       int* iterations_out, void* workspace, size_t workspace_bytes, piso_stream_t stream);
 
 /* Fixed-work variant for bandwidth measurements: runs exactly `iterations` CG iterations (no convergence test),
- * optionally timing the K1 (fused p-update + stencil + dots) and K2 (x/r update + dots) kernels with HIP events on
- * `stream`; kernel_ms_out: host float[2] = average ms per launch of K1, K2 (NULL to skip). */
+ * optionally timing the kernels with HIP events on `stream`; kernel_ms_out (NULL to skip): host float[2] = average ms per
+ * launch of K1 (fused p-update + stencil + dots) and K2 (x/r update + dots), or, when the iterations ran inside persistent
+ * launches, {average ms per ITERATION, 0}. */
 int piso_cg_fixed_iterations_f64(int nx, int ny, int periodic_x, int periodic_y, const double* laplace,
                                  const double* divergence, double* x_out, int rank_deficient, int iterations,
                                  float* kernel_ms_out, void* workspace, size_t workspace_bytes, piso_stream_t stream);
