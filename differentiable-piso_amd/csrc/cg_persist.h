@@ -371,6 +371,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   CT eW[NQ];
   auto issue_coef = [&](int t) __attribute__((always_inline)) {
     const int q = t / R, jj = t - q * R;
+#if defined(PISO_ABLATE) && PISO_ABLATE == 4
+    { for (int e = 0; e < V; ++e) { cS[t].v[e] = (CT)1; cW[t].v[e] = (CT)1; cE[t].v[e] = (CT)1; cN[t].v[e] = (CT)1; cD[t].v[e] = (T)-4; }
+      if (jj == 0) eW[q] = (CT)1; if (jj == R - 1) for (int e = 0; e < V; ++e) cSh[q].v[e] = (CT)1; return; }
+#endif
     const unsigned sT = (unsigned)(j0[q] + jj) * rowT, sC = (unsigned)(j0[q] + jj) * rowC;
     cS[t] = bld<CT, V>(RoS, vC[q], sC); cW[t] = bld<CT, V>(RoW, vC[q], sC);
     if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vC[q], sC); cN[t] = bld<CT, V>(RoN, vC[q], sC); }
@@ -399,6 +403,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   // both call this on the same registers, so they see bitwise the same z'.
   auto zrow = [&](int t) __attribute__((always_inline)) -> Vec<T, V> {
     const int q = t / R, jj = t - q * R;
+#if defined(PISO_ABLATE) && PISO_ABLATE == 3
+    { Vec<T, V> z0; for (int e = 0; e < V; ++e) z0.v[e] = pp[q][jj].v[e] * (T)cS[t].v[e]; return z0; }
+#endif
     const Vec<T, V> behind = (jj > 0) ? pp[q][jj > 0 ? jj - 1 : 0] : pnb[q];
     const Vec<T, V> cur = pp[q][jj];
     const Vec<T, V> ahead = (jj + 1 < R) ? pp[q][jj + 1 < R ? jj + 1 : jj] : pna[q];
@@ -440,6 +447,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   };
   // perimeter of row jj of region q (what neighbouring regions read): the whole first / last row, else the two end cells
   auto publish = [&](rsrc_t Rd, int q, int jj, const Vec<T, V>& val) __attribute__((always_inline)) {
+#if defined(PISO_ABLATE) && PISO_ABLATE == 1
+    return;
+#endif
     const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
     if (jj == 0 || jj == R - 1) {
       bst<T, V, kAgent>(Rd, vT[q], sT, val);
@@ -485,6 +495,12 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
         if (cc < 0) cc = a.per_x ? nx - 1 : -1;
         else if (cc >= nx) cc = a.per_x ? 0 : -1;
         const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
+#if defined(PISO_ABLATE) && PISO_ABLATE == 2
+        eP[q] = 0; eR[q] = 0;
+        for (int e = 0; e < V; ++e) { hbR[q].v[e] = 0; hbP[q].v[e] = 0; haR[q].v[e] = 0; haP[q].v[e] = 0; }
+        (void)vo;
+        continue;
+#endif
         eP[q] = bld1<T, kAgent>(Rpin, vo, 0);
         eR[q] = bld1<T, kAgent>(Rr, vo, 0);
         bool vb, va;

@@ -117,3 +117,40 @@ def test_unrolled_adjoint_matches_oracle(name, steps, cut):
         assert max(e) < 2 * TOL, e
     else:
         assert vel_t.grad is None or float(vel_t.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name,shape", [("periodic", (32, 128)), ("xper_ywall", (32, 128))])
+def test_unrolled_16_steps_adjoint_through_persistent_cg(name, shape, monkeypatch):
+    """The north star's bar itself: forward + 16-step unrolled adjoint within 1e-5 relative L2 of the reference algorithm,
+    with every pressure solve (forward and adjoint) running inside the persistent CG kernel that the 2048^2 benchmark uses
+    (forced here: the grid is small)."""
+    import ctypes as C
+    import diffpiso as dp
+    from diffpiso import _native as N
+    monkeypatch.setenv("PISO_CG_PERSIST", "1")
+    steps = 16
+    c = make_case(name, shape[0], shape[1], seed=8)
+    kw = dict(SOLVER, lin_double=True, lin_tol=1e-10)
+    s = oracle_setup(c, **kw)
+    P = product_setup(c, **kw)
+    vels, ps, tapes = R.run_steps(s, c["vel"], c["p"], c["dt"], c["dirichlet_values"], steps)
+    vel_t = P["vel_tensor"].clone().requires_grad_(True)
+    velocity = dp.StaggeredGrid(vel_t, P["velocity"].box, extrapolation=P["velocity"].extrapolation)
+    p_t = P["pressure"].data.clone().requires_grad_(True)
+    pressure = dp.CenteredGrid(p_t, P["pressure"].box, P["pressure"].extrapolation)
+    N.lib.piso_cg_profile_enable(1, 8)
+    try:
+        va, pa, vn, pn, warn = dp.run_piso_steps(velocity, pressure, c["dt"], P["sim"], step_count=steps)
+        e_f = (rel(vn.staggered_tensor().detach().cpu().numpy(), vels[-1]), rel(pn.data[0, :, :, 0].detach().cpu().numpy(), ps[-1]))
+        loss = 0.5 * (vn.staggered_tensor() ** 2).sum()
+        loss.backward()
+        ms, cnt = (C.c_double * 4)(), (C.c_longlong * 4)()
+        N.lib.piso_cg_profile_read(ms, cnt)
+    finally:
+        N.lib.piso_cg_profile_enable(0, 8)
+    assert cnt[2] > 100 * steps, "the pressure solves did not run in the persistent kernel"
+    d_vel, d_p, _ = R.run_steps_backward(s, tapes, vels[-1], np.zeros_like(ps[-1]))
+    e_b = (rel(vel_t.grad.cpu().numpy(), d_vel), rel(p_t.grad[0, :, :, 0].cpu().numpy(), d_p))
+    print("16-step unroll rel-L2 fields (u, p):", e_f, " gradients (d_vel, d_p):", e_b)
+    assert max(e_f) < TOL, e_f
+    assert max(e_b) < 2 * TOL, e_b
