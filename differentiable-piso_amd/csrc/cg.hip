@@ -251,8 +251,8 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     std::vector<unsigned long long> h(12 * persist_grid);
     PISO_HIP_CHECK(hipMemcpy(h.data(), pc.timing, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     PISO_HIP_CHECK(hipFree(pc.timing));
-    const char* names[4] = {"phaseA", "barrierA", "phaseB", "barrierB"};
-    for (int q = 0; q < 4; ++q) {
+    const char* names[5] = {"phaseA", "barrierA", "phaseB", "barrierB", "(halo loads alone, ablation 5)"};
+    for (int q = 0; q < 5; ++q) {
       double s = 0, mn = 1e300, mx = 0;
       for (int b = 0; b < persist_grid; ++b) { const double v = (double)h[q * persist_grid + b]; s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
       fprintf(stderr, "cg_persist %s: avg %.2f us/iter  min %.2f  max %.2f\n", names[q], 0.01 * s / persist_grid / (double)(k_last > 0 ? k_last : 1),

@@ -14,6 +14,27 @@
 #pragma once
 #include "cg_kernels.h"
 
+// scheduling fences of the two row loops (experiments: -DPISO_SB_MODE=0 none, 1 only around the refill loads, 2 default)
+#ifndef PISO_SB_MODE
+#define PISO_SB_MODE 2
+#endif
+#if PISO_SB_MODE == 2
+#define PISO_SB_A1 __builtin_amdgcn_sched_barrier(0)
+#define PISO_SB_A2 __builtin_amdgcn_sched_barrier(0)
+#define PISO_SB_B1 __builtin_amdgcn_sched_barrier(0)
+#define PISO_SB_B2 __builtin_amdgcn_sched_barrier(0)
+#elif PISO_SB_MODE == 1
+#define PISO_SB_A1 __builtin_amdgcn_sched_barrier(0)
+#define PISO_SB_A2 (void)0
+#define PISO_SB_B1 __builtin_amdgcn_sched_barrier(0)
+#define PISO_SB_B2 (void)0
+#else
+#define PISO_SB_A1 (void)0
+#define PISO_SB_A2 (void)0
+#define PISO_SB_B1 (void)0
+#define PISO_SB_B2 (void)0
+#endif
+
 namespace piso {
 
 constexpr int kPersistThreads = 512;            // 8 waves per CU = 2 per SIMD -> 256 VGPRs per lane: state in registers without spills
@@ -84,6 +105,9 @@ __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], un
       const int vq = lane >> 1;
       const u64 bits = (u64)__double_as_longlong((double)(vq == 0 ? s[0] : (vq == 1 ? s[1] : s[2])));
       const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+#ifdef PISO_PERSIST_FENCE
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // experiment: explicit L2 write-back before publishing
+#endif
       if (lane < 6) __hip_atomic_store(rec + (size_t)blockIdx.x * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // Lane l owns records l, l + 64, ...  Arrivals cluster: once a lane's first record is there, the others almost always
@@ -466,7 +490,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   unsigned epoch = 0;
   bool healthy = true;
   int k = k_begin;
-  unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = (kPersistDiag && c.timing) ? wall_clock64() : 0;
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = (kPersistDiag && c.timing) ? wall_clock64() : 0;
   auto tick = [&](int slot) __attribute__((always_inline)) {
     if (kPersistDiag && c.timing) { const unsigned long long t = wall_clock64(); tacc[slot] += t - tlast; tlast = t; }   // (scalar registers only)
   };
@@ -511,6 +535,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
         haR[q] = bld<T, V, kAgent>(Rr, ha, (unsigned)ja * rowT);
         haP[q] = bld<T, V, kAgent>(Rpin, ha, (unsigned)ja * rowT);
       }
+#if defined(PISO_ABLATE) && PISO_ABLATE == 5
+      __builtin_amdgcn_s_waitcnt(0);                       // timing experiment: how long do the halo loads alone take?
+      tick(4);
+#endif
       // meanwhile, on chip: the new direction; its perimeter goes out for iteration k+1
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -541,9 +569,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
           sA[1] = fma(pp[q][jj].v[e], rr[q][jj].v[e], sA[1]);
           sA[2] = fma(pp[q][jj].v[e], z.v[e], sA[2]);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        PISO_SB_A1;
         if constexpr (D < NT) issue_coef(t + D < NT ? t + D : t + D - NT);   // wraps: rows 0 .. D-1 again, for phase B
-        __builtin_amdgcn_sched_barrier(0);
+        PISO_SB_A2;
       }
     }
     ++epoch;
@@ -577,9 +605,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
           sB[2] += (absval(rn) < accuracy) ? (T)0 : (T)1;
         }
         publish(Rr, q, jj, rr[q][jj]);
-        __builtin_amdgcn_sched_barrier(0);
+        PISO_SB_B1;
         if constexpr (D < NT) issue_coef(t + D < NT ? t + D : t + D - NT);   // wraps: rows 0 .. D-1 for phase A of the next iteration
-        __builtin_amdgcn_sched_barrier(0);
+        PISO_SB_B2;
       }
     }
     ++epoch;
@@ -592,7 +620,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   }
   if (kPersistDiag && c.timing && threadIdx.x == 0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) c.timing[q * gridDim.x + blockIdx.x] += tacc[q];
+    for (int q = 0; q < 5; ++q) c.timing[q * gridDim.x + blockIdx.x] += tacc[q];
   }
 
   // ---- back to the global-memory state of the two-kernel path (iteration k reads its direction from p[k & 1])

@@ -18,6 +18,41 @@ def problem():
     return bench.build_problem(N, torch.device("cuda"), 1e-6, 10000, 1000)
 
 
+@pytest.mark.parametrize("walls", [False, True])
+def test_persistent_cg_equals_two_kernel_path_2048(walls, monkeypatch):
+    """The persistent kernel at the benchmark size (all 256 CUs, 2048 regions exchanging perimeters and partial sums across
+    the 8 XCDs) against the two-kernel iteration: same arithmetic per cell, only the summation order of the dot products
+    differs, so after 150 iterations the iterates agree to round-off.  One stale halo cell or one torn exchange record would
+    show up at the 1e-3 level.  Repeated to catch timing-dependent failures."""
+    from diffpiso.solvers import cg_solve_native, laplace_matrix_native
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu")
+    g.manual_seed(11)
+    a0 = 0.5 + torch.rand(N * (N + 1) + (N + 1) * N, generator=g)
+    a0v = a0[:N * (N + 1)].view(N + 1, N)
+    a0u = a0[N * (N + 1):].view(N, N + 1)
+    a0v[N] = a0v[0]
+    a0u[:, N] = a0u[:, 0]
+    a0 = a0.to(dev)
+    act = torch.ones((N + 2, N + 2))
+    if walls:                                              # closed box: the ghost frame is solid (non-periodic halo paths)
+        act[0, :] = 0; act[-1, :] = 0; act[:, 0] = 0; act[:, -1] = 0
+    act = act.reshape(-1).to(dev)
+    L = laplace_matrix_native(N, N, act, act, a0, torch.float64)
+    b = torch.randn(N * N, generator=g, dtype=torch.float64).to(dev)
+    b -= b.mean()
+    per = not walls
+    monkeypatch.setenv("PISO_CG_PERSIST", "0")
+    xa, ita = cg_solve_native(N, N, per, per, L, b, 1e-30, 150, False, 1000)
+    monkeypatch.setenv("PISO_CG_PERSIST", "1")
+    monkeypatch.setenv("PISO_CG_SEGMENT", "40")
+    scale = float(xa.abs().max())
+    for rep in range(4):
+        xb, itb = cg_solve_native(N, N, per, per, L, b, 1e-30, 150, False, 1000)
+        assert ita == itb == 150
+        assert float((xa - xb).abs().max()) <= 1e-10 * scale, rep
+
+
 def test_cg_manufactured_solution_2048():
     """b = (L + c 11^T) x_true  ->  the solver must return x_true (the shift pins the mean)."""
     from diffpiso.solvers import cg_solve_native, laplace_matrix_native
