@@ -1,0 +1,85 @@
+"""Golden fixtures for the "next" rows of SURVEY.md 8(f): LES strain / Smagorinsky viscosity (diffpiso/LES_models.py), the
+numpy energy spectrum (diffpiso/evaluation_tools.py:92-113) and the staggered pieces the losses are built from
+(PhiFlow: StaggeredGrid(tensor), at_centers, math.gradient 'forward').  Same machinery as make_golden.py: the reference's own
+Python on PhiFlow's numpy backend; only inputs and outputs are stored.  The TensorFlow arithmetic of diffpiso/losses.py and
+EK_spectrum_2D_tf cannot run here (no TensorFlow): those are restated in oracle/eval_ref.py and marked "parity unpinned".
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_eval.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as G          # sets up the PhiFlow numpy backend, the tf decorator shim and loads piso_helpers as G.H
+
+pf, REF = G.pf, G.REF
+
+
+def _load_ref_module(fname, modname, extra=None):
+    """Execute a reference module file with its relative import of piso_helpers satisfied by the already loaded G.H."""
+    pkg = types.ModuleType("refpkg")
+    pkg.__path__ = []
+    sys.modules["refpkg"] = pkg
+    sys.modules["refpkg.piso_helpers"] = G.H
+    for k, v in (extra or {}).items():
+        sys.modules[k] = v
+    spec = importlib.util.spec_from_file_location("refpkg." + modname, os.path.join(REF, "diffpiso", fname))
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = "refpkg"
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    rng = np.random.default_rng(20240611)
+    LES = _load_ref_module("LES_models.py", "LES_models")
+    # evaluation_tools imports matplotlib.pyplot (present) and tensorflow (the decorator shim; only numpy functions are called)
+    import matplotlib
+    matplotlib.use("Agg")
+    EV = _load_ref_module("evaluation_tools.py", "evaluation_tools")
+    out = {}
+    for name in ("periodic", "xper_ywall", "spatial_ml", "closed"):
+        res, size, boundaries = G.CASES[name]
+        res = (res[0] + 3, res[1] + 2)                      # a little larger than the helper cases
+        size = (size[0] / G.CASES[name][0][0] * res[0], size[0] / G.CASES[name][0][0] * res[1])   # square cells (LES uses dx[0])
+        domain = pf.Domain(list(res), boundaries=boundaries, box=pf.box[0:size[0], 0:size[1]])
+        ny, nx = res
+        vel_t = rng.standard_normal((1, ny + 1, nx + 1, 2)).astype(np.float32)
+        vel = pf.StaggeredGrid.sample(vel_t, domain=domain)
+        out[name + "/resolution"] = np.array(res)
+        out[name + "/box"] = np.array(size, np.float64)
+        out[name + "/vel_in"] = vel_t
+        out[name + "/velocity_extrapolation"] = G._ext_to_obj(vel.extrapolation)
+        st = LES.strain_tensor(vel)
+        for i, s in enumerate(st):
+            out[name + "/strain_%d" % i] = np.asarray(s)
+        sc = LES.strain_tensor_centered(vel)
+        for i, s in enumerate(sc):
+            out[name + "/strain_centered_%d" % i] = np.asarray(s)
+        out[name + "/smagorinsky_0p17"] = np.asarray(LES.smagorinsky_eddy_viscosity(vel, 0.17))
+        out[name + "/vorticity"] = np.asarray(G.H.vorticity(vel))
+        # pieces of losses.py evaluated by PhiFlow: StaggeredGrid(tensor) round trip, at_centers, forward gradients of the
+        # component arrays (strain_rate_loss :69-74)
+        sg = pf.StaggeredGrid(vel_t)
+        out[name + "/default_grid_staggered_tensor"] = np.asarray(sg.staggered_tensor())
+        out[name + "/default_grid_at_centers"] = np.asarray(sg.at_centers().data)
+        for i in range(2):
+            out[name + "/fwd_gradient_comp%d" % i] = np.asarray(pf.math.gradient(vel.data[i].data, vel.dx, "forward"))
+    # numpy energy spectrum of evaluation_tools.py:92-113 on square and non-square centred fields
+    for tag, shape in (("sq", (16, 16)), ("rect", (12, 20))):
+        vc = rng.standard_normal(shape + (2,))
+        k, e = EV.EK_spectrum_2D(vc, None)
+        out["spectrum_%s/velocity_centered" % tag] = vc
+        out["spectrum_%s/wavenumbers" % tag] = np.asarray(k, np.float64)
+        out["spectrum_%s/energy" % tag] = np.asarray(e, np.float64)
+    np.savez_compressed(os.path.join(HERE, "eval_les.npz"), **out)
+    print("wrote eval_les.npz with", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+"""SURVEY.md 8(f) rows 2-4 on the CPU: LES strain / Smagorinsky viscosity and the numpy energy spectrum against fixtures
+generated from the reference's own Python (tests/golden/eval_les.npz, make_golden_eval.py); the differentiable spectrum and
+the four training losses against the loop-style numpy restatement in oracle/eval_ref.py (TensorFlow arithmetic: parity
+unpinned, see its header) and against the pinned numpy spectrum where the two must coincide; frame-file round trip."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import diffpiso as dp
+from oracle import eval_ref as E
+
+CASES = ["periodic", "xper_ywall", "spatial_ml", "closed"]
+TOL = dict(rtol=3e-6, atol=3e-6)
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "eval_les.npz"))
+
+
+def _grid(gold, name):
+    ny, nx = gold[name + "/resolution"]
+    ly, lx = gold[name + "/box"]
+    ext = ast.literal_eval(str(gold[name + "/velocity_extrapolation"]))
+    return dp.StaggeredGrid(torch.tensor(gold[name + "/vel_in"]), dp.box[0:ly, 0:lx], extrapolation=ext)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_les_strain_and_smagorinsky_against_reference_golden(gold, name):
+    vel = _grid(gold, name)
+    for i, s in enumerate(dp.strain_tensor(vel)):
+        np.testing.assert_allclose(s.numpy(), gold[name + "/strain_%d" % i], **TOL)
+    for i, s in enumerate(dp.strain_tensor_centered(vel)):
+        np.testing.assert_allclose(s.numpy(), gold[name + "/strain_centered_%d" % i], **TOL)
+    np.testing.assert_allclose(dp.smagorinsky_eddy_viscosity(vel, 0.17).numpy(), gold[name + "/smagorinsky_0p17"], **TOL)
+    np.testing.assert_allclose(dp.vorticity(vel).numpy(), gold[name + "/vorticity"], **TOL)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_loss_building_blocks_against_reference_golden(gold, name):
+    """What losses.py does through PhiFlow: StaggeredGrid(tensor) with default box / extrapolation, at_centers, forward
+    gradients of the component arrays -- and the oracle's own restatement of the same pieces."""
+    from diffpiso.les import forward_gradient
+    t = torch.tensor(gold[name + "/vel_in"])
+    sg = dp.StaggeredGrid(t)
+    np.testing.assert_allclose(sg.staggered_tensor().numpy(), gold[name + "/default_grid_staggered_tensor"], **TOL)
+    np.testing.assert_allclose(sg.at_centers().data.numpy(), gold[name + "/default_grid_at_centers"], **TOL)
+    np.testing.assert_allclose(E.staggered_tensor(gold[name + "/vel_in"]), gold[name + "/default_grid_staggered_tensor"], **TOL)
+    np.testing.assert_allclose(E.at_centers(gold[name + "/vel_in"]), gold[name + "/default_grid_at_centers"], **TOL)
+    vel = _grid(gold, name)
+    for i in range(2):
+        ref = gold[name + "/fwd_gradient_comp%d" % i]
+        np.testing.assert_allclose(forward_gradient(vel.data[i].data, vel.dx).numpy(), ref, **TOL)
+        np.testing.assert_allclose(E._fwd(E.split_staggered(gold[name + "/vel_in"])[i].astype(np.float64), vel.dx), ref, **TOL)
+
+
+@pytest.mark.parametrize("tag", ["sq", "rect"])
+def test_energy_spectra(gold, tag):
+    vc = gold["spectrum_%s/velocity_centered" % tag]
+    k, e = dp.EK_spectrum_2D(vc, None)
+    np.testing.assert_allclose(k, gold["spectrum_%s/wavenumbers" % tag])
+    np.testing.assert_allclose(e, gold["spectrum_%s/energy" % tag], rtol=1e-10, atol=1e-18)
+    # the differentiable (TF) version: equals the pinned numpy spectrum on even-sized domains (up to its cutoff), and the
+    # loop restatement everywhere
+    et = dp.EK_spectrum_2D_tf(torch.tensor(vc)).numpy()
+    n = min(len(et), len(e))
+    np.testing.assert_allclose(et[:n], e[:n], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(et, E.spectrum_2d_tf(vc), rtol=1e-9, atol=1e-15)
+    odd = np.random.default_rng(0).standard_normal((9, 13, 2))
+    np.testing.assert_allclose(dp.EK_spectrum_2D_tf(torch.tensor(odd)).numpy(), E.spectrum_2d_tf(odd), rtol=1e-9, atol=1e-15)
+    e1 = dp.EK_spectrum_1D_tf(torch.tensor(vc), 1).numpy()
+    ref1 = (np.abs(np.fft.fft(vc[..., 1], axis=1)) ** 2 + np.abs(np.fft.fft(vc[..., 0], axis=1)) ** 2).sum(0)[:vc.shape[1] // 2 + 1]
+    np.testing.assert_allclose(e1, ref1, rtol=1e-9)
+
+
+def _sequences(ny=12, nx=16, steps=5, seed=3):
+    rng = np.random.default_rng(seed)
+    gt = rng.standard_normal((1, steps, ny + 1, nx + 1, 2)).astype(np.float32)
+    pred = [(gt[:, s] + 0.3 * rng.standard_normal((1, ny + 1, nx + 1, 2))).astype(np.float32) for s in range(steps)]
+    box = dp.box[0:ny * 0.5, 0:nx * 0.25]
+    leaves = [torch.tensor(p, dtype=torch.float64).requires_grad_(True) for p in pred]
+    grids = [dp.StaggeredGrid(t, box, extrapolation="periodic") for t in leaves]
+    return gt, pred, grids, leaves
+
+
+def test_losses_against_numpy_restatement():
+    gt, pred, grids, leaves = _sequences()
+    gtt = torch.tensor(gt, dtype=torch.float64)
+    steps, bw = len(pred), [[1, 2], [2, 1]]
+    lf = [0.5 + 0.1 * s for s in range(steps)]
+    zero = torch.zeros((), dtype=torch.float64)
+    tot, c = dp.L2_field_loss(zero, [grids], [gtt], steps, bw, lf, 0)
+    assert float(c) == pytest.approx(E.l2_field_loss([pred], [gt], [0, steps], bw, lf, 0), rel=3e-6)
+    tot, c = dp.L2_field_loss(zero + 2.0, [grids], [gtt], [1, 4], None, 0.7, 0)
+    assert float(c) == pytest.approx(E.l2_field_loss([pred], [gt], [1, 4], None, [0.7] * 4, 0), rel=3e-6) and float(tot) == pytest.approx(float(c) + 2.0)
+    for log_distance in (True, False):
+        tot, c = dp.spectral_energy_loss(zero, [grids], [gtt], steps, [[0, 0], [0, 0]], 1.5, 0, log_distance=log_distance, start_wavenumber=1)
+        ref = E.spectral_energy_loss([pred], [gt], [0, steps], [[0, 0], [0, 0]], [1.5] * steps, 0, log_distance, 1)
+        assert float(c) == pytest.approx(ref, rel=3e-5)
+    tot, c = dp.strain_rate_loss(zero, [grids], [gtt], steps, None, 2.0)
+    assert float(c) == pytest.approx(E.strain_rate_loss([pred], [gt], [0, steps], [2.0] * steps, (0.5, 0.25)), rel=3e-6)
+    for window in (None, 3, 2):
+        tot, c = dp.multistep_averaging_loss(zero, [grids], [gtt], steps, bw, 1.3, loss_influence_range=window)
+        assert float(c) == pytest.approx(E.multistep_averaging_loss([pred], [gt], [0, steps], bw, 1.3, window), rel=3e-6)
+    # per-step mode: lists of the right length, consistent with the summed mode
+    per, groups = dp.L2_field_loss([zero] * steps, [grids], [gtt], steps, bw, lf, 0, sum_steps=False, loss_influence_range=2)
+    assert len(per) == steps and len(groups) == 3
+    assert float(sum(groups)) == pytest.approx(E.l2_field_loss([pred], [gt], [0, steps], bw, lf, 0), rel=3e-6)
+    # the losses are differentiable down to the staggered tensors of the predicted fields
+    tot, _ = dp.spectral_energy_loss(zero, [grids], [gtt], steps, [[0, 0], [0, 0]], 1.0, 0)
+    tot2, _ = dp.strain_rate_loss(tot, [grids], [gtt], steps, None, 1.0)
+    tot3, _ = dp.multistep_averaging_loss(tot2, [grids], [gtt], steps, bw, 1.0, loss_influence_range=3)
+    tot4, _ = dp.L2_field_loss(tot3, [grids], [gtt], steps, bw, lf, 0)
+    tot4.backward()
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() and float(t.grad.abs().sum()) > 0 for t in leaves)
+
+
+def test_frame_files_round_trip(tmp_path):
+    base = dp.create_base_dir(str(tmp_path) + "/", "run_")
+    assert base.endswith("run_000000") and os.path.isdir(base)
+    assert dp.create_base_dir(str(tmp_path) + "/", "run_").endswith("run_000001")
+    rng = np.random.default_rng(1)
+    frames = [rng.standard_normal((1, 5, 6, 2)).astype(np.float32) for _ in range(6)]
+    for i, f in enumerate(frames):
+        dp.save_frame(base + "/", "velocity", i, f)
+        dp.save_frame(base + "/", "pressure", i, f[..., :1])
+    lists = dp.data_path_assembler([base + "/"], ["velocity", "pressure"], [7.5], [0], [6], [2])
+    assert len(lists) == 3 and len(lists[0]) == 4 and lists[0][1][2].endswith("velocity_000003.npz")
+    vel, prs, ch = dp.load_function(lists[0][1], lists[1][1], lists[2][1])
+    assert vel.shape == (1, 3, 5, 6, 2) and prs.shape == (1, 3, 5, 6, 1) and ch.shape == (1,) and ch[0] == 7.5
+    np.testing.assert_array_equal(vel[:, 2], frames[3])
+    batches = list(dp.make_dataset(lists, batch_size=3, shuffle=True, seed=0))
+    assert [b[0].shape[0] for b in batches] == [3, 1]
