@@ -24,7 +24,8 @@ from .datamanagement import create_base_dir, data_path_assembler, load_function,
 from .evaluation_tools import EK_spectrum_1D_tf, EK_spectrum_2D, EK_spectrum_2D_tf, tf_fftshift
 from .les import smagorinsky_eddy_viscosity, strain_tensor, strain_tensor_centered
 from .losses import L2_field_loss, multistep_averaging_loss, spectral_energy_loss, strain_rate_loss
-from .setups import compute_mixingLayer_masks, update_dirichlet_values
+from .setups import (compute_mixingLayer_masks, spatialMixingLayer_setup, sponge_viscosity_field, temporal_mixing_layer_masks,
+                     update_dirichlet_values)
 from .unroll import run_piso_steps, zero_gradient_op
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -83,3 +83,41 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def main_setups():
+    """temporal_mixing_layer_masks (piso_helpers.py:136-166) and the sponge-layer viscosity field of spatialMixingLayer_setup
+    (combined_training_integrated.py:525-532: CenteredGrid(viscosity).at(velocity) flattened u-first)."""
+    rng = np.random.default_rng(99)
+    out = {}
+    ny, nx = 6, 9
+    st_shape = (1, ny + 1, nx + 1, 2)
+    lo = rng.standard_normal((1, 1, nx + 2, 1)).astype(np.float32)
+    hi = rng.standard_normal((1, 1, nx + 2, 1)).astype(np.float32)
+    np.bool = bool                                          # the reference predates numpy 1.24 (scipy is already imported)
+    try:
+        m, v, bb, act, acc = G.H.temporal_mixing_layer_masks(st_shape, ((True, True), (False, False)), ((lo, hi), (None, None)))
+    finally:
+        del np.bool
+    out["tml/staggered_shape"] = np.array(st_shape)
+    out["tml/bc_lower"], out["tml/bc_upper"] = lo, hi
+    out["tml/dirichlet_mask"], out["tml/dirichlet_values"] = np.asarray(m), np.asarray(v)
+    out["tml/boundary_bool_x"], out["tml/boundary_bool_y"] = np.asarray(bb[0]), np.asarray(bb[1])
+    out["tml/active_mask"], out["tml/accessible_mask"] = np.asarray(act), np.asarray(acc)
+    # sponge viscosity: the lines of the reference's set-up that go through PhiFlow, on a small domain
+    res, box = (8, 12), (4.0, 6.0)
+    domain = pf.Domain(list(res), box=pf.box[0:box[0], 0:box[1]], boundaries=((pf.OPEN, pf.OPEN), (pf.OPEN, pf.CLOSED)))
+    velocity = pf.StaggeredGrid.sample(np.zeros((1, res[0] + 1, res[1] + 1, 2), np.float32), domain=domain)
+    nu, sponge_start, sponge_max = 1e-3, 7, 0.05
+    visc = np.ones((1, res[0], res[1], 1)) * nu
+    visc[:, :, sponge_start:, :] += np.expand_dims(np.matmul(np.ones((res[0], 1)), np.expand_dims(np.linspace(0, sponge_max, res[1] - sponge_start), 0)), (0, -1))
+    flat = G.H.flatten_staggered_data(pf.CenteredGrid(visc, domain.box).at(velocity), coord_flip=True)
+    out["sponge/resolution"], out["sponge/box"] = np.array(res), np.array(box)
+    out["sponge/params"] = np.array([nu, sponge_start, sponge_max])
+    out["sponge/viscosity_flat_ufirst"] = np.asarray(flat)
+    np.savez_compressed(os.path.join(HERE, "setups_extra.npz"), **out)
+    print("wrote setups_extra.npz with", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main_setups()

@@ -134,3 +134,37 @@ def test_frame_files_round_trip(tmp_path):
     np.testing.assert_array_equal(vel[:, 2], frames[3])
     batches = list(dp.make_dataset(lists, batch_size=3, shuffle=True, seed=0))
     assert [b[0].shape[0] for b in batches] == [3, 1]
+
+
+def test_temporal_mixing_layer_masks_and_sponge_viscosity_against_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "setups_extra.npz"))
+    m, v, bb, act, acc = dp.temporal_mixing_layer_masks(tuple(g["tml/staggered_shape"]), ((True, True), (False, False)),
+                                                        ((g["tml/bc_lower"], g["tml/bc_upper"]), (None, None)))
+    np.testing.assert_array_equal(m, g["tml/dirichlet_mask"])
+    np.testing.assert_array_equal(v, g["tml/dirichlet_values"])
+    np.testing.assert_array_equal(bb[0], g["tml/boundary_bool_x"])
+    np.testing.assert_array_equal(bb[1], g["tml/boundary_bool_y"])
+    np.testing.assert_array_equal(act, g["tml/active_mask"])
+    np.testing.assert_array_equal(acc, g["tml/accessible_mask"])
+    nu, start, smax = g["sponge/params"]
+    flat = dp.sponge_viscosity_field(g["sponge/resolution"], nu, int(start), smax)
+    np.testing.assert_allclose(flat, g["sponge/viscosity_flat_ufirst"], rtol=1e-6, atol=1e-9)
+
+
+def test_spatial_mixing_layer_setup_objects():
+    """combined_training_integrated.py:481-539: shapes, masks and the inlet profile of the set-up the training scripts use."""
+    sim = dict(HRres=[32, 96], dx_ratio=2, box=dp.box[0:8, 0:24], sponge_ratio=0.75, relative_sponge_max=20.0)
+    phys = dict(average_velocity=1.0, velocity_difference=0.8, inlet_profile_sharpness=2.0, viscosity=2e-3)
+    domain, sp, ps, vel, prs, visc, bcx = dp.spatialMixingLayer_setup(sim, 1e-6, phys, step_count=4, device="cpu")
+    ny, nx = 16, 48
+    assert list(domain.resolution) == [ny, nx] and vel.staggered_tensor().shape == (1, ny + 1, nx + 1, 2)
+    assert prs.data.shape == (1, ny, nx, 1) and visc.shape == ((nx + 1) * ny + nx * (ny + 1),)
+    assert bcx.shape == (1, ny + 2, 1, 1)
+    assert bcx[0, 0, 0, 0] == pytest.approx(1.0 - 0.4 * np.tanh(2.0 * 4.0), rel=1e-6) and bcx[0, -1, 0, 0] == pytest.approx(1.0 + 0.4 * np.tanh(8.0), rel=1e-6)
+    dm, dv = np.asarray(sp.dirichlet_mask), np.asarray(sp.dirichlet_values)
+    assert dm.dtype == bool and dm[0, :ny, 0, 1].all() and not dm[0, :ny, nx, 1].any()       # inflow Dirichlet, outflow free
+    np.testing.assert_allclose(dv[0, :ny, 0, 1], bcx[0, 1:-1, 0, 0])
+    assert dm[0, 0, :nx, 0].all() and dm[0, ny, :nx, 0].all() and float(np.abs(dv[..., 0]).max()) == 0.0
+    assert sp.bool_periodic == (False, False) and ps.dx == pytest.approx(0.5)
+    flat = visc.numpy()
+    assert flat.min() == pytest.approx(2e-3) and flat.max() == pytest.approx(2e-3 + 2e-3 * 20.0, rel=1e-6)
