@@ -26,6 +26,7 @@ from .les import smagorinsky_eddy_viscosity, strain_tensor, strain_tensor_center
 from .losses import L2_field_loss, multistep_averaging_loss, spectral_energy_loss, strain_rate_loss
 from .setups import (compute_mixingLayer_masks, spatialMixingLayer_setup, sponge_viscosity_field, temporal_mixing_layer_masks,
                      update_dirichlet_values)
+from .training import boundary_perturbation_fun, training_run
 from .unroll import run_piso_steps, zero_gradient_op
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -165,6 +165,57 @@ def stack_staggered_components(tensors):
     return torch.cat([v, u], dim=-1)
 
 
+# ---------------------------------------------------------------------------------------------------- resampling
+def _axis_interpolate(t, dim, coords, mode):
+    """Linear interpolation of `t` along `dim` at fractional index positions `coords` (1-D tensor).  Outside the samples:
+    'boundary' -> edge value (phi.math.resample with boundary='replicate'), 'periodic' -> wrap, 'constant' -> zeros."""
+    n = t.shape[dim]
+    lo_f = torch.floor(coords)
+    w = (coords - lo_f).to(t.dtype)
+    lo = lo_f.long()
+    hi = lo + 1
+    if mode == "periodic":
+        lo_i, hi_i = lo % n, hi % n
+        m_lo = m_hi = None
+    else:
+        lo_i, hi_i = lo.clamp(0, n - 1), hi.clamp(0, n - 1)
+        m_lo = m_hi = None
+        if mode == "constant":
+            m_lo = ((lo >= 0) & (lo < n)).to(t.dtype)
+            m_hi = ((hi >= 0) & (hi < n)).to(t.dtype)
+    shape = [1] * t.dim()
+    shape[dim] = -1
+    a, b = t.index_select(dim, lo_i), t.index_select(dim, hi_i)
+    if m_lo is not None:
+        a, b = a * m_lo.view(shape), b * m_hi.view(shape)
+    return a * (1 - w).view(shape) + b * w.view(shape)
+
+
+def _sample_grid(data, lower, dx, points_yx, extrapolation):
+    """Values of a cell-centred array `data` [1,H,W,C] (cell (0,0) starts at `lower`, spacing `dx`) at the tensor-product
+    points (ys, xs) -- what phi's Field.at does for axis-aligned grids: linear interpolation in index space, sample
+    centres at (i + 1/2) dx."""
+    ext = axis_extrapolation(extrapolation, 2)
+    out = data
+    for axis in (0, 1):
+        mode = ext[axis] if isinstance(ext[axis], str) else ext[axis][0]
+        coords = (torch.as_tensor(points_yx[axis], dtype=torch.float64, device=data.device) - float(lower[axis])) / float(dx[axis]) - 0.5
+        out = _axis_interpolate(out, axis + 1, coords, mode)
+    return out
+
+
+def _centre_points(box, resolution):
+    return [box.lower[a] + (np.arange(int(resolution[a])) + 0.5) * (box.size[a] / resolution[a]) for a in (0, 1)]
+
+
+def _face_points(box, resolution, comp):
+    """Sample points of staggered component `comp` (0: v on y-faces, 1: u on x-faces)."""
+    pts = _centre_points(box, resolution)
+    d = box.size[comp] / resolution[comp]
+    pts[comp] = box.lower[comp] + np.arange(int(resolution[comp]) + 1) * d
+    return pts
+
+
 # ---------------------------------------------------------------------------------------------------- fields
 class CenteredGrid(object):
     """PhiFlow/phi/physics/field/grid.py:25-194 (data holder + `padded`)."""
@@ -235,6 +286,20 @@ class CenteredGrid(object):
     def sample(value, domain, batch_size=None, name=None):
         return domain.centered_grid(value)
 
+    def at(self, other):
+        """Field.at for axis-aligned grids (phi/physics/field/grid.py:125-140): this field sampled at the points of `other`
+        -- a CenteredGrid (cell centres) or a StaggeredGrid (face centres; a scalar field goes to both components, a
+        2-channel field channel-wise).  Used by the scripts to bring high-resolution frames and cell-centred viscosity to the
+        simulation grid."""
+        if isinstance(other, StaggeredGrid):
+            comps = []
+            for c in (0, 1):
+                d = self.data if self.data.shape[-1] == 1 else self.data[..., c:c + 1]
+                comps.append(_sample_grid(d, self.box.lower, self.dx, _face_points(other.box, other.resolution, c), self.extrapolation))
+            return StaggeredGrid(stack_staggered_components(comps), other.box, extrapolation=other.extrapolation)
+        pts = _centre_points(other.box, other.resolution)
+        return CenteredGrid(_sample_grid(self.data, self.box.lower, self.dx, pts, self.extrapolation), other.box, other.extrapolation)
+
 
 class StaggeredGrid(object):
     """PhiFlow/phi/physics/field/staggered_grid.py:56-228: `.data` is the tuple (v-component, u-component) of CenteredGrids."""
@@ -282,6 +347,17 @@ class StaggeredGrid(object):
 
     def unstack(self):
         return self.data
+
+    def at(self, other):
+        """staggered_grid.py `at`: every component resampled to the matching face points of `other` (a StaggeredGrid over
+        any resolution / box).  A component is a cell-centred array over the box grown by half a cell along its own axis."""
+        assert isinstance(other, StaggeredGrid)
+        comps = []
+        for c in (0, 1):
+            lower = np.array(self.box.lower, dtype=np.float64).copy()
+            lower[c] -= 0.5 * self.dx[c]
+            comps.append(_sample_grid(self.data[c].data, lower, self.dx, _face_points(other.box, other.resolution, c), self.extrapolation))
+        return StaggeredGrid(stack_staggered_components(comps), other.box, extrapolation=other.extrapolation)
 
     def at_centers(self):
         """Linear interpolation of both components to the cell centres -> CenteredGrid [1,Ny,Nx,2] (y component first)."""

@@ -121,3 +121,28 @@ def main_setups():
 
 if __name__ == "__main__":
     main_setups()
+
+
+def main_resample():
+    """HR -> LR resampling the training script applies to every data frame (combined_training_integrated.py:169-174):
+    StaggeredGrid(hr_tensor, box).at(lr_velocity) and CenteredGrid(hr_p, box).at(lr_pressure), default extrapolation."""
+    rng = np.random.default_rng(5)
+    out = {}
+    for tag, hr, lr in (("r2", (12, 16), (6, 8)), ("r4", (16, 24), (4, 6)), ("r1p5", (9, 12), (6, 8))):
+        size = (3.0, 4.0)
+        box = pf.box[0:size[0], 0:size[1]]
+        hv = rng.standard_normal((1, hr[0] + 1, hr[1] + 1, 2)).astype(np.float32)
+        hp = rng.standard_normal((1, hr[0], hr[1], 1)).astype(np.float32)
+        dom = pf.Domain(list(lr), box=box, boundaries=((pf.OPEN, pf.OPEN), (pf.OPEN, pf.CLOSED)))
+        lr_vel = pf.StaggeredGrid.sample(np.zeros((1, lr[0] + 1, lr[1] + 1, 2), np.float32), domain=dom)
+        lr_p = pf.CenteredGrid(np.zeros((1, lr[0], lr[1], 1), np.float32), box=box)
+        out[tag + "/hr_res"], out[tag + "/lr_res"], out[tag + "/box"] = np.array(hr), np.array(lr), np.array(size)
+        out[tag + "/hr_velocity"], out[tag + "/hr_pressure"] = hv, hp
+        out[tag + "/lr_velocity"] = np.asarray(pf.StaggeredGrid(hv, box).at(lr_vel).staggered_tensor())
+        out[tag + "/lr_pressure"] = np.asarray(pf.CenteredGrid(hp, box).at(lr_p).data)
+    np.savez_compressed(os.path.join(HERE, "resample.npz"), **out)
+    print("wrote resample.npz with", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main_resample()

@@ -168,3 +168,23 @@ def test_spatial_mixing_layer_setup_objects():
     assert sp.bool_periodic == (False, False) and ps.dx == pytest.approx(0.5)
     flat = visc.numpy()
     assert flat.min() == pytest.approx(2e-3) and flat.max() == pytest.approx(2e-3 + 2e-3 * 20.0, rel=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["r2", "r4", "r1p5"])
+def test_resampling_of_data_frames_against_reference_golden(golden_dir, tag):
+    """StaggeredGrid(hr).at(lr_velocity) / CenteredGrid(hr_p).at(lr_pressure) (combined_training_integrated.py:169-174)."""
+    g = np.load(os.path.join(golden_dir, "resample.npz"))
+    lr, size = g[tag + "/lr_res"], g[tag + "/box"]
+    box = dp.box[0:size[0], 0:size[1]]
+    dom = dp.Domain([int(lr[0]), int(lr[1])], box=box, boundaries=((dp.OPEN, dp.OPEN), (dp.OPEN, dp.CLOSED)))
+    lr_vel = dp.StaggeredGrid.sample(torch.zeros((1, lr[0] + 1, lr[1] + 1, 2)), domain=dom)
+    lr_p = dp.CenteredGrid(torch.zeros((1, lr[0], lr[1], 1)), box=box)
+    v = dp.StaggeredGrid(torch.tensor(g[tag + "/hr_velocity"]), box).at(lr_vel)
+    np.testing.assert_allclose(v.staggered_tensor().numpy(), g[tag + "/lr_velocity"], **TOL)
+    p = dp.CenteredGrid(torch.tensor(g[tag + "/hr_pressure"]), box).at(lr_p)
+    np.testing.assert_allclose(p.data.numpy(), g[tag + "/lr_pressure"], **TOL)
+    # the set-up's own use: cell-centred viscosity to the faces equals sponge_viscosity_field
+    visc = np.ones((1, int(lr[0]), int(lr[1]), 1), np.float32) * 2e-3
+    visc[:, :, 3:, :] += np.linspace(0, 0.1, int(lr[1]) - 3, dtype=np.float32)[None, None, :, None]
+    flat = dp.flatten_staggered_data(dp.CenteredGrid(torch.tensor(visc), box).at(lr_vel), coord_flip=True)
+    np.testing.assert_allclose(flat.numpy(), dp.sponge_viscosity_field(lr, 2e-3, 3, 0.1), rtol=1e-6, atol=1e-9)

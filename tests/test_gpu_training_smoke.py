@@ -53,3 +53,71 @@ def test_closure_training_iterations_reduce_the_loss():
         opt.step()
     print("closure training smoke: loss history", ["%.5f" % h for h in history])
     assert history[-1] < history[0]
+
+
+def _frames(tmp, n_frames, hr, box, phys, dt):
+    """A small high-resolution data set produced by the solver itself (perturbed inflow), in the reference's file format."""
+    import diffpiso as dp
+    sim = dict(HRres=list(hr), dx_ratio=1, box=box, sponge_ratio=0.75, relative_sponge_max=20.0)
+    domain, sp, ps, vel, prs, visc, bcx = dp.spatialMixingLayer_setup(sim, 1e-7, phys)
+    dev = vel.staggered_tensor().device
+    t = torch.zeros((1, hr[0] + 1, hr[1] + 1, 2), device=dev)
+    t[0, :hr[0], :, 1] = torch.tensor(bcx[0, 1:-1, 0, 0], device=dev)[:, None]
+    velocity, pressure = dp.StaggeredGrid.sample(t, domain=domain), prs
+    base = sp.dirichlet_values
+    path = str(tmp) + "/data/"
+    import os
+    os.makedirs(path)
+    with torch.no_grad():
+        for f in range(n_frames):
+            dp.save_frame(path, "velocity", f, velocity.staggered_tensor().cpu().numpy())
+            dp.save_frame(path, "pressure", f, pressure.data.cpu().numpy())
+            pert = dp.boundary_perturbation_fun(domain, phys["average_velocity"], bcx.shape, f * dt, (0.08, 0.05))
+            sp.dirichlet_values = dp.update_dirichlet_values(torch.as_tensor(base, dtype=torch.float32, device=dev), ((False, False), (True, False)),
+                                                             ((None, None), (torch.tensor(bcx + pert, dtype=torch.float32, device=dev), None)))
+            _, _, velocity, pressure, warn = dp.run_piso_steps(velocity, pressure, dt, sp, step_count=1, viscosity_field=visc)
+    return path
+
+
+def test_training_run_files_recovery_and_learning(tmp_path, monkeypatch, capsys):
+    """diffpiso.training_run (combined_training_integrated.py:27-388): one epoch over solver-generated frames; the files the
+    reference writes appear, the loss history is filled, a linear-solver warning triggers the restore-and-reinitialise path
+    instead of an optimiser step, and validation runs."""
+    import os
+    import diffpiso as dp
+    import diffpiso.training as T
+    hr, box = (32, 96), dp.box[0:8, 0:24]
+    phys = dict(average_velocity=1.0, velocity_difference=0.8, inlet_profile_sharpness=2.0, viscosity=5e-3)
+    dt = 0.1
+    data = _frames(tmp_path, 12, hr, box, phys, dt)
+    base_dir = str(tmp_path) + "/run"
+    os.makedirs(base_dir)
+    sim = dict(HRres=list(hr), dx_ratio=2, box=box, sponge_ratio=0.75, relative_sponge_max=20.0, dt=dt, dt_ratio=1,
+               setup_fun=dp.spatialMixingLayer_setup)
+    calls = {"n": 0}
+    real = T.run_piso_steps
+
+    def flaky(*a, **k):                                       # the 3rd training evaluation reports a failed linear solve
+        out = real(*a, **k)
+        calls["n"] += 1
+        if calls["n"] == 3:
+            out[4][0] = torch.ones(1, dtype=torch.bool)
+        return out
+    monkeypatch.setattr(T, "run_piso_steps", flaky)
+    td = dict(HR_buffer_width=[[2, 2], [2, 2]], learning_rate=2e-4, step_count=2, epochs=1, store_interm_ckpts=2, padding="SAME",
+              network_initialiser=lambda buffer_width, padding: dp.initialise_fullyconv_network(buffer_width, padding=padding, seed=5),
+              network_wrapper=None, loss_functions=[dp.L2_field_loss, dp.strain_rate_loss], loss_factor=[1.0, 1e-3], sum_steps=True,
+              loss_influence_range=None, dataset=[data], start_frame=[0], frame_count_training=[8], frame_count_validation=[4],
+              dataset_characteristics=[(0.08, 0.05)], perturb_inlet=True, load_model_path=None, lr_decay_fun=lambda lr: 0.5 * lr, seed=1)
+    hist, hist_val = dp.training_run(base_dir, phys, sim, td, solver_precision=1e-7)
+    out = capsys.readouterr().out
+    assert len(hist) == 6 and len(hist_val) == 2
+    assert (hist == -1).sum() == 1 and hist[2] == -1            # the flagged iteration is recorded as -1 (:257)
+    assert "RESTARTING FROM LAST WORKING" in out
+    good = hist[hist > 0]
+    assert len(good) == 5 and np.isfinite(good).all() and np.isfinite(hist_val).all() and (hist_val > 0).all()
+    for f in ("model_last_working", "model_epoch_000000.ckpt", "training_loss_progression.npz", "validation_loss_progression.npz", "loss.log"):
+        assert os.path.exists(os.path.join(base_dir, f)), f
+    assert any(n.startswith("model_epoch_000000i") for n in os.listdir(base_dir))
+    w = torch.load(os.path.join(base_dir, "model_epoch_000000.ckpt"))
+    assert len(w) == 7 and all(torch.isfinite(x).all() for x in w)          # the seven convolution kernels (networks.py:3-73)
