@@ -81,8 +81,6 @@ def main():
     print("wrote eval_les.npz with", len(out), "arrays")
 
 
-if __name__ == "__main__":
-    main()
 
 
 def main_setups():
@@ -119,8 +117,6 @@ def main_setups():
     print("wrote setups_extra.npz with", len(out), "arrays")
 
 
-if __name__ == "__main__":
-    main_setups()
 
 
 def main_resample():
@@ -145,4 +141,6 @@ def main_resample():
 
 
 if __name__ == "__main__":
+    main()
+    main_setups()
     main_resample()
