@@ -1,16 +1,21 @@
-// Persistent CG segment kernel: many NORMAL iterations in ONE launch, for grids whose per-wave working set fits on chip.
+// Persistent CG segment kernel: many NORMAL iterations in ONE launch, for grids whose solver state fits on chip
+// (DESIGN.md 3.1 has the measurements behind every choice below).
 //
-// One workgroup of 512 threads per CU; every wave owns two fixed regions of 128 columns x R rows (2 x 16 cells per lane at
-// R = 8, i.e. up to 4096 regions = 2048^2 cells on 256 CUs).  Across the iterations of a segment
-//   * the residual r and z' = L p of the region stay in REGISTERS, the solution x in LDS (128 KB per workgroup);
-//   * only the search direction p (ping-pong, read with its halo and written once), the 4 float off-diagonals and the
-//     PERIMETER of r (edge rows / columns that neighbouring regions need to rebuild p on their halo) touch HBM:
-//     ~4.7 words per cell and iteration instead of 11;
-//   * the two global reductions of an iteration are two grid barriers (monotonic counter, agent-scope release / acquire)
-//     that also carry the per-workgroup partial sums, reduced by everyone in a fixed order (deterministic).
-// The arithmetic, its order and the stopping logic are those of cg_k1 / cg_k2 (same helper code paths); a segment starts
-// from and ends in the global-memory state of the two-kernel path, so resets, the first iteration and grids that do not
-// fit simply use cg_k1 / cg_k2.
+// One workgroup of 512 threads per CU (2 waves per SIMD, 256 VGPRs per lane); every wave owns one region of 16 rows x 128
+// columns (or two regions of 2 / 4 / 8 rows on smaller grids): 2048^2 cells = 2048 regions = 256 CUs x 8 waves.
+// Across the iterations of a segment
+//   * the residual r and the search direction p of the region stay in REGISTERS, the solution x in LDS (128 KB per workgroup);
+//     z' = L p is never stored: phase A computes it for the dot products, phase B computes it again (same registers, same
+//     instruction sequence, bitwise the same values) for the update of r;
+//   * HBM sees only the float coefficient rows (S and W when the matrix is symmetric, else all four; streamed once per phase
+//     through a circular 4-row software pipeline) and the PERIMETERS of r and p (first / last row and end columns of a region)
+//     that neighbouring regions need to rebuild p_new = r + beta p on their halo - written write-through and read at agent
+//     scope (sc1), the scope at which the 8 XCD-private L2s are coherent;
+//   * the two global reductions of an iteration are two grid-wide EXCHANGES without atomics or fences: every workgroup
+//     publishes three partial sums as tagged 8-byte words, wave 0 polls all records and adds them in a fixed order, so every
+//     workgroup holds bitwise the same totals (grid_exchange below).
+// The arithmetic per cell, its order and the stopping logic are those of cg_k1 / cg_k2; a segment starts from and ends in
+// the global-memory state of the two-kernel path, so resets, the first iteration and grids that do not fit use cg_k1 / cg_k2.
 #pragma once
 #include "cg_kernels.h"
 
@@ -45,7 +50,7 @@ struct PersistCtl {
   unsigned long long* rec;   // exchange records: [2 (parity)][kPersistMaxGrid][8] 8-byte words, zeroed before every launch
   int* err;             // set to 1 if a spin gave up
   int nreg, ntx;        // regions (= waves with work), strips per row
-  unsigned long long* timing;   // diagnostics (PISO_CG_PERSIST_TIMING): [4][grid] 100 MHz ticks in phase A / barrier A / phase B / barrier B
+  unsigned long long* timing;   // diagnostics (-DPISO_PERSIST_DIAG + PISO_CG_PERSIST_TIMING): [5][grid] 100 MHz ticks per phase / exchange
 };
 #ifdef PISO_PERSIST_DIAG
 constexpr bool kPersistDiag = true;     // per-phase clocks of wave 0 (PISO_CG_PERSIST_TIMING=1); costs a few registers
