@@ -107,8 +107,12 @@ __device__ __forceinline__ double wave_sum_uniform(double v) {
 // (s_waitcnt vmcnt(0)) by every wave before the workgroup publishes; readers load it at agent scope as well.
 // KEEP = number of vector-memory LOADS this wave issued after its last store and may leave in flight (prefetch for the next
 // phase; vmcnt retires in issue order, so "at most KEEP outstanding" means every store has completed).
-template <typename T, int KEEP, bool HYBRID>
-__device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], unsigned epoch, T* smem) {
+// `between(rec)` runs in every wave while the exchange is in flight (wave 0: right after it has published the workgroup's
+// record, before it starts polling): a record that carries the epoch also says "this workgroup's perimeter stores have
+// completed", which phase A uses to fetch its halos from the neighbouring workgroups before the global sums are known.
+struct NoBetween { __device__ __forceinline__ void operator()(const unsigned long long*) const {} };
+template <typename T, int KEEP, bool HYBRID, typename F = NoBetween>
+__device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], unsigned epoch, T* smem, F between = F()) {
   typedef unsigned long long u64;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   T* sm = smem + (epoch & 1) * 32;                          // parity double buffer: two __syncthreads per exchange
@@ -138,6 +142,7 @@ __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], un
 #endif
       if (lane < 6) __hip_atomic_store(rec + (size_t)blockIdx.x * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    between(rec);
     // Lane l owns records l, l + 64, ...  Arrivals cluster: once a lane's first record is there, the others almost always
     // are too.  HYBRID polls the first record, then reads the remaining ones in one go and re-polls only stragglers (two
     // memory round trips instead of up to four) - 36 more registers, which the kernels with 16 rows of state per wave
@@ -232,6 +237,8 @@ __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], un
       sm[27] = good ? (T)0 : (T)1;
       if (!good) *c.err = 1;
     }
+  } else {
+    between(c.rec + (size_t)(epoch & 1) * kPersistMaxGrid * 8);
   }
   __syncthreads();
 #pragma unroll
@@ -328,6 +335,11 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   static_assert(R * NQ <= 16 && 2 * R <= 64, "at most 16 rows per wave; the edge columns of a region fit one wave-wide load");
   __shared__ T xs[kPersistWaves * NQ * R * 64 * V];        // the solution of my regions (128 KB at 16 rows per wave, fp64)
   __shared__ T smem[64];
+  __shared__ int nbr_s[kPersistWaves * 8];                   // per wave: record slots of the (up to 4 NQ) neighbouring workgroups
+  // p_new on the rows below / above my regions (rebuilt from the neighbours' perimeters in phase A, used by the first / last
+  // row of both phases): parked in LDS, two reads per phase, instead of 8 registers held through both row loops
+  constexpr bool kParkHalos = (NQ * R < 16) || NQ == 1;     // (two regions of 8 rows: x already fills the LDS)
+  __shared__ T halo_s[kParkHalos ? kPersistWaves * NQ * 2 * 64 * V : 1];
   const int nx = a.nx, ny = a.ny;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar branches, SGPRs
@@ -359,13 +371,13 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   // ---- load the state of the two-kernel path: r and the search direction p of my regions into registers, x into LDS
   const T alpha0 = pend ? uniform(a.scal[SC_ALPHA]) : (T)0;   // pend: x still lacks alpha p of the iteration before k_begin
   Vec<T, V> rr[NQ][R], pp[NQ][R];
-  unsigned vT[NQ], vC[NQ];
+  unsigned vT[NQ];
   {
     const rsrc_t Rp = (k_begin & 1) ? Rp1 : Rp0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int cq = (tx0[q] * 64 + lane) * V;
-      vT[q] = (unsigned)(cq * sizeof(T)); vC[q] = (unsigned)(cq * sizeof(CT));
+      vT[q] = (unsigned)(cq * sizeof(T));
       T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
 #pragma unroll
       for (int jj = 0; jj < R; ++jj) {
@@ -416,20 +428,29 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   constexpr int budget = (NQ == 1 || NT < 16) ? 16 : 8;    // VGPRs for rows in flight (two regions keep twice the halo state)
   constexpr int Dw = budget / coef_regs < 2 ? 2 : (budget / coef_regs > kPersistMaxDepth ? kPersistMaxDepth : budget / coef_regs);
   constexpr int D = (NT >= Dw) ? Dw : NT;
+  constexpr bool kFetchEarly = (NQ == 1) || NT <= 8;                  // halos fetched during exchange B (20 registers per region)
   constexpr bool kHybridPoll = NT <= 8;                                // (see grid_exchange: a question of registers)
   constexpr int kBaseLoads = (SYM ? 2 : 4) + (RECON ? 0 : 1);          // vector loads every row issues (some rows one or two more)
   Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT], cSh[NQ];
   Vec<T, V> cD[NT];
   CT eW[NQ];
+  // (the per-lane byte offset into a coefficient row is recomputed from vT at every use - one shift - instead of living in a
+  // register for the whole kernel: the empty asm keeps the optimiser from hoisting it back into one)
+  auto coef_offset = [&](int q) __attribute__((always_inline)) -> unsigned {
+    unsigned o = vT[q];
+    asm volatile("" : "+v"(o));
+    return (unsigned)((unsigned long long)o * sizeof(CT) / sizeof(T));
+  };
   auto issue_coef = [&](int t) __attribute__((always_inline)) {
     const int q = t / R, jj = t - q * R;
+    const unsigned vCq = coef_offset(q);
 #if defined(PISO_ABLATE) && PISO_ABLATE == 4
     { for (int e = 0; e < V; ++e) { cS[t].v[e] = (CT)1; cW[t].v[e] = (CT)1; cE[t].v[e] = (CT)1; cN[t].v[e] = (CT)1; cD[t].v[e] = (T)-4; }
       if (jj == 0) eW[q] = (CT)1; if (jj == R - 1) for (int e = 0; e < V; ++e) cSh[q].v[e] = (CT)1; return; }
 #endif
     const unsigned sT = (unsigned)(j0[q] + jj) * rowT, sC = (unsigned)(j0[q] + jj) * rowC;
-    cS[t] = bld<CT, V>(RoS, vC[q], sC); cW[t] = bld<CT, V>(RoW, vC[q], sC);
-    if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vC[q], sC); cN[t] = bld<CT, V>(RoN, vC[q], sC); }
+    cS[t] = bld<CT, V>(RoS, vCq, sC); cW[t] = bld<CT, V>(RoW, vCq, sC);
+    if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vCq, sC); cN[t] = bld<CT, V>(RoN, vCq, sC); }
     if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
     if constexpr (SYM) {
       if (jj == 0) {                                       // W of the first column of the strip to the right: E of my last column
@@ -442,15 +463,15 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
       if (jj == R - 1) {                                   // S of the row above the region: N of my last row
         bool valid;
         const int jw = row_wrap(j0[q] + R, valid);
-        cSh[q] = bld<CT, V>(RoS, valid ? vC[q] : 0xffffffffu, (unsigned)jw * rowC);
+        cSh[q] = bld<CT, V>(RoS, valid ? vCq : 0xffffffffu, (unsigned)jw * rowC);
       }
     }
   };
   // p_new on the cells around a region, rebuilt from what the neighbours published (perimeters of r and of the old p):
   // pnb / pna = the rows below / above, edge = the two columns next to the strip (lane l < R: left neighbour of row l,
   // lane R + l: right neighbour).  Kept from phase A to phase B.
-  Vec<T, V> pnb[NQ], pna[NQ];
   T edge[NQ];
+  Vec<T, V> pnb[NQ], pna[NQ];                               // (registers when the LDS has no room: !kParkHalos)
   // z' = L p of row t of my regions: summation order of calcZ_v4 (pressure_solve_op.cu.cc:81-90).  Phase A and phase B
   // both call this on the same registers, so they see bitwise the same z'.
   auto zrow = [&](int t) __attribute__((always_inline)) -> Vec<T, V> {
@@ -458,9 +479,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
 #if defined(PISO_ABLATE) && PISO_ABLATE == 3
     { Vec<T, V> z0; for (int e = 0; e < V; ++e) z0.v[e] = pp[q][jj].v[e] * (T)cS[t].v[e]; return z0; }
 #endif
-    const Vec<T, V> behind = (jj > 0) ? pp[q][jj > 0 ? jj - 1 : 0] : pnb[q];
+    T* hs = halo_s + (kParkHalos ? (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V : 0);
+    const Vec<T, V> behind = (jj > 0) ? pp[q][jj > 0 ? jj - 1 : 0] : (kParkHalos ? ldv<T, V>(hs) : pnb[q]);
     const Vec<T, V> cur = pp[q][jj];
-    const Vec<T, V> ahead = (jj + 1 < R) ? pp[q][jj + 1 < R ? jj + 1 : jj] : pna[q];
+    const Vec<T, V> ahead = (jj + 1 < R) ? pp[q][jj + 1 < R ? jj + 1 : jj] : (kParkHalos ? ldv<T, V>(hs + (kParkHalos ? 64 * V : 0)) : pna[q]);
     const T left = shift_lane<true, T>(cur.v[V - 1], read_lane<T>(edge[q], jj));
     const T right = shift_lane<false, T>(cur.v[0], read_lane<T>(edge[q], R + jj));
     Vec<CT, V> kN, kE;
@@ -510,6 +532,78 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
       if (lane == 63) bst1<T, kAgent>(Rd, vT[q] + (unsigned)((V - 1) * sizeof(T)), sT, val.v[V - 1]);
     }
   };
+  // ---- halos: what the neighbours published (perimeters of r and of the direction): the columns next to the strip (all R
+  // rows with ONE pair of loads: lane l < R the left neighbour of row l, lane R + l the right one; lanes without a cell and
+  // walls read out of range -> 0) and the rows below / above the region.  Issued either at the top of phase A or - normally -
+  // by fetch_halos() in the middle of the previous exchange B, as soon as the NEIGHBOURING workgroups have published.
+  T eP[NQ], eR[NQ];
+  Vec<T, V> hbR[NQ], hbP[NQ], haR[NQ], haP[NQ];
+  bool have_halos = false;
+  auto issue_halos = [&](rsrc_t Rp) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int side = lane / R, er = lane - side * R;
+      int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
+      if (cc < 0) cc = a.per_x ? nx - 1 : -1;
+      else if (cc >= nx) cc = a.per_x ? 0 : -1;
+      const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
+#if defined(PISO_ABLATE) && PISO_ABLATE == 2
+      eP[q] = 0; eR[q] = 0;
+      for (int e = 0; e < V; ++e) { hbR[q].v[e] = 0; hbP[q].v[e] = 0; haR[q].v[e] = 0; haP[q].v[e] = 0; }
+      (void)vo;
+      continue;
+#endif
+      eP[q] = bld1<T, kAgent>(Rp, vo, 0);
+      eR[q] = bld1<T, kAgent>(Rr, vo, 0);
+      bool vb, va;
+      const int jb = row_wrap(j0[q] - 1, vb), ja = row_wrap(j0[q] + R, va);
+      const unsigned hb = vb ? vT[q] : 0xffffffffu, ha = va ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
+      hbR[q] = bld<T, V, kAgent>(Rr, hb, (unsigned)jb * rowT);
+      hbP[q] = bld<T, V, kAgent>(Rp, hb, (unsigned)jb * rowT);
+      haR[q] = bld<T, V, kAgent>(Rr, ha, (unsigned)ja * rowT);
+      haP[q] = bld<T, V, kAgent>(Rp, ha, (unsigned)ja * rowT);
+    }
+  };
+  // lane l < 4 NQ: the workgroup (record slot) that owns the region below / above / left / right of my region l / 4, or -1
+  // (no neighbour there, or my own workgroup - whose stores are complete once the exchange's first barrier has passed)
+  int nbr_slot = -1;
+  if (has[0] && lane < 4 * NQ) {
+    const int q = lane >> 2, dir = lane & 3;
+    const int nty = ny / R;
+    int ty = 0, tx = 0;
+#pragma unroll
+    for (int qq = 0; qq < NQ; ++qq) if (q == qq) { ty = j0[qq] / R; tx = tx0[qq]; }   // (wave-uniform arrays, selected per lane)
+    int y = ty + (dir == 0 ? -1 : (dir == 1 ? 1 : 0)), x = tx + (dir == 2 ? -1 : (dir == 3 ? 1 : 0));
+    bool exists = true;
+    if (y < 0) { exists = a.per_y; y = nty - 1; }
+    if (y >= nty) { exists = a.per_y; y = 0; }
+    if (x < 0) { exists = exists && a.per_x; x = c.ntx - 1; }
+    if (x >= c.ntx) { exists = exists && a.per_x; x = 0; }
+    if (exists) {
+      const int lw = (y * c.ntx + x) / (kPersistWaves * NQ);           // logical workgroup of that region
+      int b = lw;                                                       // inverse of the XCD permutation above
+      if (gridDim.x % kXcds == 0) { const int per = gridDim.x / kXcds; b = (lw % per) * kXcds + lw / per; }
+      if (b != (int)blockIdx.x) nbr_slot = b;
+    }
+  }
+  if (lane < 8) nbr_s[wave * 8 + lane] = nbr_slot;           // (parked in LDS: read once per iteration, not worth a register)
+  unsigned fetch_epoch = 0;
+  rsrc_t fetch_rp = Rp0;
+  auto fetch_halos = [&](const unsigned long long* rec) __attribute__((always_inline)) {
+    if (!has[0]) return;
+    unsigned spins = 0;
+    const int slot = nbr_s[wave * 8 + (lane & 7)];
+    const bool mine = lane < 4 * NQ && slot >= 0;
+    while (true) {                                          // (a give-up here is harmless: the global exchange then fails too)
+      bool ok = true;
+      if (mine)
+        ok = (unsigned)(__hip_atomic_load(rec + (size_t)slot * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffffull) == fetch_epoch;
+      if (__all(ok) || ++spins > (1u << 20)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    issue_halos(fetch_rp);
+  };
+
   if (has[0]) {
 #pragma unroll
     for (int t = 0; t < D; ++t) issue_coef(t);
@@ -536,33 +630,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     // ---- phase A: p_new = r + beta p_old (registers) ; z' = L p_new ; sums p, p.r, p.z'
     T sA[3] = {0, 0, 0};
     if (has[0]) {                                          // the host makes nreg a multiple of NQ: a wave owns NQ regions or none
-      // what the neighbours published: the columns next to the strip (all R rows with ONE pair of loads; lanes without a cell
-      // and walls read out of range -> 0) and the rows below / above the region
-      T eP[NQ], eR[NQ];
-      Vec<T, V> hbR[NQ], hbP[NQ], haR[NQ], haP[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int side = lane / R, er = lane - side * R;
-        int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
-        if (cc < 0) cc = a.per_x ? nx - 1 : -1;
-        else if (cc >= nx) cc = a.per_x ? 0 : -1;
-        const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
-#if defined(PISO_ABLATE) && PISO_ABLATE == 2
-        eP[q] = 0; eR[q] = 0;
-        for (int e = 0; e < V; ++e) { hbR[q].v[e] = 0; hbP[q].v[e] = 0; haR[q].v[e] = 0; haP[q].v[e] = 0; }
-        (void)vo;
-        continue;
-#endif
-        eP[q] = bld1<T, kAgent>(Rpin, vo, 0);
-        eR[q] = bld1<T, kAgent>(Rr, vo, 0);
-        bool vb, va;
-        const int jb = row_wrap(j0[q] - 1, vb), ja = row_wrap(j0[q] + R, va);
-        const unsigned hb = vb ? vT[q] : 0xffffffffu, ha = va ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
-        hbR[q] = bld<T, V, kAgent>(Rr, hb, (unsigned)jb * rowT);
-        hbP[q] = bld<T, V, kAgent>(Rpin, hb, (unsigned)jb * rowT);
-        haR[q] = bld<T, V, kAgent>(Rr, ha, (unsigned)ja * rowT);
-        haP[q] = bld<T, V, kAgent>(Rpin, ha, (unsigned)ja * rowT);
-      }
+      if (!have_halos) issue_halos(Rpin);                  // (first iteration of a launch; later ones were fetched in exchange B)
 #if defined(PISO_ABLATE) && PISO_ABLATE == 5
       __builtin_amdgcn_s_waitcnt(0);                       // timing experiment: how long do the halo loads alone take?
       tick(4);
@@ -581,10 +649,18 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         edge[q] = fma(beta, eP[q], eR[q]);
+        Vec<T, V> below, above;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          pnb[q].v[e] = fma(beta, hbP[q].v[e], hbR[q].v[e]);
-          pna[q].v[e] = fma(beta, haP[q].v[e], haR[q].v[e]);
+          below.v[e] = fma(beta, hbP[q].v[e], hbR[q].v[e]);
+          above.v[e] = fma(beta, haP[q].v[e], haR[q].v[e]);
+        }
+        if constexpr (kParkHalos) {
+          T* hs = halo_s + (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V;
+          stv<T, V>(hs, below);
+          stv<T, V>(hs + 64 * V, above);
+        } else {
+          pnb[q] = below; pna[q] = above;
         }
       }
 #pragma unroll
@@ -641,7 +717,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     ++epoch;
     tick(2);
     // (the last row's perimeter store is followed by exactly one row of coefficient loads)
-    healthy = grid_exchange<T, (D < NT) ? kBaseLoads : 0, kHybridPoll>(c, sB, epoch, smem);
+    if constexpr (kFetchEarly) {
+      fetch_epoch = epoch;
+      fetch_rp = Rpout;                                    // iteration k+1 reads the direction this iteration published
+      healthy = grid_exchange<T, (D < NT) ? kBaseLoads : 0, kHybridPoll>(c, sB, epoch, smem, fetch_halos);
+      have_halos = true;
+    } else {
+      healthy = grid_exchange<T, (D < NT) ? kBaseLoads : 0, kHybridPoll>(c, sB, epoch, smem);
+    }
     tick(3);
 #pragma unroll
     for (int q = 0; q < 3; ++q) tB[q] = uniform(sB[q]);
