@@ -41,6 +41,7 @@ class _Run(object):
     def __init__(self, physical_parameters, simulation_parameters, training_dict, solver_precision, buffer_width, sponge_start):
         self.pp, self.sp, self.td = physical_parameters, simulation_parameters, training_dict
         self.sponge_start = sponge_start
+        self.buffer_width = buffer_width
         (self.domain, self.sim_physics, self.pressure_solver, self.velocity, self.pressure, self.viscosity_field,
          self.bcx) = simulation_parameters["setup_fun"](simulation_parameters, solver_precision, physical_parameters,
                                                        training_dict["step_count"])
@@ -66,6 +67,14 @@ class _Run(object):
                 return update_dirichlet_values(torch.as_tensor(self.base_dirichlet, dtype=torch.float32, device=self.device),
                                                ((False, False), (True, False)), ((None, None), (bc, None)))
         wrapper = td.get("network_wrapper")
+        if wrapper is not None:
+            # the reference calls neural_network_wrapper(network, input, fluid, physical_parameters, simulation_parameters,
+            # loss_buffer_width, buffer_width) (:446-449); two-argument wrappers (network, input) are accepted as well
+            import inspect
+            user = wrapper
+            if len(inspect.signature(user).parameters) > 2:
+                def wrapper(net, nn_in, _u=user):
+                    return _u(net, nn_in, self.velocity, self.pp, self.sp, self.loss_buffer_width, self.buffer_width)
         forcing = make_forcing_fn(self.network, pressure_included=td.get("pressure_included", True), wrapper=wrapper)
         return run_piso_steps(velocity, pressure, self.sp["dt"] * self.sp["dt_ratio"], self.sim_physics,
                               step_count=td["step_count"], loss_influence_range=td.get("loss_influence_range"),

@@ -104,9 +104,18 @@ def test_training_run_files_recovery_and_learning(tmp_path, monkeypatch, capsys)
             out[4][0] = torch.ones(1, dtype=torch.bool)
         return out
     monkeypatch.setattr(T, "run_piso_steps", flaky)
+    # the reference script's sponge wrapper, with its seven-argument signature (spatial_mixing_layer_differentiable_training.py:6-10)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sml_training_example", os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "spatial_mixing_layer_differentiable_training.py"))
+    example = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(example)
+    wrapper = example.neural_network_wrapper
     td = dict(HR_buffer_width=[[2, 2], [2, 2]], learning_rate=2e-4, step_count=2, epochs=1, store_interm_ckpts=2, padding="SAME",
-              network_initialiser=lambda buffer_width, padding: dp.initialise_fullyconv_network(buffer_width, padding=padding, seed=5),
-              network_wrapper=None, loss_functions=[dp.L2_field_loss, dp.strain_rate_loss], loss_factor=[1.0, 1e-3], sum_steps=True,
+              # (SAME padding on this 16 x 48 grid: the loss buffer is set by hand, the network's own 10-cell margin would leave nothing)
+              network_initialiser=lambda buffer_width, padding: dp.initialise_fullyconv_network(None, padding=padding, seed=5)[:2] + ([[1, 1], [1, 1]],),
+              network_wrapper=wrapper, loss_functions=[dp.L2_field_loss, dp.strain_rate_loss, dp.spectral_energy_loss, dp.multistep_averaging_loss],
+              loss_factor=[1.0, 1e-3, 1e-3, 1e-3], sum_steps=True,
               loss_influence_range=None, dataset=[data], start_frame=[0], frame_count_training=[8], frame_count_validation=[4],
               dataset_characteristics=[(0.08, 0.05)], perturb_inlet=True, load_model_path=None, lr_decay_fun=lambda lr: 0.5 * lr, seed=1)
     hist, hist_val = dp.training_run(base_dir, phys, sim, td, solver_precision=1e-7)
