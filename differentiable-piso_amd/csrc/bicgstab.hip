@@ -296,6 +296,26 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
   T prev[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) prev[e] = 0;
+  // The rows of a band are sequential (y(k) needs y(k-W)), but what a row READS from memory does not depend on the
+  // recurrence: the inputs of row jj+1 are loaded while row jj is scanned (a row is latency-, not bandwidth-bound).
+  T nv[E], na[E], nb[E];
+  auto load_row = [&](int jj) __attribute__((always_inline)) {
+    const int j = FWD ? j0 + jj : j1 - 1 - jj;
+    const int kb = r0 + j * W;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int s = i0 + e;
+      const int i = FWD ? s : W - 1 - s;
+      nv[e] = 0; na[e] = 0; nb[e] = 0;
+      if (s < W && jj < j1 - j0) {
+        const int k = kb + i;
+        T v = in[k];
+        if (!FWD) v *= a.dinv[k];
+        nv[e] = v; na[e] = ca[k]; nb[e] = cb[k];
+      }
+    }
+  };
+  load_row(0);
   for (int jj = 0; jj < j1 - j0; ++jj) {
     const int j = FWD ? j0 + jj : j1 - 1 - jj;
     const int kb = r0 + j * W;
@@ -304,17 +324,14 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int s = i0 + e;                       // position along the scan
-      const int i = FWD ? s : W - 1 - s;
       m[e] = 0; cst[e] = 0;
       if (s < W) {
-        const int k = kb + i;
-        T v = in[k];
-        if (!FWD) v *= a.dinv[k];
-        cst[e] = v - cb[k] * prev[e];
-        m[e] = -ca[k];
+        cst[e] = nv[e] - nb[e] * prev[e];
+        m[e] = -na[e];
         f = Affine<T>::then(f, Affine<T>{m[e], cst[e]});
       }
     }
+    load_row(jj + 1);                             // (in flight during the scan below)
     const Affine<T> pre = block_exclusive_scan(f, smem);
     T yl = pre.c;                                 // value just before my chunk (pre applied to 0; first m is 0 anyway)
 #pragma unroll
@@ -619,8 +636,11 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   bi_convert<T><<<grid_v, kBlock, 0, stream>>>(a, val, rowptr, col, x0, transpose ? 1 : 0);
   if (need <= 1) launch_factor<T, 1>(a, grid_b, stream);
   else if (need <= 2) launch_factor<T, 2>(a, grid_b, stream);
+  else if (need <= 3) launch_factor<T, 3>(a, grid_b, stream);             // (W = nx + 1 with nx a power of two: 2^k / 256 + 1)
   else if (need <= 4) launch_factor<T, 4>(a, grid_b, stream);
+  else if (need <= 5) launch_factor<T, 5>(a, grid_b, stream);
   else if (need <= 8) launch_factor<T, 8>(a, grid_b, stream);
+  else if (need <= 9) launch_factor<T, 9>(a, grid_b, stream);
   else if (need <= 16) launch_factor<T, 16>(a, grid_b, stream);
   else launch_factor<T, 32>(a, grid_b, stream);
   PISO_LAUNCH_CHECK();
@@ -628,8 +648,11 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   auto precond = [&](const T* in, T* out) {
     if (need <= 1) launch_sweeps<T, 1>(a, grid_b, in, out, stream);
     else if (need <= 2) launch_sweeps<T, 2>(a, grid_b, in, out, stream);
+    else if (need <= 3) launch_sweeps<T, 3>(a, grid_b, in, out, stream);
     else if (need <= 4) launch_sweeps<T, 4>(a, grid_b, in, out, stream);
+    else if (need <= 5) launch_sweeps<T, 5>(a, grid_b, in, out, stream);
     else if (need <= 8) launch_sweeps<T, 8>(a, grid_b, in, out, stream);
+    else if (need <= 9) launch_sweeps<T, 9>(a, grid_b, in, out, stream);
     else if (need <= 16) launch_sweeps<T, 16>(a, grid_b, in, out, stream);
     else launch_sweeps<T, 32>(a, grid_b, in, out, stream);
   };
