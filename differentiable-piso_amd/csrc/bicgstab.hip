@@ -23,7 +23,7 @@
 
 namespace piso {
 
-constexpr int kBiParts = 512;     // max blocks per component of a partial-producing kernel
+constexpr int kBiParts = 1024;    // max blocks per component of a partial-producing kernel
 constexpr int kExcSlots = 4;      // exception (wrap) entries per frame row
 
 struct Geo {
@@ -73,6 +73,7 @@ struct BiArgs {
   CompScalars<T>* sc;             // [2]
   int* flags;                     // [0]: unsupported pattern, [1]: NaN seen
   float tol;
+  int nparts;                     // blocks per component that write partial records (<= kBiParts; the rest stays zero)
 };
 
 __device__ __forceinline__ bool is_nan(float v) { return v != v; }
@@ -482,12 +483,10 @@ __global__ __launch_bounds__(kBlock) void bi_scalar(BiArgs<T> a, int stage) {
   const int c = blockIdx.x;
   CompScalars<T> s = a.sc[c];
   if (s.done) return;
-  T q[4];
+  T q[4] = {0, 0, 0, 0};
+  for (int b = threadIdx.x; b < a.nparts; b += kBlock) {       // (four independent loads in flight per pass)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    T v = 0;
-    for (int b = threadIdx.x; b < kBiParts; b += kBlock) v += a.parts[(c * 4 + k) * kBiParts + b];
-    q[k] = v;
+    for (int k = 0; k < 4; ++k) q[k] += a.parts[(c * 4 + k) * kBiParts + b];
   }
   block_sum<T, 4>(q, smem);
   if (threadIdx.x != 0) return;
@@ -626,6 +625,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   if (gv > kBiParts) gv = kBiParts;
   if (gv < 1) gv = 1;
   const dim3 grid_v(gv, 2);
+  a.nparts = gv;
   const int nbmax = g.nb[0] > g.nb[1] ? g.nb[0] : g.nb[1];
   const dim3 grid_b(nbmax, 2);
   const int Wmax = nx + 1;

@@ -29,7 +29,7 @@ struct Ctl {
   int* xcc;                           // out: XCC id per block
 };
 
-// ---------------- V0: counter + fence + partials (what cg_persist.h does today)
+// ---------------- V0: counter + fence + partials (the first version of cg_persist.h; kept as the baseline of the comparison)
 __device__ void exch_v0(const Ctl& c, double (&v)[3], unsigned epoch, double* smem) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int q = 0; q < 3; ++q) v[q] = wave_sum(v[q]);
