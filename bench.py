@@ -94,7 +94,7 @@ def run_unrolled(P, steps, stats=None):
     ext = dp.Material.extrapolation_mode(P["domain"].boundaries)
     velocity = dp.StaggeredGrid(vel_t, P["domain"].box, extrapolation=ext)
     pressure = dp.CenteredGrid(p_t, P["domain"].box, dp.pressure_extrapolation(P["domain"].boundaries))
-    vels, ps, vn, pn, warn = dp.run_piso_steps(velocity, pressure, P["dt"], P["sim"], step_count=steps)
+    vels, ps, vn, pn, warn = dp.unroll_piso_steps(velocity, pressure, P["dt"], P["sim"], step_count=steps)
     loss = 0.5 * (vn.staggered_tensor() ** 2).sum()
     loss.backward()
     return vel_t.grad, float(loss.detach()), warn

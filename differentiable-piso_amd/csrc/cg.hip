@@ -1,6 +1,7 @@
 // Host driver of the single-GPU pressure CG (kernels: cg_kernels.h).  See cg_kernels.h for the design.
 #include "cg_kernels.h"
 #include "cg_persist.h"
+#include "options.h"
 #include <cstdio>
 #include <vector>
 
@@ -20,7 +21,9 @@ constexpr size_t kPersistWsWords = (size_t)2 * kPersistMaxGrid * 16 + 64;   // r
 struct HostPoll {
   CgState* pinned = nullptr;   // [2]
   hipEvent_t ev[2] = {nullptr, nullptr};
+  hipEvent_t seg_ev[2] = {nullptr, nullptr};   // timing events around persistent segments (profiling only; created once)
 };
+static int g_persist_fallbacks = 0;            // solves that were restarted on the two-kernel path after an exchange timed out
 static thread_local HostPoll tl_poll;
 
 static int ensure_poll() {
@@ -44,6 +47,16 @@ static size_t cg_workspace_bytes(int nx, int ny) {
   return b + 4096;
 }
 
+template <typename T, typename CT, bool RECON, bool SYMV>
+static const void* persist_kernel(int R) {
+  switch (R) {
+    case 2: return reinterpret_cast<const void*>(&cg_persist<T, CT, 2, 2, RECON, SYMV>);
+    case 4: return reinterpret_cast<const void*>(&cg_persist<T, CT, 4, 2, RECON, SYMV>);
+    case 8: return reinterpret_cast<const void*>(&cg_persist<T, CT, 8, 2, RECON, SYMV>);
+    default: return reinterpret_cast<const void*>(&cg_persist<T, CT, 16, 1, RECON, SYMV>);
+  }
+}
+
 struct EventPool {
   static constexpr int kMax = 64;
   hipEvent_t start[2][kMax], stop[2][kMax];
@@ -54,18 +67,18 @@ static thread_local EventPool tl_events;
 
 template <typename T, typename CT, int V, bool RECON>
 static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accuracy, int max_iterations, int rank_deficient, int reset, int fixed,
-                  int* iterations_out, float* kernel_ms_out, hipStream_t stream) {
+                  int* iterations_out, float* kernel_ms_out, hipStream_t stream, bool allow_persist = true) {
   const int nx = a.nx, ny = a.ny;
   const size_t n = (size_t)nx * ny;
   a.ntx = (nx + 64 * V - 1) / (64 * V);
   int rpw = (int)(((long long)ny * a.ntx) / (4 * 1024));
   rpw = rpw < 2 ? 2 : (rpw > 16 ? 16 : rpw);
-  if (const char* e = getenv("PISO_CG_RPW")) { const int o = atoi(e); if (o > 0) rpw = o; }   // tuning knob
+  if (opt(OPT_CG_RPW) > 0) rpw = opt(OPT_CG_RPW);                                             // tuning knob
   a.rows_per_wave = rpw;
   a.nty = (ny + 4 * rpw - 1) / (4 * rpw);
   a.accuracy = fixed ? -1.0f : accuracy;                 // fixed-work mode: the test can never succeed
   int cap = 1024;
-  if (const char* e = getenv("PISO_CG_MAXBLOCKS")) { const int o = atoi(e); if (o >= 8 && o <= kMaxPartials) cap = o; }
+  if (opt(OPT_CG_MAXBLOCKS) >= 8 && opt(OPT_CG_MAXBLOCKS) <= kMaxPartials) cap = opt(OPT_CG_MAXBLOCKS);
   const int g1 = grid_for((long long)a.ntx * a.nty, 1, cap);
   const int g2 = grid_for((long long)((n / V + kBlock - 1) / kBlock), 4);
   a.nA = g1; a.nB = g2;
@@ -109,24 +122,24 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   int persist_R = 0, persist_NQ = 0, persist_grid = 0;
   PersistCtl pc;
   pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr;
-  if (V == 16 / (int)sizeof(T) && a.per_y != 2 && !getenv("PISO_CG_NO_PERSIST")) {
+  const int force = opt(OPT_CG_PERSIST), force_r = opt(OPT_CG_PERSIST_R);   // -1: automatic
+  if (V == 16 / (int)sizeof(T) && a.per_y != 2 && allow_persist && force != 0) {
     int dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int ntx = nx / (64 * V);
-    const char* force_r = getenv("PISO_CG_PERSIST_R");       // tests: force the region height
     if (nx % (64 * V) == 0) {                               // every lane of a strip has cells
       // one region of 16 rows per wave has the smallest halo overhead; taken when it keeps at least 3/4 of the waves busy
-      if (ny % 16 == 0 && (!force_r || atoi(force_r) == 16)) {
+      if (ny % 16 == 0 && (force_r <= 0 || force_r == 16)) {
         const long long nreg = (long long)ntx * (ny / 16);
-        if (nreg <= (long long)cus * kPersistWaves && (force_r || 4 * nreg >= 3LL * cus * kPersistWaves)) {
+        if (nreg <= (long long)cus * kPersistWaves && (force_r > 0 || 4 * nreg >= 3LL * cus * kPersistWaves)) {
           persist_R = 16; persist_NQ = 1; pc.nreg = (int)nreg; pc.ntx = ntx;
           persist_grid = (int)((nreg + kPersistWaves - 1) / kPersistWaves);
         }
       }
       for (int R : {2, 4, 8}) {
         if (persist_R) break;
-        if (force_r && atoi(force_r) != R) continue;
+        if (force_r > 0 && force_r != R) continue;
         if (ny % R != 0) continue;                          // every region has R rows
         const long long nreg = (long long)ntx * (ny / R);
         if (nreg % 2 == 0 && nreg <= (long long)cus * kPersistWaves * 2) {   // a wave owns 2 regions or none
@@ -135,16 +148,27 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
         }
       }
     }
-    const char* force = getenv("PISO_CG_PERSIST");
-    if (persist_R && n < 16384 && !(force && atoi(force) == 1)) persist_R = 0;    // tiny grids: two-kernel path
-    if (force && atoi(force) == 0) persist_R = 0;
+    if (persist_R && n < 16384 && force != 1) persist_R = 0;    // tiny grids: two-kernel path
+  }
+  if (persist_R) {
+    // the exchanges spin: EVERY workgroup must be resident at the same time.  What the occupancy calculator says one CU can
+    // hold (LDS, registers) times the CUs of the device must cover the grid; what it cannot see (another process, a CU mask)
+    // is caught by the spin bound -> restart on the two-kernel path (below).
+    constexpr bool kCanSymO = RECON && sizeof(CT) == 4;
+    const void* kfn = persist_kernel<T, CT, RECON, false>(persist_R);
+    if constexpr (kCanSymO) { if (symmetric) kfn = persist_kernel<T, CT, RECON, true>(persist_R); }
+    int per_cu = 0, dev = 0, cus = 0;
+    PISO_HIP_CHECK(hipGetDevice(&dev));
+    PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    PISO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPersistThreads, 0));
+    if ((long long)per_cu * cus < persist_grid) persist_R = 0;
   }
   if (persist_R) {
     pc.rec = reinterpret_cast<unsigned long long*>(persist_ws);
     pc.err = reinterpret_cast<int*>(persist_ws + kPersistWsWords - 16);
     PISO_HIP_CHECK(hipMemsetAsync(persist_ws, 0, kPersistWsWords * sizeof(unsigned), stream));
     if (persist_grid > kPersistMaxGrid) persist_R = 0;
-    if (getenv("PISO_CG_PERSIST_TIMING")) {               // diagnostics only: per-phase clocks of every workgroup
+    if (kPersistDiag && opt_on(OPT_CG_PERSIST_TIMING)) {   // diagnostic builds only: per-phase clocks of every workgroup
       PISO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&pc.timing), 12 * persist_grid * sizeof(unsigned long long)));
       PISO_HIP_CHECK(hipMemsetAsync(pc.timing, 0, 12 * persist_grid * sizeof(unsigned long long), stream));
     }
@@ -173,9 +197,9 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   };
   int seg_len = (int)(20000.0 / ((double)n * 8.5e-6 + 4.0));   // ~20 ms of work per segment (one host look per segment)
   seg_len = seg_len < 50 ? 50 : (seg_len > 2000 ? 2000 : seg_len);
-  if (const char* e = getenv("PISO_CG_SEGMENT")) { const int o = atoi(e); if (o > 0) seg_len = o; }
-  hipEvent_t seg_ev[2] = {nullptr, nullptr};
-  if (persist_R && prof) { PISO_HIP_CHECK(hipEventCreate(&seg_ev[0])); PISO_HIP_CHECK(hipEventCreate(&seg_ev[1])); }
+  if (opt(OPT_CG_SEGMENT) > 0) seg_len = opt(OPT_CG_SEGMENT);
+  hipEvent_t* seg_ev = tl_poll.seg_ev;
+  if (persist_R && prof && !seg_ev[0]) { PISO_HIP_CHECK(hipEventCreate(&seg_ev[0])); PISO_HIP_CHECK(hipEventCreate(&seg_ev[1])); }
   double seg_ms = 0; long long seg_iters = 0, seg_launches = 0;
   for (int k = 0; k < total && !finished; ++k) {
     const bool is_reset = !fixed && ((k + 1) % reset == 0);
@@ -192,7 +216,14 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
         int herr = 0;
         PISO_HIP_CHECK(hipMemcpyAsync(&herr, pc.err, sizeof(int), hipMemcpyDeviceToHost, stream));
         PISO_HIP_CHECK(hipStreamSynchronize(stream));
-        if (herr) { set_error_msg("piso_cg_solve: grid barrier of the persistent CG kernel timed out"); return PISO_ERR_HIP; }
+        if (herr) {
+          // A grid-wide exchange gave up: some workgroups were not resident (another kernel or process holds CUs).  The
+          // segment's state is unusable; the two-kernel path needs no co-residency: run the whole solve again on it.
+          ++g_persist_fallbacks;
+          if (pc.timing) { PISO_HIP_CHECK(hipFree(pc.timing)); pc.timing = nullptr; }
+          return cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out,
+                                         kernel_ms_out, stream, false);
+        }
         if (prof) { float t = 0; PISO_HIP_CHECK(hipEventElapsedTime(&t, seg_ev[0], seg_ev[1])); seg_ms += t; seg_iters += ke - k; ++seg_launches; }
         if (tl_poll.pinned[0].done) { finished = true; stop_it = tl_poll.pinned[0].iterations; }
         k_last = ke - 1;
@@ -312,7 +343,7 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   a.ntx = a.nty = a.rows_per_wave = 0; a.nA = a.nB = 0; a.accuracy = accuracy;
   a.gA = nullptr; a.gB = nullptr;
   a.nt = 0;
-  if (const char* e = getenv("PISO_CG_NT")) a.nt = atoi(e);
+  if (opt(OPT_CG_NT) > 0) a.nt = opt(OPT_CG_NT);
   if (!ar.ok()) { set_error_msg("piso_cg_solve: workspace too small"); return PISO_ERR_INVALID_ARG; }
 
   PISO_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(int), stream));
@@ -327,9 +358,9 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
     PISO_HIP_CHECK(hipMemcpyAsync(hflags, flags, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
     PISO_HIP_CHECK(hipStreamSynchronize(stream));
   }
-  if (getenv("PISO_CG_NO_COMPACT")) hflags[0] = hflags[1] = 1;      // tuning / test knob: plain T coefficients
-  if (getenv("PISO_CG_NO_RECON")) hflags[1] = 1;
-  if (getenv("PISO_CG_NO_SYM")) hflags[2] = 1;
+  if (opt_on(OPT_CG_NO_COMPACT)) hflags[0] = hflags[1] = 1;         // tuning / test knob: plain T coefficients
+  if (opt_on(OPT_CG_NO_RECON)) hflags[1] = 1;
+  if (opt_on(OPT_CG_NO_SYM)) hflags[2] = 1;
   const bool symmetric = !hflags[2];
   constexpr int VMID = 16 / sizeof(T);
   const bool aligned = ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(x_out)) & 15) == 0;
@@ -385,6 +416,8 @@ void piso_cg_profile_enable(int enable, int stride) {
   if (stride > 0) g_prof.stride = stride;
   for (int q = 0; q < 4; ++q) { g_prof.ms[q] = 0; g_prof.count[q] = 0; }
 }
+
+int piso_cg_persist_fallbacks(void) { return g_persist_fallbacks; }
 
 void piso_cg_profile_read(double* ms_sum, long long* count) {
   for (int q = 0; q < 4; ++q) { ms_sum[q] = g_prof.ms[q]; count[q] = g_prof.count[q]; }

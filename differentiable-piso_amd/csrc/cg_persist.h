@@ -19,26 +19,12 @@
 #pragma once
 #include "cg_kernels.h"
 
-// scheduling fences of the two row loops (experiments: -DPISO_SB_MODE=0 none, 1 only around the refill loads, 2 default)
-#ifndef PISO_SB_MODE
-#define PISO_SB_MODE 2
-#endif
-#if PISO_SB_MODE == 2
+// scheduling fences of the two row loops (measured: with / without them the iteration time is the same; they keep the
+// register allocation of the unrolled loops predictable)
 #define PISO_SB_A1 __builtin_amdgcn_sched_barrier(0)
 #define PISO_SB_A2 __builtin_amdgcn_sched_barrier(0)
 #define PISO_SB_B1 __builtin_amdgcn_sched_barrier(0)
 #define PISO_SB_B2 __builtin_amdgcn_sched_barrier(0)
-#elif PISO_SB_MODE == 1
-#define PISO_SB_A1 __builtin_amdgcn_sched_barrier(0)
-#define PISO_SB_A2 (void)0
-#define PISO_SB_B1 __builtin_amdgcn_sched_barrier(0)
-#define PISO_SB_B2 (void)0
-#else
-#define PISO_SB_A1 (void)0
-#define PISO_SB_A2 (void)0
-#define PISO_SB_B1 (void)0
-#define PISO_SB_B2 (void)0
-#endif
 
 namespace piso {
 
@@ -137,9 +123,6 @@ __device__ __forceinline__ bool grid_exchange(const PersistCtl& c, T (&v)[3], un
       const int vq = lane >> 1;
       const u64 bits = (u64)__double_as_longlong((double)(vq == 0 ? s[0] : (vq == 1 ? s[1] : s[2])));
       const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
-#ifdef PISO_PERSIST_FENCE
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // experiment: explicit L2 write-back before publishing
-#endif
       if (lane < 6) __hip_atomic_store(rec + (size_t)blockIdx.x * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     between(rec);
@@ -336,6 +319,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   __shared__ T xs[kPersistWaves * NQ * R * 64 * V];        // the solution of my regions (128 KB at 16 rows per wave, fp64)
   __shared__ T smem[64];
   __shared__ int nbr_s[kPersistWaves * 8];                   // per wave: record slots of the (up to 4 NQ) neighbouring workgroups
+  __shared__ int bad_s;                                      // a neighbour poll gave up (read after the exchange's last barrier)
   // p_new on the rows below / above my regions (rebuilt from the neighbours' perimeters in phase A, used by the first / last
   // row of both phases): parked in LDS, two reads per phase, instead of 8 registers held through both row loops
   constexpr bool kParkHalos = (NQ * R < 16) || NQ == 1;     // (two regions of 8 rows: x already fills the LDS)
@@ -444,10 +428,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   auto issue_coef = [&](int t) __attribute__((always_inline)) {
     const int q = t / R, jj = t - q * R;
     const unsigned vCq = coef_offset(q);
-#if defined(PISO_ABLATE) && PISO_ABLATE == 4
-    { for (int e = 0; e < V; ++e) { cS[t].v[e] = (CT)1; cW[t].v[e] = (CT)1; cE[t].v[e] = (CT)1; cN[t].v[e] = (CT)1; cD[t].v[e] = (T)-4; }
-      if (jj == 0) eW[q] = (CT)1; if (jj == R - 1) for (int e = 0; e < V; ++e) cSh[q].v[e] = (CT)1; return; }
-#endif
     const unsigned sT = (unsigned)(j0[q] + jj) * rowT, sC = (unsigned)(j0[q] + jj) * rowC;
     cS[t] = bld<CT, V>(RoS, vCq, sC); cW[t] = bld<CT, V>(RoW, vCq, sC);
     if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vCq, sC); cN[t] = bld<CT, V>(RoN, vCq, sC); }
@@ -476,9 +456,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   // both call this on the same registers, so they see bitwise the same z'.
   auto zrow = [&](int t) __attribute__((always_inline)) -> Vec<T, V> {
     const int q = t / R, jj = t - q * R;
-#if defined(PISO_ABLATE) && PISO_ABLATE == 3
-    { Vec<T, V> z0; for (int e = 0; e < V; ++e) z0.v[e] = pp[q][jj].v[e] * (T)cS[t].v[e]; return z0; }
-#endif
     T* hs = halo_s + (kParkHalos ? (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V : 0);
     const Vec<T, V> behind = (jj > 0) ? pp[q][jj > 0 ? jj - 1 : 0] : (kParkHalos ? ldv<T, V>(hs) : pnb[q]);
     const Vec<T, V> cur = pp[q][jj];
@@ -521,9 +498,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   };
   // perimeter of row jj of region q (what neighbouring regions read): the whole first / last row, else the two end cells
   auto publish = [&](rsrc_t Rd, int q, int jj, const Vec<T, V>& val) __attribute__((always_inline)) {
-#if defined(PISO_ABLATE) && PISO_ABLATE == 1
-    return;
-#endif
     const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
     if (jj == 0 || jj == R - 1) {
       bst<T, V, kAgent>(Rd, vT[q], sT, val);
@@ -547,12 +521,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
       if (cc < 0) cc = a.per_x ? nx - 1 : -1;
       else if (cc >= nx) cc = a.per_x ? 0 : -1;
       const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
-#if defined(PISO_ABLATE) && PISO_ABLATE == 2
-      eP[q] = 0; eR[q] = 0;
-      for (int e = 0; e < V; ++e) { hbR[q].v[e] = 0; hbP[q].v[e] = 0; haR[q].v[e] = 0; haP[q].v[e] = 0; }
-      (void)vo;
-      continue;
-#endif
       eP[q] = bld1<T, kAgent>(Rp, vo, 0);
       eR[q] = bld1<T, kAgent>(Rr, vo, 0);
       bool vb, va;
@@ -587,6 +555,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     }
   }
   if (lane < 8) nbr_s[wave * 8 + lane] = nbr_slot;           // (parked in LDS: read once per iteration, not worth a register)
+  if (threadIdx.x == 0) bad_s = 0;
   unsigned fetch_epoch = 0;
   rsrc_t fetch_rp = Rp0;
   auto fetch_halos = [&](const unsigned long long* rec) __attribute__((always_inline)) {
@@ -594,11 +563,15 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     unsigned spins = 0;
     const int slot = nbr_s[wave * 8 + (lane & 7)];
     const bool mine = lane < 4 * NQ && slot >= 0;
-    while (true) {                                          // (a give-up here is harmless: the global exchange then fails too)
+    while (true) {
       bool ok = true;
       if (mine)
         ok = (unsigned)(__hip_atomic_load(rec + (size_t)slot * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffffull) == fetch_epoch;
-      if (__all(ok) || ++spins > (1u << 20)) break;
+      if (__all(ok)) break;
+      if (++spins > (1u << 22)) {                           // same bound as the global exchange; a give-up FAILS the launch:
+        if (lane == 0) { bad_s = 1; *c.err = 1; }           // the halos below would be stale (the host restarts on cg_k1 / cg_k2)
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
     issue_halos(fetch_rp);
@@ -631,10 +604,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     T sA[3] = {0, 0, 0};
     if (has[0]) {                                          // the host makes nreg a multiple of NQ: a wave owns NQ regions or none
       if (!have_halos) issue_halos(Rpin);                  // (first iteration of a launch; later ones were fetched in exchange B)
-#if defined(PISO_ABLATE) && PISO_ABLATE == 5
-      __builtin_amdgcn_s_waitcnt(0);                       // timing experiment: how long do the halo loads alone take?
-      tick(4);
-#endif
       // meanwhile, on chip: the new direction; its perimeter goes out for iteration k+1
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -721,6 +690,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
       fetch_epoch = epoch;
       fetch_rp = Rpout;                                    // iteration k+1 reads the direction this iteration published
       healthy = grid_exchange<T, (D < NT) ? kBaseLoads : 0, kHybridPoll>(c, sB, epoch, smem, fetch_halos);
+      healthy = healthy && (__builtin_amdgcn_readfirstlane(bad_s) == 0);
       have_halos = true;
     } else {
       healthy = grid_exchange<T, (D < NT) ? kBaseLoads : 0, kHybridPoll>(c, sB, epoch, smem);

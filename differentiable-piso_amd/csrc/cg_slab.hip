@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "cg_kernels.h"
+#include "options.h"
 
 namespace piso {
 
@@ -300,8 +301,8 @@ static int slab_solve(std::vector<SlabRank<T>>& R, Comm<T>& comm, int nx, int ny
   T hg[3];
   PISO_HIP_CHECK(hipMemcpyAsync(hg, R[0].g + 8, 3 * sizeof(T), hipMemcpyDeviceToHost, stream));
   PISO_HIP_CHECK(hipStreamSynchronize(stream));
-  const bool f32ok = sizeof(T) == 8 && hg[1] == 0 && !getenv("PISO_CG_NO_COMPACT");
-  const bool recon = f32ok && hg[2] == 0 && !getenv("PISO_CG_NO_RECON");
+  const bool f32ok = sizeof(T) == 8 && hg[1] == 0 && !opt_on(OPT_CG_NO_COMPACT);
+  const bool recon = f32ok && hg[2] == 0 && !opt_on(OPT_CG_NO_RECON);
   for (int q = 0; q < nloc; ++q) {
     SlabRank<T>& k = R[q];
     const int gflat = grid_for((long long)n, kBlock * 4);

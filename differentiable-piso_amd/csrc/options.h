@@ -1,0 +1,25 @@
+// Tuning / test knobs of libpiso_hip.so.  Every knob has a default taken ONCE, when the library is loaded, from the
+// environment variable PISO_<NAME> (upper case); afterwards only piso_set_option() changes it.  -1 = "not set / automatic".
+#pragma once
+
+namespace piso {
+
+enum Opt {
+  OPT_CG_PERSIST = 0,      // 0 forbid / 1 force the persistent CG kernel (default: by grid size)
+  OPT_CG_PERSIST_R,        // rows per region of the persistent kernel: 2 | 4 | 8 | 16
+  OPT_CG_SEGMENT,          // CG iterations per persistent launch
+  OPT_CG_EXCHANGES,        // grid-wide exchanges per persistent iteration: 1 (merged reductions) | 2 (reference recurrences)
+  OPT_CG_PERSIST_TIMING,   // per-phase clocks of the persistent kernel (diagnostic builds only)
+  OPT_CG_RPW,              // two-kernel path: rows per wave of K1
+  OPT_CG_MAXBLOCKS,        // two-kernel path: grid cap of K1
+  OPT_CG_NT,               // two-kernel path: non-temporal access bits
+  OPT_CG_NO_COMPACT,       // keep the off-diagonals in T (no exact-float32 compression)
+  OPT_CG_NO_RECON,         // read the diagonal instead of recomputing it
+  OPT_CG_NO_SYM,           // stream all four off-diagonal arrays even if the matrix is symmetric
+  OPT_COUNT
+};
+
+int opt(Opt o);                       // current value (-1 = not set)
+inline bool opt_on(Opt o) { return opt(o) > 0; }
+
+}  // namespace piso

@@ -15,7 +15,7 @@ from .grids import (AABox, CLOSED, NO_SLIP, NO_STICK, OPEN, PERIODIC, SLIPPERY, 
                     StaggeredGrid, as_tensor, box, default_device, placeholder, stack_staggered_components,
                     unstack_staggered_tensor)
 from .piso import Physics, SimulationParameters, advection_matrix_cuda, explicit_H_csr, piso_step, pressure_extrapolation
-from .solvers import (LinearSolver, LinearSolverCudaMultiBicgstabILU, LinearSolverHipMultiBicgstabILU,
+from .solvers import (LinearSolver, LinearSolverCudaMultiBicgstabILU, LinearSolverHipMultiBicgstabILU, LinearSolverScipy,
                       PisoPressureSolverCudaCustom, PisoPressureSolverHip, PoissonSolver)
 from .stencils import (arrange_rhs_term_tf, calculate_centered_shape, calculate_staggered_shape, convert_to_scipy_csr,
                        custom_padded, finite_volume_divergence, finite_volume_gradient_tensor, flatten_staggered_data,
@@ -27,6 +27,6 @@ from .losses import L2_field_loss, multistep_averaging_loss, spectral_energy_los
 from .setups import (compute_mixingLayer_masks, spatialMixingLayer_setup, sponge_viscosity_field, temporal_mixing_layer_masks,
                      update_dirichlet_values)
 from .training import boundary_perturbation_fun, training_run
-from .unroll import run_piso_steps, zero_gradient_op
+from .unroll import run_piso_steps, unroll_piso_steps, zero_gradient_op
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -10,7 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpiso_hip.so")
+# PISO_HIP_LIB: load another BUILD of the same library (A/B timing of kernel variants, scripts/sweep_*.sh) instead of
+# overwriting the product library in place.  It is not a fallback: the file must exist and export the same C ABI.
+LIB_PATH = os.environ.get("PISO_HIP_LIB") or os.path.join(_HERE, "libpiso_hip.so")
 
 if not os.path.isfile(LIB_PATH):
     raise ImportError('HIP binaries not found at %s. Run "python differentiable-piso_amd/build_native.py" '
@@ -24,6 +26,11 @@ _ip = C.POINTER(C.c_int)
 lib.piso_version.restype = C.c_char_p
 lib.piso_last_error_string.restype = C.c_char_p
 lib.piso_device_count.restype = _i
+lib.piso_set_option.argtypes = [C.c_char_p, _i]
+lib.piso_set_option.restype = _i
+lib.piso_get_option.argtypes = [C.c_char_p, _ip]
+lib.piso_get_option.restype = _i
+lib.piso_cg_persist_fallbacks.restype = _i
 lib.piso_csr_nnz.argtypes = [_i, _i, _i, _i, _ip, _ip]
 lib.piso_csr_nnz.restype = None
 lib.piso_assemble_csr.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _f, _vp]
@@ -69,6 +76,19 @@ class PisoNativeError(RuntimeError):
     pass
 
 
+def set_option(name, value):
+    """Tuning / test knob of the library (include/piso_hip.h: piso_set_option); -1 = automatic."""
+    if lib.piso_set_option(name.encode(), int(value)) != 0:
+        raise PisoNativeError("unknown libpiso_hip option %r" % name)
+
+
+def get_option(name):
+    v = C.c_int(0)
+    if lib.piso_get_option(name.encode(), C.byref(v)) != 0:
+        raise PisoNativeError("unknown libpiso_hip option %r" % name)
+    return v.value
+
+
 def check(status, what):
     if status != 0:
         raise PisoNativeError("%s failed with status %d: %s" % (what, status, lib.piso_last_error_string().decode()))
@@ -82,6 +102,10 @@ def ptr(t):
         raise PisoNativeError("libpiso_hip needs device tensors; got a %s tensor (no CPU fallback exists)" % t.device)
     if not t.is_contiguous():
         raise PisoNativeError("non-contiguous tensor passed to libpiso_hip")
+    if t.device.index != torch.cuda.current_device():
+        # the kernels are launched on the CURRENT device's stream: a tensor of another GPU would be a wild pointer there
+        raise PisoNativeError("tensor lives on %s but the current HIP device is cuda:%d (wrap the call in "
+                              "`with torch.cuda.device(t.device)`)" % (t.device, torch.cuda.current_device()))
     return C.c_void_p(t.data_ptr())
 
 

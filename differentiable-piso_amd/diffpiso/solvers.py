@@ -2,6 +2,7 @@
 
 Same class surface as the reference (diffpiso/linear_solver.py, diffpiso/piso_cuda_pressure_solver.py):
   LinearSolver                              base type                               (linear_solver.py:15-30)
+  LinearSolverScipy                         host-side direct solve, cross-check only   (linear_solver.py:33-57)
   LinearSolverCudaMultiBicgstabILU          u+v ILU(0)-BiCGStab, adjoint = A^T solve  (linear_solver.py:113-178)
   PisoPressureSolverCudaCustom              A0-weighted 5-diagonal CG, adjoint = same solve (piso_cuda_pressure_solver.py:36-114)
 The adjoint linear solves are `torch.autograd.Function` nodes (the reference uses tf.custom_gradient).
@@ -41,6 +42,46 @@ def _scalar(v):
     return float(v)
 
 
+class _ScipySolveFn(torch.autograd.Function):
+    """solve_call of LinearSolverScipy (diffpiso/linear_solver.py:45-54): direct sparse solve on the host, gradient w.r.t. the
+    right-hand side = solve with the transposed matrix."""
+
+    @staticmethod
+    def _solve(mv, ci, rp, rhs, transpose):
+        import scipy.sparse
+        import scipy.sparse.linalg
+        m = scipy.sparse.csr_matrix((mv.detach().cpu().numpy(), ci.detach().cpu().numpy(), rp.detach().cpu().numpy()))
+        if transpose:
+            m = m.transpose()
+        x = scipy.sparse.linalg.spsolve(m.tocsr(), rhs.detach().cpu().numpy().reshape(-1))
+        return torch.as_tensor(np.asarray(x, dtype=np.float32), device=rhs.device)
+
+    @staticmethod
+    def forward(ctx, rhs, mv, ci, rp, transpose):
+        ctx.save_for_backward(mv, ci, rp)
+        ctx.transpose = transpose
+        return _ScipySolveFn._solve(mv, ci, rp, rhs, transpose)
+
+    @staticmethod
+    def backward(ctx, ds):
+        mv, ci, rp = ctx.saved_tensors
+        return _ScipySolveFn._solve(mv, ci, rp, ds, not ctx.transpose), None, None, None, None
+
+
+class LinearSolverScipy(LinearSolver):
+    """diffpiso/linear_solver.py:33-57: scipy.sparse.linalg.spsolve on ONE CSR matrix, on the host (the reference's manual
+    cross-check for the CUDA solvers; it wraps it in tf.py_function).  It is a CPU solver by design, exactly as in the
+    reference -- `piso_step` never selects it by itself and the HIP solvers never fall back to it."""
+
+    def __init__(self):
+        LinearSolver.__init__(self, "Scipy Solver for sparse matrix", supported_devices="CPU", supports_guess=False,
+                              supports_batch=False, solver_type="-", input_format="csr")
+
+    def solve(self, matrix_values, row_ptr, col_indices, rhs, transpose=False):
+        return _ScipySolveFn.apply(rhs.reshape(-1), matrix_values.reshape(-1), col_indices.reshape(-1), row_ptr.reshape(-1),
+                                   bool(transpose))
+
+
 def multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn):
     """One call of piso_multi_bicgstab_ilu_{f32,f64}. Returns (x, iterations[2]); sets warn[0] in place on NaN input."""
     dt = values.dtype
@@ -70,15 +111,17 @@ class _LinearSolveFn(torch.autograd.Function):
         x, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, solver.max_iterations,
                                            transpose, solver.band_rows, warn)
         solver.last_iterations = its
-        ctx.save_for_backward(values, row_ptr, col_indices, x0)
+        # the reference's backward op receives the SAME warn buffer the forward op aliased and mutated
+        # (linear_solver.py:165-173, multi_bicgstab_ilu_linear_solve_op.cc:136-140): a forward warning zeroes the gradient
+        ctx.save_for_backward(values, row_ptr, col_indices, x0, warn.clone())
         ctx.meta = (solver, nx, ny, transpose)
         return x.to(torch.float32), warn.to(torch.float32)
 
     @staticmethod
     def backward(ctx, ds, dw):
-        values, row_ptr, col_indices, x0 = ctx.saved_tensors
+        values, row_ptr, col_indices, x0, warn_fwd = ctx.saved_tensors
         solver, nx, ny, transpose = ctx.meta
-        warn_b = torch.zeros(1, dtype=torch.uint8, device=ds.device)
+        warn_b = warn_fwd.clone()
         tol = _scalar(solver.accuracy)
         df, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, ds.to(values.dtype), x0, nx, ny, tol,
                                             solver.max_iterations, not transpose, solver.band_rows, warn_b)

@@ -8,7 +8,6 @@ import os
 import numpy as np
 import torch
 
-from .closure import make_forcing_fn
 from .datamanagement import data_path_assembler, load_function, make_dataset
 from .grids import CenteredGrid, StaggeredGrid
 from .setups import update_dirichlet_values
@@ -59,26 +58,34 @@ class _Run(object):
                 CenteredGrid(p.data, self.pressure.box, self.pressure.extrapolation))
 
     def forward(self, velocity, pressure, inlet_perturbation=None):
+        """The graph-construction call of training_run (:54-56) evaluated eagerly: run_piso_steps with the reference's 14
+        arguments; `inlet_perturbation` (one [1,Ny+2,1,1] array per step) stands where the reference feeds bc_placeholders."""
         td = self.td
-        update = None
-        if inlet_perturbation is not None:                   # time-dependent inflow (:440-441): bcx + perturbation of step i
-            def update(i, dirichlet_values):
-                bc = torch.as_tensor(self.bcx + inlet_perturbation[i], dtype=torch.float32, device=self.device)
-                return update_dirichlet_values(torch.as_tensor(self.base_dirichlet, dtype=torch.float32, device=self.device),
-                                               ((False, False), (True, False)), ((None, None), (bc, None)))
         wrapper = td.get("network_wrapper")
-        if wrapper is not None:
+        if wrapper is None:
+            def wrapper(net, nn_in, *_):
+                return net(nn_in)
+        else:
             # the reference calls neural_network_wrapper(network, input, fluid, physical_parameters, simulation_parameters,
-            # loss_buffer_width, buffer_width) (:446-449); two-argument wrappers (network, input) are accepted as well
+            # loss_buffer_width, buffer_width) (:403, :449); two-argument wrappers (network, input) are accepted as well
             import inspect
             user = wrapper
-            if len(inspect.signature(user).parameters) > 2:
-                def wrapper(net, nn_in, _u=user):
-                    return _u(net, nn_in, self.velocity, self.pp, self.sp, self.loss_buffer_width, self.buffer_width)
-        forcing = make_forcing_fn(self.network, pressure_included=td.get("pressure_included", True), wrapper=wrapper)
-        return run_piso_steps(velocity, pressure, self.sp["dt"] * self.sp["dt_ratio"], self.sim_physics,
-                              step_count=td["step_count"], loss_influence_range=td.get("loss_influence_range"),
-                              viscosity_field=self.viscosity_field, forcing_fn=forcing, dirichlet_update_fn=update)
+            if len(inspect.signature(user).parameters) <= 2:
+                def wrapper(net, nn_in, *_, _u=user):
+                    return _u(net, nn_in)
+        placeholders, update = None, None
+        if inlet_perturbation is not None:                   # time-dependent inflow (:440-441): bcx + perturbation of step i
+            placeholders = torch.as_tensor(np.stack(inlet_perturbation), dtype=torch.float32, device=self.device)
+            update = self.sp.get("placeholder_update") or (
+                lambda dv, pl: update_dirichlet_values(dv, ((False, False), (True, False)), pl))
+        self.sim_physics.dirichlet_values = torch.as_tensor(self.base_dirichlet, dtype=torch.float32, device=self.device)
+        td_run = dict(td)
+        td_run.setdefault("pressure_included", True)
+        td_run.setdefault("loss_influence_range", td["step_count"] + 1)
+        out = run_piso_steps(velocity, pressure, self.domain, self.pp, self.sp, td_run, self.network, wrapper,
+                             self.sim_physics, self.viscosity_field, self.bcx, placeholders, update, self.loss_buffer_width)
+        velocity_all_steps, pressure_all_steps, _, velnew, pnew, _, warn, _, _ = out
+        return velocity_all_steps, pressure_all_steps, velnew, pnew, warn
 
     def loss(self, steps, target):
         td = self.td

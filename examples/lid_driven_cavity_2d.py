@@ -51,12 +51,17 @@ def run(n=128, reynolds=1000, dt=0.01, steps=2500, out=None, save_every=100, ver
         for i in range(steps):
             # the reference tightens the predictor tolerance once the start-up transient is over
             sim.linear_solver.accuracy = 1e-3 if i < 100 else 1e-5
-            _, _, velocity, pressure, warn = dp.run_piso_steps(velocity, pressure, dt, sim, step_count=1)
+            # the reference's script calls piso_step directly (lid_driven_cavity_2d.py:57-61)
+            pressure_inc1 = dp.CenteredGrid(torch.zeros_like(pressure.data), pressure.box, pressure.extrapolation)
+            pressure_inc2 = dp.CenteredGrid(torch.zeros_like(pressure.data) + 1e-12, pressure.box, pressure.extrapolation)
+            vel_piso, pnew, warn = dp.piso_step(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, sim.dirichlet_values)
+            velocity = dp.StaggeredGrid(vel_piso.staggered_tensor(), velocity.box, extrapolation=velocity.extrapolation)
+            pressure = dp.CenteredGrid(pnew.data, pressure.box, pressure.extrapolation)
             if save_path and i % save_every == 0:
                 dp.save_frame(save_path + "/", "velocity", i // save_every, velocity.staggered_tensor().cpu().numpy())
                 dp.save_frame(save_path + "/", "pressure", i // save_every, pressure.data.cpu().numpy())
             if verbose and i % 50 == 0:
-                print("step %5d  max|u| %.4f  warn %s" % (i, float(velocity.staggered_tensor().abs().max()), bool(warn[0].any())))
+                print("step %5d  max|u| %.4f  warn %s" % (i, float(velocity.staggered_tensor().abs().max()), bool(warn.any())))
     return velocity, pressure
 
 

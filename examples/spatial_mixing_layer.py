@@ -39,13 +39,18 @@ def run(out=None, steps=1000, hr=(128, 512), box=None, perturbation_amp=(0.082, 
         save_path = dp.create_base_dir(out, "/mixingLayer_HRdata_pert%.3f-%.3f_%d-%d_" % (perturbation_amp + (ny, nx)))
         dp.save_frame(save_path + "/", "velocity", 0, velocity.staggered_tensor().cpu().numpy())
         dp.save_frame(save_path + "/", "pressure", 0, pressure.data.cpu().numpy())
-    base = torch.as_tensor(sp.dirichlet_values, dtype=torch.float32, device=dev)
+    dirichlet_placeholder_update = lambda dv, pl: dp.update_dirichlet_values(dv, ((False, False), (True, False)), pl)
     with torch.no_grad():
         for i in range(steps):
-            pert = inflow_perturbation(domain, phys["average_velocity"], bcx.shape, dt * i, perturbation_amp)
-            sp.dirichlet_values = dp.update_dirichlet_values(base, ((False, False), (True, False)),
-                                                             ((None, None), (torch.tensor(bcx + pert, dtype=torch.float32, device=dev), None)))
-            _, _, velocity, pressure, warn = dp.run_piso_steps(velocity, pressure, dt, sp, step_count=1, viscosity_field=viscosity_field)
+            # the reference feeds `bc_placeholders` [step_count, 1, Ny+2, 1, 1] per session run; here it is the tensor itself
+            bc_placeholders = torch.tensor(inflow_perturbation(domain, phys["average_velocity"], (1,) + bcx.shape, dt * i,
+                                                               perturbation_amp), dtype=torch.float32, device=dev)
+            # exactly the reference's call (spatial_mixing_layer.py:40-43)
+            velocity_all_steps, pressure_all_steps, nn_all_steps, velnew, pnew, NN_out, warn, velocity_all_arrays, pressure_all_arrays = \
+                dp.run_piso_steps(velocity, pressure, domain, phys, sim, None, None, None,
+                                  sp, viscosity_field, bcx, bc_placeholders,
+                                  dirichlet_placeholder_update=dirichlet_placeholder_update)
+            velocity, pressure = velnew, pnew
             if save_path:
                 dp.save_frame(save_path + "/", "velocity", i + 1, velocity.staggered_tensor().cpu().numpy())
                 dp.save_frame(save_path + "/", "pressure", i + 1, pressure.data.cpu().numpy())

@@ -44,6 +44,13 @@ const char* piso_version(void);
 const char* piso_last_error_string(void);
 /* Number of visible HIP devices (0 if none; never initialises a context). */
 int piso_device_count(void);
+/* Tuning / test knobs (no counterpart in the reference).  Each knob `name` takes its default ONCE, at library load, from the
+ * environment variable PISO_<NAME IN UPPER CASE>; -1 = not set (automatic).  Process-wide, not thread-safe against a
+ * concurrent solve.  Names: cg_persist (0 forbid / 1 force the persistent CG kernel), cg_persist_r (2|4|8|16 rows per region),
+ * cg_segment (iterations per persistent launch), cg_exchanges (1|2 grid exchanges per persistent iteration),
+ * cg_persist_timing, cg_rpw, cg_maxblocks, cg_nt, cg_no_compact, cg_no_recon, cg_no_sym. */
+int piso_set_option(const char* name, int value);
+int piso_get_option(const char* name, int* value_out);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Advection-diffusion matrix assembly.
@@ -108,9 +115,7 @@ int piso_laplace_matrix_f32(int nx, int ny, const float* active, const float* fl
  * The call returns when the solve has finished (the host must see the convergence flag, as in the reference).
  * Grids whose rows are a multiple of 128 cells (fp64; 256 for fp32) and that fit the chip run the iterations inside
  * persistent launches (csrc/cg_persist.h); a grid-wide exchange that times out fails the call with
- * PISO_ERR_HIP.  Tuning / test knobs (environment, read per call): PISO_CG_PERSIST=0|1 (forbid / force the persistent
- * kernel), PISO_CG_PERSIST_R=2|4|8|16 (rows per region), PISO_CG_SEGMENT=n (iterations per launch), PISO_CG_NO_SYM,
- * PISO_CG_NO_RECON, PISO_CG_NO_COMPACT (disable the symmetric / recomputed-diagonal / float32 coefficient fast paths).
+ * PISO_ERR_HIP.  Tuning / test knobs: piso_set_option() above.
  * ------------------------------------------------------------------------------------------------------------- */
 size_t piso_cg_workspace_bytes(int nx, int ny, int elem_size);
 

@@ -2,6 +2,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
 import numpy as np, torch
+import diffpiso._native as N_
 from oracle import native as O
 from tests.test_gpu_kernels import _laplace_case, dev
 from diffpiso.solvers import cg_solve_native
@@ -11,7 +12,7 @@ for shape in [(32, 256), (64, 512)]:
         for nit, tol in [(3, 1e-30), (20, 1e-30), (2000, 1e-4)]:
             res = []
             for persist in ("0", "1"):
-                os.environ["PISO_CG_PERSIST"] = persist; os.environ["PISO_CG_SEGMENT"] = "25"
+                N_.set_option("cg_persist", int(persist)); N_.set_option("cg_segment", 25)
                 x, it = cg_solve_native(s.nx, s.ny, True, True, dev(L, torch.float32), dev(b, torch.float32), tol, nit, shift, 1000)
                 res.append((x.cpu().numpy(), it))
             xo, ito = O.cg_solve(s.nx, s.ny, True, True, L, b, tol, nit, shift, 1000, dtype=np.float32)

@@ -17,3 +17,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def piso_option():
+    """Set tuning / test knobs of libpiso_hip.so for one test (piso_set_option); restored afterwards."""
+    import diffpiso._native as N
+    saved = {}
+
+    def set_(name, value):
+        saved.setdefault(name, N.get_option(name))
+        N.set_option(name, value)
+    yield set_
+    for name, value in saved.items():
+        N.set_option(name, value)

@@ -62,7 +62,7 @@ def test_network_weight_gradients_through_unrolled_piso(name):
     # ---- product
     vel_t = P["vel_tensor"].clone().requires_grad_(True)
     velocity = dp.StaggeredGrid(vel_t, P["velocity"].box, extrapolation=P["velocity"].extrapolation)
-    va, pa, vn, pn, warn = dp.run_piso_steps(velocity, P["pressure"], c["dt"], P["sim"], step_count=steps,
+    va, pa, vn, pn, warn = dp.unroll_piso_steps(velocity, P["pressure"], c["dt"], P["sim"], step_count=steps,
                                              forcing_fn=dp.make_forcing_fn(net_gpu))
     assert rel(vn.staggered_tensor().detach().cpu().numpy(), vel) < 1e-5
     (0.5 * (vn.staggered_tensor() ** 2).sum()).backward()

@@ -29,7 +29,7 @@ def test_config1_lid_driven_cavity_65x64_three_steps(rank_deficient, p_tol, tol_
     vel = dp.StaggeredGrid(torch.tensor(c["vel"], device="cuda"), P["velocity"].box, extrapolation=P["velocity"].extrapolation)
     prs = dp.CenteredGrid(torch.zeros_like(P["pressure"].data), P["pressure"].box, P["pressure"].extrapolation)
     with torch.no_grad():
-        va, pa, vn, pn, warn = dp.run_piso_steps(vel, prs, c["dt"], P["sim"], step_count=3)
+        va, pa, vn, pn, warn = dp.unroll_piso_steps(vel, prs, c["dt"], P["sim"], step_count=3)
     e = (rel(vn.staggered_tensor().cpu().numpy(), vels[-1]), rel(pn.data[0, :, :, 0].cpu().numpy(), ps[-1]))
     print("config1 rel-L2 (vel, p):", rank_deficient, e)
     assert e[0] < tol_v and e[1] < tol_p
@@ -44,7 +44,7 @@ def test_config2_decaying_turbulence_256_forward():
     P = product_setup(c, **kw)
     vels, ps, tapes = R.run_steps(s, c["vel"], c["p"], c["dt"], c["dirichlet_values"], 2)
     with torch.no_grad():
-        va, pa, vn, pn, warn = dp.run_piso_steps(P["velocity"], P["pressure"], c["dt"], P["sim"], step_count=2)
+        va, pa, vn, pn, warn = dp.unroll_piso_steps(P["velocity"], P["pressure"], c["dt"], P["sim"], step_count=2)
     assert rel(vn.staggered_tensor().cpu().numpy(), vels[-1]) < 1e-5
     assert rel(pn.data[0, :, :, 0].cpu().numpy(), ps[-1]) < 1e-4
 
@@ -64,7 +64,7 @@ def test_config3_temporal_mixing_layer_unrolled_adjoint():
     velocity = dp.StaggeredGrid(vel_t, P["velocity"].box, extrapolation=P["velocity"].extrapolation)
     p_t = P["pressure"].data.clone().requires_grad_(True)
     pressure = dp.CenteredGrid(p_t, P["pressure"].box, P["pressure"].extrapolation)
-    va, pa, vn, pn, warn = dp.run_piso_steps(velocity, pressure, c["dt"], P["sim"], step_count=steps)
+    va, pa, vn, pn, warn = dp.unroll_piso_steps(velocity, pressure, c["dt"], P["sim"], step_count=steps)
     assert rel(vn.staggered_tensor().detach().cpu().numpy(), vels[-1]) < 1e-5
     (0.5 * (vn.staggered_tensor() ** 2).sum()).backward()
     e = (rel(vel_t.grad.cpu().numpy(), d_vel), rel(p_t.grad[0, :, :, 0].cpu().numpy(), d_p))

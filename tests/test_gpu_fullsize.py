@@ -19,7 +19,7 @@ def problem():
 
 
 @pytest.mark.parametrize("walls", [False, True])
-def test_persistent_cg_equals_two_kernel_path_2048(walls, monkeypatch):
+def test_persistent_cg_equals_two_kernel_path_2048(walls, piso_option):
     """The persistent kernel at the benchmark size (all 256 CUs, 2048 regions exchanging perimeters and partial sums across
     the 8 XCDs) against the two-kernel iteration: same arithmetic per cell, only the summation order of the dot products
     differs, so after 150 iterations the iterates agree to round-off.  One stale halo cell or one torn exchange record would
@@ -42,10 +42,10 @@ def test_persistent_cg_equals_two_kernel_path_2048(walls, monkeypatch):
     b = torch.randn(N * N, generator=g, dtype=torch.float64).to(dev)
     b -= b.mean()
     per = not walls
-    monkeypatch.setenv("PISO_CG_PERSIST", "0")
+    piso_option("cg_persist", 0)
     xa, ita = cg_solve_native(N, N, per, per, L, b, 1e-30, 150, False, 1000)
-    monkeypatch.setenv("PISO_CG_PERSIST", "1")
-    monkeypatch.setenv("PISO_CG_SEGMENT", "40")
+    piso_option("cg_persist", 1)
+    piso_option("cg_segment", 40)
     scale = float(xa.abs().max())
     for rep in range(4):
         xb, itb = cg_solve_native(N, N, per, per, L, b, 1e-30, 150, False, 1000)

@@ -157,7 +157,7 @@ def _persist_iterations():
 @pytest.mark.parametrize("shape,reset,segment,rows", [((16, 128), 1000, 7, 2), ((64, 256), 200, 16, 8), ((36, 384), 1000, 1000, 2),
                                                       ((32, 128), 1000, 30, 4), ((16, 256), 25, 1000, 8),
                                                       ((32, 128), 1000, 9, 16), ((64, 256), 300, 1000, 16)])
-def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, monkeypatch):
+def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, piso_option):
     """The persistent segment kernel (cg_persist.h: r / z' in registers, x in LDS, grid-wide exchanges instead of launches)
     is the path the 2048^2 benchmark runs; force it on small grids and hold it to the same bar as the two-kernel path:
     round-off level agreement with the oracle along the trajectory, across segment boundaries and residual resets, and the
@@ -166,9 +166,9 @@ def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, 
     from diffpiso import _native as N
     s, L, b = _laplace_case(name, shape[0], shape[1], seed=5)
     px, py = s.periodic_yx[1], s.periodic_yx[0]
-    monkeypatch.setenv("PISO_CG_PERSIST", "1")
-    monkeypatch.setenv("PISO_CG_SEGMENT", str(segment))
-    monkeypatch.setenv("PISO_CG_PERSIST_R", str(rows))     # region height (2 / 4 / 8 / 16 rows): four kernel instantiations
+    piso_option("cg_persist", 1)
+    piso_option("cg_segment", segment)
+    piso_option("cg_persist_r", rows)     # region height (2 / 4 / 8 / 16 rows): four kernel instantiations
     N.lib.piso_cg_profile_enable(1, 8)
     try:
         for nit in (2, 3, 9, 23, 47):
@@ -192,17 +192,17 @@ def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, 
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_cg_persistent_symmetric_streaming_is_bitwise_neutral(name, monkeypatch):
+def test_cg_persistent_symmetric_streaming_is_bitwise_neutral(name, piso_option):
     """For a symmetric matrix (checked bit for bit at set-up) the persistent kernel streams only the S and W coefficient
     arrays and takes N / E from the neighbouring cell; the arithmetic is the same, so the result must not change by a bit.
     Matrices that fail the check (one-sided couplings at open boundaries) silently use all four arrays."""
     from diffpiso.solvers import cg_solve_native
     s, L, b = _laplace_case(name, 32, 256, seed=9)
     px, py = s.periodic_yx[1], s.periodic_yx[0]
-    monkeypatch.setenv("PISO_CG_PERSIST", "1")
-    monkeypatch.setenv("PISO_CG_PERSIST_R", "8")
+    piso_option("cg_persist", 1)
+    piso_option("cg_persist_r", 8)
     x1, it1 = cg_solve_native(s.nx, s.ny, px, py, dev(L), dev(b), 1e-30, 40, False, 1000)
-    monkeypatch.setenv("PISO_CG_NO_SYM", "1")
+    piso_option("cg_no_sym", 1)
     x2, it2 = cg_solve_native(s.nx, s.ny, px, py, dev(L), dev(b), 1e-30, 40, False, 1000)
     assert it1 == it2 == 40
     assert torch.equal(x1, x2)
@@ -210,11 +210,11 @@ def test_cg_persistent_symmetric_streaming_is_bitwise_neutral(name, monkeypatch)
     assert np.abs(x1.cpu().numpy() - xo).max() <= 1e-6 * np.abs(xo).max()
 
 
-def test_cg_persistent_shift_nan_and_float32(monkeypatch):
+def test_cg_persistent_shift_nan_and_float32(piso_option):
     from diffpiso.solvers import cg_solve_native
     from diffpiso import _native as N
-    monkeypatch.setenv("PISO_CG_PERSIST", "1")
-    monkeypatch.setenv("PISO_CG_SEGMENT", "25")
+    piso_option("cg_persist", 1)
+    piso_option("cg_segment", 25)
     s, L, b = _laplace_case("periodic", 32, 256, seed=2)
     N.lib.piso_cg_profile_enable(1, 8)
     try:

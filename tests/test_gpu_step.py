@@ -100,7 +100,7 @@ def test_unrolled_adjoint_matches_oracle(name, steps, cut):
     velocity = dp.StaggeredGrid(vel_t, P["velocity"].box, extrapolation=P["velocity"].extrapolation)
     p_t = P["pressure"].data.clone().requires_grad_(True)
     pressure = dp.CenteredGrid(p_t, P["pressure"].box, P["pressure"].extrapolation)
-    va, pa, vn, pn, warn = dp.run_piso_steps(velocity, pressure, c["dt"], P["sim"], step_count=steps, loss_influence_range=cut)
+    va, pa, vn, pn, warn = dp.unroll_piso_steps(velocity, pressure, c["dt"], P["sim"], step_count=steps, loss_influence_range=cut)
     assert rel(vn.staggered_tensor().detach().cpu().numpy(), vels[-1]) < TOL
     loss = 0.5 * (vn.staggered_tensor() ** 2).sum()                 # L = 1/2 ||u_N||^2
     loss.backward()
@@ -120,14 +120,14 @@ def test_unrolled_adjoint_matches_oracle(name, steps, cut):
 
 
 @pytest.mark.parametrize("name,shape", [("periodic", (32, 128)), ("xper_ywall", (32, 128))])
-def test_unrolled_16_steps_adjoint_through_persistent_cg(name, shape, monkeypatch):
+def test_unrolled_16_steps_adjoint_through_persistent_cg(name, shape, piso_option):
     """The north star's bar itself: forward + 16-step unrolled adjoint within 1e-5 relative L2 of the reference algorithm,
     with every pressure solve (forward and adjoint) running inside the persistent CG kernel that the 2048^2 benchmark uses
     (forced here: the grid is small)."""
     import ctypes as C
     import diffpiso as dp
     from diffpiso import _native as N
-    monkeypatch.setenv("PISO_CG_PERSIST", "1")
+    piso_option("cg_persist", 1)
     steps = 16
     c = make_case(name, shape[0], shape[1], seed=8)
     kw = dict(SOLVER, lin_double=True, lin_tol=1e-10)
@@ -140,7 +140,7 @@ def test_unrolled_16_steps_adjoint_through_persistent_cg(name, shape, monkeypatc
     pressure = dp.CenteredGrid(p_t, P["pressure"].box, P["pressure"].extrapolation)
     N.lib.piso_cg_profile_enable(1, 8)
     try:
-        va, pa, vn, pn, warn = dp.run_piso_steps(velocity, pressure, c["dt"], P["sim"], step_count=steps)
+        va, pa, vn, pn, warn = dp.unroll_piso_steps(velocity, pressure, c["dt"], P["sim"], step_count=steps)
         e_f = (rel(vn.staggered_tensor().detach().cpu().numpy(), vels[-1]), rel(pn.data[0, :, :, 0].detach().cpu().numpy(), ps[-1]))
         loss = 0.5 * (vn.staggered_tensor() ** 2).sum()
         loss.backward()
@@ -154,3 +154,58 @@ def test_unrolled_16_steps_adjoint_through_persistent_cg(name, shape, monkeypatc
     print("16-step unroll rel-L2 fields (u, p):", e_f, " gradients (d_vel, d_p):", e_b)
     assert max(e_f) < TOL, e_f
     assert max(e_b) < 2 * TOL, e_b
+
+
+def test_run_piso_steps_reference_call_returns_nine_values():
+    """combined_training_integrated.py:396-478 called as spatial_mixing_layer.py:40-43 / training_run :54-56 do: 14 arguments,
+    9 return values; with a network the forcing enters every step and NN_out is the last step's output; the per-step inlet
+    values are bcx + bc_placeholders[i] through dirichlet_placeholder_update."""
+    import diffpiso as dp
+    c = make_case("spatial_ml", 16, 24, seed=3)
+    P = product_setup(c, **SOLVER)
+    sim, domain = P["sim"], P["domain"]
+    steps = 3
+    ny = c["ny"]
+    bcx = np.zeros((1, ny + 2, 1, 1), f32)
+    bcx[0, 1:-1, 0, 0] = c["dirichlet_values"][0, :ny, 0, 1]
+    pert = (0.01 * np.random.default_rng(0).standard_normal((steps,) + bcx.shape)).astype(f32)
+    update = lambda dv, pl: dp.update_dirichlet_values(dv, ((False, False), (True, False)), pl)
+    simulation_parameters = dict(dt=c["dt"], dt_ratio=1, dx_ratio=1)
+    training_dict = dict(step_count=steps, loss_influence_range=2, pressure_included=True, HR_buffer_width=[[0, 0], [0, 0]])
+    net = dp.FullyConvNetwork(None, padding="SAME", seed=2).cuda()
+    seen = []
+
+    def wrapper(network, nn_in, fluid, physical_parameters, simulation_parameters_, loss_buffer_width, buffer_width):
+        seen.append((fluid is domain, buffer_width, tuple(nn_in.shape)))
+        return 0.05 * network(nn_in)
+
+    out = dp.run_piso_steps(P["velocity"], P["pressure"], domain, {}, simulation_parameters, training_dict, net, wrapper,
+                            sim, None, bcx, torch.tensor(pert, device="cuda"), update, None)
+    assert len(out) == 9
+    vels, prs, nn_all, velnew, pnew, nn_out, warn, vel_arrays, p_arrays = out
+    assert len(vels) == len(prs) == len(nn_all) == len(warn) == len(vel_arrays) == len(p_arrays) == steps
+    assert nn_out is nn_all[-1] and nn_out.shape == (1, ny, c["nx"], 2)
+    assert seen == [(True, [[0, 0], [0, 0]], (1, ny, c["nx"], 4))] * steps
+    assert torch.equal(velnew.staggered_tensor(), vel_arrays[-1]) and torch.equal(pnew.data, p_arrays[-1])
+    # the same unroll through the hook form
+    base = torch.tensor(c["dirichlet_values"], device="cuda")
+
+    def dv_of(i):
+        return update(base, (([], []), (torch.tensor(bcx + pert[i], device="cuda"), [])))
+    sim.dirichlet_values = dv_of(0)
+    try:
+        v2, p2, vn2, pn2, w2 = dp.unroll_piso_steps(
+            P["velocity"], P["pressure"], c["dt"], sim, step_count=steps, loss_influence_range=2,
+            forcing_fn=lambda i, v, p: dp.centered_to_staggered(0.05 * net(dp.network_input(v, p, True))),
+            dirichlet_update_fn=lambda i, _: dv_of(i))
+    finally:
+        sim.dirichlet_values = c["dirichlet_values"]
+    for a, b in zip(vel_arrays, v2):
+        assert torch.equal(a, b.staggered_tensor())
+    # the inlet faces of step i carry bcx + bc_placeholders[i]
+    for i in range(steps):
+        np.testing.assert_allclose(vel_arrays[i][0, :ny, 0, 1].detach().cpu().numpy(), (bcx + pert[i])[0, 1:-1, 0, 0], atol=1e-6)
+    # no network, training_dict None: one step (spatial_mixing_layer.py:40-43)
+    out = dp.run_piso_steps(P["velocity"], P["pressure"], domain, {}, simulation_parameters, None, None, None, sim, None, bcx,
+                            torch.tensor(pert[:1], device="cuda"), dirichlet_placeholder_update=update)
+    assert len(out) == 9 and len(out[0]) == 1 and out[2] == [] and out[5] == []

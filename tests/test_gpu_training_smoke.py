@@ -30,7 +30,7 @@ def test_closure_training_iterations_reduce_the_loss():
     force = torch.zeros_like(t)
     force[0, :ny, :, 1] = 0.3 * torch.sin(3.14 * yy[:ny]) * torch.cos(6.28 * xx)
     with torch.no_grad():
-        gt_steps, _, _, _, warn = dp.run_piso_steps(velocity, prs0, dt, sp, step_count=steps, viscosity_field=visc,
+        gt_steps, _, _, _, warn = dp.unroll_piso_steps(velocity, prs0, dt, sp, step_count=steps, viscosity_field=visc,
                                                     forcing_fn=lambda i, v, p: force)
     assert float(sum(float(w.detach().sum()) for w in warn)) == 0.0
     gt = torch.stack([g.staggered_tensor() for g in gt_steps], dim=1)            # [1, T, Ny+1, Nx+1, 2]
@@ -42,7 +42,7 @@ def test_closure_training_iterations_reduce_the_loss():
     history = []
     for it in range(6):
         opt.zero_grad()
-        pred, _, _, _, warn = dp.run_piso_steps(velocity, prs0, dt, sp, step_count=steps, viscosity_field=visc,
+        pred, _, _, _, warn = dp.unroll_piso_steps(velocity, prs0, dt, sp, step_count=steps, viscosity_field=visc,
                                                 forcing_fn=dp.make_forcing_fn(net))
         loss, l2 = dp.L2_field_loss(torch.zeros((), device=dev), [pred], [gt], steps, [[1, 1], [1, 1]], 1.0, 0)
         loss, sr = dp.strain_rate_loss(loss, [pred], [gt], steps, None, 1e-3)
@@ -75,7 +75,7 @@ def _frames(tmp, n_frames, hr, box, phys, dt):
             pert = dp.boundary_perturbation_fun(domain, phys["average_velocity"], bcx.shape, f * dt, (0.08, 0.05))
             sp.dirichlet_values = dp.update_dirichlet_values(torch.as_tensor(base, dtype=torch.float32, device=dev), ((False, False), (True, False)),
                                                              ((None, None), (torch.tensor(bcx + pert, dtype=torch.float32, device=dev), None)))
-            _, _, velocity, pressure, warn = dp.run_piso_steps(velocity, pressure, dt, sp, step_count=1, viscosity_field=visc)
+            _, _, velocity, pressure, warn = dp.unroll_piso_steps(velocity, pressure, dt, sp, step_count=1, viscosity_field=visc)
     return path
 
 
@@ -101,7 +101,7 @@ def test_training_run_files_recovery_and_learning(tmp_path, monkeypatch, capsys)
         out = real(*a, **k)
         calls["n"] += 1
         if calls["n"] == 3:
-            out[4][0] = torch.ones(1, dtype=torch.bool)
+            out[6][0] = torch.ones(1, dtype=torch.bool)        # warn is the 7th of the reference's 9 return values
         return out
     monkeypatch.setattr(T, "run_piso_steps", flaky)
     # the reference script's sponge wrapper, with its seven-argument signature (spatial_mixing_layer_differentiable_training.py:6-10)

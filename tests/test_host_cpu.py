@@ -188,3 +188,51 @@ def test_closure_network_shapes_and_gradients():
     assert tuple(netv(x).shape) == (1, 40, 44, 2) and rbwv == [[11, 11], [10, 12]]
     z = netv(x)
     assert float(z[:, :2].abs().sum()) == 0 and float(z[:, :, :1].abs().sum()) == 0      # buffer zones are zero padded
+
+
+def test_run_piso_steps_has_the_reference_signature():
+    """diffpiso/combined_training_integrated.py:396-397: 14 parameters in this order, the last two optional."""
+    import inspect
+    sig = inspect.signature(dp.run_piso_steps)
+    assert list(sig.parameters) == ["velocity", "pressure", "domain", "physical_parameters", "simulation_parameters", "training_dict",
+                                    "neural_network", "neural_network_wrapper", "sim_physics", "viscosity_field", "bcx",
+                                    "bc_placeholders", "dirichlet_placeholder_update", "loss_buffer_width"]
+    assert sig.parameters["dirichlet_placeholder_update"].default is None and sig.parameters["loss_buffer_width"].default is None
+    assert all(p.default is inspect.Parameter.empty for n, p in list(sig.parameters.items())[:12])
+
+
+def test_linear_solver_scipy_forward_and_transpose_adjoint():
+    """diffpiso/linear_solver.py:33-57: direct solve; gradient w.r.t. rhs = transposed solve."""
+    import scipy.sparse as sp
+    A = (sp.random(30, 30, 0.2, format="csr", random_state=3) + sp.eye(30) * 4).tocsr()
+    s = dp.LinearSolverScipy()
+    assert s.supported_devices == "CPU" and not s.supports_guess
+    mv, rp, ci = torch.tensor(A.data, dtype=torch.float32), torch.tensor(A.indptr), torch.tensor(A.indices)
+    b = torch.randn(30, generator=torch.Generator().manual_seed(0)).requires_grad_(True)
+    g = torch.randn(30, generator=torch.Generator().manual_seed(1))
+    x = s.solve(mv, rp, ci, b)
+    np.testing.assert_allclose(A @ x.detach().numpy(), b.detach().numpy(), atol=2e-6)
+    (x * g).sum().backward()
+    np.testing.assert_allclose(A.T @ b.grad.numpy(), g.numpy(), atol=2e-6)
+    xt = s.solve(mv, rp, ci, b.detach(), transpose=True)
+    np.testing.assert_allclose(A.T @ xt.numpy(), b.detach().numpy(), atol=2e-6)
+
+
+def test_frame_file_format(tmp_path):
+    """<field>_%06d.npz / arr_0, windows of step_count+1 frames spaced dt_ratio apart, [1,T,...] stacking
+    (diffpiso/datamanagement.py:35-57 describes the format; spatial_mixing_layer.py:60-75 writes it)."""
+    d = str(tmp_path) + "/"
+    for f in range(9):
+        dp.save_frame(d, "velocity", f, np.full((1, 3, 4, 2), f, np.float64))
+        dp.save_frame(d, "pressure", f, np.full((1, 2, 3, 1), 10 + f, np.float64))
+    assert sorted(os.listdir(d))[0] == "pressure_000000.npz"
+    assert list(np.load(d + "velocity_000003.npz").keys()) == ["arr_0"]
+    lists = dp.data_path_assembler([d], ["velocity", "pressure"], [[(float(i), 0.5) for i in range(9)]], [1], [8], [2], dt_ratio=2)
+    assert len(lists) == 3 and len(lists[0]) == 8 - 2 * 2 == len(lists[2])
+    assert lists[0][0] == [d + "velocity_%06d.npz" % k for k in (1, 3, 5)]
+    assert lists[2][1] == (1.0, 0.5)                        # per-frame characteristics are indexed by the window start
+    vel, prs, ch = dp.load_function(lists[0][1], lists[1][1], lists[2][1])
+    assert vel.shape == (1, 3, 3, 4, 2) and vel.dtype == np.float32 and prs.shape == (1, 3, 2, 3, 1)
+    assert [float(vel[0, t, 0, 0, 0]) for t in range(3)] == [2.0, 4.0, 6.0] and ch.shape == (1, 2)
+    lists = dp.data_path_assembler([d], ["velocity"], [7.5], [0], [6], [2])
+    assert len(lists[0]) == 4 and lists[1] == [7.5] * 4
