@@ -3,20 +3,28 @@
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under
 torch.distributed.run with one rank per GPU.  One "step" = one PISO step (implicit predictor + two pressure correctors)
-forward AND its reverse-mode sweep: the timed region unrolls K steps forward, then back-propagates L = 1/2 |u_K|^2 through
-all K steps (the reference's training pattern, diffpiso/combined_training_integrated.py:396-478).  Inputs are synthetic
-(random solenoidal velocity with E(k) ~ k^4 exp(-(k/8)^2), seed 0, u_rms = 1, nu = 1e-3, CFL 0.5, p0 = 0) and
-resident in HBM before the clock starts.  Solver settings are the reference's training settings: tolerance 1e-6,
-max_iterations 10000, CG residual_reset 1000, pressure solve fp64, advection solve fp32.
+forward AND its reverse-mode sweep: the timed region unrolls K steps forward through `run_piso_steps` (the reference's
+unroll, diffpiso/combined_training_integrated.py:396-478), then back-propagates L = 1/2 |u_K|^2 through all K steps.
+Inputs are synthetic (random solenoidal velocity with E(k) ~ k^4 exp(-(k/8)^2), seed 0, u_rms = 1, nu = 1e-3,
+CFL 0.5, p0 = 0) and resident in HBM before the clock starts.  Solver settings are the reference's training settings:
+tolerance 1e-6, max_iterations 10000, CG residual_reset 1000, pressure solve fp64, advection solve fp32.
 
-Multi-GPU (round 1): "replicas only" -- every rank runs the same independent 2048^2 problem, no data-path collective
-(DESIGN.md "Multi-GPU"); value = N * K / max-over-ranks time, scaling "weak".
+Multi-GPU: "replicas" (default) -- every rank runs the same independent 2048^2 problem, no data-path collective; value =
+N * K / max-over-ranks time, scaling "weak".  `--decomp slab` cuts the pressure CG of ONE grid into y-slabs (RCCL).
 
-One JSON line on stdout (rank 0).  Extra objects: `roofline` (dominant kernel = CG K1, HIP-event timed inside the timed
-region) and `cpu_baseline` (the C oracle on a bounded sample of the same workload, rank 0, N = 1 only).
+One JSON line on stdout (rank 0) with, besides the contract's keys:
+  roofline      the dominant kernel (persistent pressure CG), HIP-event timed inside the timed region.  `achieved` counts the
+                bytes THIS design has to move through the memory fabric per launch (DESIGN.md 3.1), so frac <= 1;
+                `algorithmic_equivalent` is SURVEY.md 8(d)'s 128 B per cell and iteration of the textbook iteration;
+                `floors_us_per_iteration` lists what bounds an iteration of this kernel (it is latency / issue bound)
+  bicgstab      fixed-work run of the ILU(0)-BiCGStab (both components, every launch does work), 296 B per row and iteration
+  phases        forward / adjoint ms per step, CG iterations per step, CG share of the step
+  other_configs ms per step of BASELINE.json's config 2 (256^2 forward) and config 3 (512x256 fwd + adjoint, 4 steps)
+  cpu_baseline  the C oracle (a port of the reference's algorithm) on all host cores, bounded sample (rank 0, N = 1 only)
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -29,14 +37,26 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-# 128 B per cell per CG iteration = 16 fp64 words: matrix 5, SpMV 2, x update 3, r update 3, p update 3.
-K1_BYTES_PER_CELL = 104.0    # K1 covers matrix 5 + SpMV 2 + p update 3 + x update 3 words (it adds the previous direction to x)
-K2_BYTES_PER_CELL = 24.0     # K2 covers the r update: 3 words
-CG_BYTES_PER_CELL_ITER = 128.0   # 16 fp64 words per cell and CG iteration
-# what cg_persist has to move through HBM per cell and iteration (symmetric matrix, one region of 16 rows x 128 columns per
-# wave): the S and W float off-diagonals in each of the two phases 2 * 8 B, perimeters of r and p written 2 * (2/16 + 2/128)
-# * 8 B and read by the neighbours (the same again), extra coefficient row / column per region ~0.6 B
-PERSIST_HBM_BYTES_PER_CELL_ITER = 21.1
+CG_BYTES_PER_CELL_ITER = 128.0   # 16 fp64 words per cell and CG iteration (matrix 5, SpMV 2, x 3, r 3, p 3)
+K1_BYTES_PER_CELL = 104.0    # two-kernel path: K1 covers matrix 5 + SpMV 2 + p update 3 + x update 3 words
+K2_BYTES_PER_CELL = 24.0     #                  K2 covers the r update: 3 words
+BICG_BYTES_PER_ROW_ITER = 296.0  # CSR fp32/int32 BiCGStab(ILU0): 2 SpMV 104 + 4 triangular sweeps 128 + updates 64
+BICG_BYTES_PER_ROW_ONCE = 148.0  # ILU0 factor 88 + initial residual 60
+# What cg_persist must move through the fabric per cell and iteration (symmetric matrix, regions of 16 rows x 128 columns):
+# the S and W float off-diagonals once per stencil pass (2 passes x 8 B), the perimeters of the published vectors written and
+# read back by the neighbours (2 vectors x 2 x (2/16 + 2/128) x 8 B), the extra coefficient row / column per region (~0.6 B).
+PERSIST_STENCIL_PASSES = 2
+PERSIST_PUBLISHED_VECTORS = {1: 3, 2: 2}   # exchanges per iteration -> vectors whose perimeters are published (r, p [, z])
+# floors of one persistent iteration (scripts/barrier_bench.hip, scripts/fp64_rate.hip measured on MI355X)
+EXCHANGE_US = 4.4            # one tagged-record grid exchange over 256 workgroups
+FP64_ISSUE_CYCLES = 4.75     # cycles per fp64 VALU instruction per SIMD with two waves resident
+FP64_INSTR_PER_CELL = 38     # two stencil passes (2 x 13) + vector updates / sums (12)
+CLOCK_GHZ = 2.4
+
+
+def persist_fabric_bytes_per_cell(exchanges):
+    nvec = PERSIST_PUBLISHED_VECTORS.get(exchanges, 2)
+    return PERSIST_STENCIL_PASSES * 8.0 + nvec * 2 * (2.0 / 16 + 2.0 / 128) * 8.0 + 0.6
 
 
 def turbulence_velocity(n, seed=0, k0=8.0):
@@ -65,6 +85,7 @@ def turbulence_velocity(n, seed=0, k0=8.0):
 
 
 def build_problem(n, device, tol, max_it, reset):
+    """The metric workload: 2-D decaying turbulence n^2, doubly periodic."""
     import torch
     import diffpiso as dp
     L = 2 * np.pi
@@ -79,31 +100,110 @@ def build_problem(n, device, tol, max_it, reset):
     vel = turbulence_velocity(n)
     dx = L / n
     dt = 0.5 * dx / float(np.abs(vel).max())
-    vel_t = torch.tensor(vel, device=device)
-    p_t = torch.zeros((1, n, n, 1), device=device)
-    dv = torch.zeros(st, device=device)
-    sim.dirichlet_values = dv
-    return dict(domain=domain, sim=sim, vel=vel, vel_t=vel_t, p_t=p_t, dt=dt, lin=lin, ps=ps)
+    sim.dirichlet_values = torch.zeros(st, device=device)
+    return dict(domain=domain, sim=sim, vel=vel, vel_t=torch.tensor(vel, device=device), p_t=torch.zeros((1, n, n, 1), device=device),
+                dt=dt, lin=lin, ps=ps)
 
 
-def run_unrolled(P, steps, stats=None):
-    """K steps forward, then the reverse sweep of L = 1/2 |u_K|^2."""
+def build_mixing_layer(ny, nx, device, tol, max_it, reset):
+    """BASELINE.json config 3: temporally evolving mixing layer, x periodic, walls in y (v Dirichlet), tanh shear + noise."""
+    import torch
     import diffpiso as dp
-    vel_t = P["vel_t"].clone().requires_grad_(True)
-    p_t = P["p_t"].clone().requires_grad_(True)
+    domain = dp.Domain([ny, nx], boundaries=(dp.CLOSED, dp.PERIODIC), box=dp.box[0:float(ny), 0:float(nx)])
+    st = (1, ny + 1, nx + 1, 2)
+    cells = np.ones((1, ny + 2, nx + 2, 1), np.float32)
+    cells[0, 0], cells[0, -1] = 0, 0
+    dmask = np.zeros(st, bool)
+    dmask[0, 0, :nx, 0] = True
+    dmask[0, ny, :nx, 0] = True
+    lin = dp.LinearSolverCudaMultiBicgstabILU(accuracy=tol, max_iterations=max_it, cast_to_double=False)
+    ps = dp.PisoPressureSolverCudaCustom(dx=[], accuracy=tol, max_iterations=max_it, residual_reset=reset, cast_to_double=True)
+    sim = dp.SimulationParameters(dirichlet_mask=dmask, dirichlet_values=np.zeros(st, np.float32), active_mask=cells,
+                                  accessible_mask=cells.copy(), bool_periodic=(False, True), no_slip_mask=None, viscosity=1e-3,
+                                  linear_solver=lin, pressure_solver=ps)
+    rng = np.random.default_rng(0)
+    vel = np.zeros(st, np.float32)
+    yy = (np.arange(ny) + 0.5) / ny
+    vel[0, :ny, :, 1] = np.tanh(16.0 * (yy - 0.5))[:, None] + 0.05 * rng.standard_normal((ny, nx + 1))
+    vel[0, :ny, nx, 1] = vel[0, :ny, 0, 1]
+    vel[0, 1:ny, :nx, 0] = 0.05 * rng.standard_normal((ny - 1, nx))
+    dt = 0.5 / float(np.abs(vel).max())
+    sim.dirichlet_values = torch.zeros(st, device=device)
+    return dict(domain=domain, sim=sim, vel=vel, vel_t=torch.tensor(vel, device=device), p_t=torch.zeros((1, ny, nx, 1), device=device),
+                dt=dt, lin=lin, ps=ps)
+
+
+def run_unrolled(P, steps, backward=True, clock=None):
+    """K steps forward through the reference-signature run_piso_steps, then the reverse sweep of L = 1/2 |u_K|^2.
+    clock (optional dict): 'fwd_s' / 'bwd_s' accumulate wall time with a device synchronisation between the two sweeps."""
+    import torch
+    import diffpiso as dp
+    vel_t = P["vel_t"].clone().requires_grad_(backward)
+    p_t = P["p_t"].clone().requires_grad_(backward)
     ext = dp.Material.extrapolation_mode(P["domain"].boundaries)
     velocity = dp.StaggeredGrid(vel_t, P["domain"].box, extrapolation=ext)
     pressure = dp.CenteredGrid(p_t, P["domain"].box, dp.pressure_extrapolation(P["domain"].boundaries))
-    vels, ps, vn, pn, warn = dp.unroll_piso_steps(velocity, pressure, P["dt"], P["sim"], step_count=steps)
-    loss = 0.5 * (vn.staggered_tensor() ** 2).sum()
-    loss.backward()
+    t0 = time.perf_counter()
+    with torch.set_grad_enabled(backward):
+        out = dp.run_piso_steps(velocity, pressure, P["domain"], None, {"dt": P["dt"], "dt_ratio": 1},
+                                {"step_count": steps, "loss_influence_range": steps + 1}, None, None, P["sim"], None, None, None)
+        vn, warn = out[3], out[6]
+        loss = 0.5 * (vn.staggered_tensor() ** 2).sum()
+    if clock is not None:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        clock["fwd_s"] = clock.get("fwd_s", 0.0) + t1 - t0
+    if backward:
+        loss.backward()
+        if clock is not None:
+            torch.cuda.synchronize()
+            clock["bwd_s"] = clock.get("bwd_s", 0.0) + time.perf_counter() - t1
     return vel_t.grad, float(loss.detach()), warn
 
 
-def cpu_baseline(P, n, tol, cg_iters_per_step, sample_iters=12):
-    """The C oracle (a port, single thread) on a bounded sample of the SAME 2048^2 workload: one matrix assembly, one
-    forward BiCGStab(ILU0) solve and `sample_iters` CG iterations are timed; a step is priced as
-    assembly x2 + BiCGStab x2 + (CG iterations per fwd+adjoint step observed on the GPU) x time per CG iteration."""
+def bicgstab_fixed_work(P, n, iters=10, reps=3):
+    """Fixed-work run of the ILU(0)-BiCGStab on the benchmark's matrices: tol = 0 makes every iteration of both restart passes
+    run on both components (no early-return launches), 2 * iters iterations per call; timed with events on the launch stream."""
+    import torch
+    import diffpiso as dp
+    from diffpiso.solvers import multi_bicgstab_ilu_native
+    dev = P["vel_t"].device
+    ext = dp.Material.extrapolation_mode(P["domain"].boundaries)
+    velocity = dp.StaggeredGrid(P["vel_t"], P["domain"].box, extrapolation=ext)
+    sim = P["sim"]
+    beta = (2 * np.pi / n) ** 2 / P["dt"]
+    val, rp, col, A, nnz, Aflat = dp.advection_matrix_cuda(velocity, sim.dirichlet_mask_flat(dev), sim.viscosity, beta=beta,
+                                                           bool_periodic=sim.bool_periodic, active_mask=sim.active_mask_tensor(dev),
+                                                           accessible_mask=sim.accessible_mask_tensor(dev))
+    x0 = dp.flatten_staggered_data(velocity, True)
+    rhs = x0 * beta
+    warn = torch.zeros(1, dtype=torch.uint8, device=dev)
+    rows = x0.numel()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    best, its = None, (0, 0)
+    for r in range(reps + 1):
+        ev[0].record()
+        x, its = multi_bicgstab_ilu_native(-val, rp, col, rhs, x0, n, n, 0.0, iters, False, 0, warn)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1])
+        if r > 0:
+            best = ms if best is None else min(best, ms)
+    total_its = max(its)                      # iterations executed per component (two passes of `iters`)
+    nbytes = rows * (BICG_BYTES_PER_ROW_ITER * total_its + 2 * BICG_BYTES_PER_ROW_ONCE)
+    gbs = nbytes / (best * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "piso_multi_bicgstab_ilu_f32: whole solve (u and v together), %d iterations per component, "
+                                      "no early-return launches, host look every 2 iterations included" % total_its,
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "ms_per_solve": best, "us_per_iteration": 1e3 * best / max(total_its, 1), "rows": rows,
+            "algorithmic_bytes_per_solve": nbytes, "bytes_per_row_iteration": BICG_BYTES_PER_ROW_ITER}
+
+
+def cpu_baseline(P, n, tol, cg_iters_per_step, bicg_solves_per_step=2, sample_iters=240):
+    """The C oracle (a port of the reference's algorithms) on the host cores, bounded sample of the SAME 2048^2 workload:
+    one matrix assembly, one BiCGStab(ILU0) solve (both single-threaded: sequential triangular sweeps) and `sample_iters`
+    CG iterations on all cores (OpenMP) are timed; a step is priced as 2 assemblies + 2 BiCGStab solves + the CG iterations
+    per fwd+adjoint step observed on the GPU."""
     from oracle import native as O, piso_ref as R
     s = R.OracleSetup(n, n, (2 * np.pi / n,) * 2, (True, True), np.zeros((1, n + 1, n + 1, 2), bool),
                       np.ones((1, n + 2, n + 2, 1), np.float32), np.ones((1, n + 2, n + 2, 1), np.float32),
@@ -120,21 +220,44 @@ def cpu_baseline(P, n, tol, cg_iters_per_step, sample_iters=12):
     a0 = ((np.float32(1) / (np.float32(beta) - A_t)) * np.float32(1.0)).astype(np.float32)
     L = O.laplace_matrix(n, n, s.active, s.accessible, R.flatten_staggered(a0, False))
     div = R.fv_divergence(R.stagger_flattened(x, n, n, True), s.dx_yx).astype(np.float64).ravel()
+    threads = O.omp_threads()
+    O.cg_solve_omp(n, n, True, True, L, div, 1e-30, 8, True, 1000)           # page in / spin up the thread pool
     t0 = time.perf_counter()
-    O.cg_solve(n, n, True, True, L, div, 1e-30, sample_iters, True, 1000)
+    O.cg_solve_omp(n, n, True, True, L, div, 1e-30, sample_iters, True, 1000)
     t_cg_iter = (time.perf_counter() - t0) / sample_iters
-    step_s = 2 * t_asm + 2 * t_bicg + cg_iters_per_step * t_cg_iter
-    return dict(value=1.0 / step_s, unit="PISO steps/s (fwd+adjoint) at %d^2" % n, cores=1, kind="port",
-                sample=("C oracle, 1 thread, %d^2: 1 assembly (%.2fs) + 1 BiCGStab-ILU0 solve (%.2fs, %s its) + %d CG iterations "
-                        "(%.3fs each) timed; step priced as 2*assembly + 2*BiCGStab + %d CG iterations (the count per fwd+adjoint "
-                        "step observed on the GPU)") % (n, t_asm, t_bicg, its, sample_iters, t_cg_iter, cg_iters_per_step))
+    step_s = 2 * t_asm + bicg_solves_per_step * t_bicg + cg_iters_per_step * t_cg_iter
+    return dict(value=1.0 / step_s, unit="PISO steps/s (fwd+adjoint) at %d^2" % n, cores=threads, kind="port",
+                sample=("C oracle at %d^2: %d CG iterations on %d OpenMP threads (%.4f s each; os.cpu_count() = %s) + 1 assembly "
+                        "(%.2f s) + 1 BiCGStab-ILU0 solve (%.2f s, %s its), the last two on 1 thread; step priced as 2 assemblies + "
+                        "%d BiCGStab solves + %d CG iterations (the count per fwd+adjoint step observed on the GPU)")
+                % (n, sample_iters, threads, t_cg_iter, os.cpu_count(), t_asm, t_bicg, its, bicg_solves_per_step, cg_iters_per_step))
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for f in ("cg_persist.h", "cg_kernels.h", "cg.hip"):
+        with open(os.path.join(ROOT, "differentiable-piso_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(n, kernel):
+    """HBM/fabric bytes of `kernel` from the rocprofv3 PMC passes recorded in profiles/traffic.json -- only if they were taken
+    from THIS version of the kernel sources (sha recorded by scripts/profile_bench.sh); otherwise null."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        e = tj[str(n)][kernel]
+        if e.get("kernel_source_sha") != kernel_source_sha():
+            return None, "profiles/traffic.json was measured on another version of the kernel sources"
+        return e, e.get("source")
+    except Exception as ex:
+        return None, "no PMC record (%s)" % type(ex).__name__
 
 
 def slab_self_check(n, device, rank, world, iters=300):
     """N > 1 only, AFTER the timed region: the slab-decomposed CG (RCCL all-reduce + halo exchange) on one
     2048^2 pressure system cut into `world` slabs, against the single-GPU solve of the same system on every rank."""
     import torch
-    import diffpiso._native as N
     from diffpiso.distributed import SlabCommunicator, cg_solve_slab
     from diffpiso.solvers import cg_solve_native, laplace_matrix_native
     g = torch.Generator(device="cpu")
@@ -174,6 +297,7 @@ def main():
     ap.add_argument("--max-iterations", type=int, default=10000)
     ap.add_argument("--residual-reset", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bicgstab / other_configs legs (profiling runs)")
     ap.add_argument("--decomp", choices=["replicas", "slab"], default=os.environ.get("PISO_BENCH_DECOMP", "replicas"),
                     help="N > 1: 'replicas' = one independent grid per GPU (weak); 'slab' = ONE grid, pressure CG cut into "
                          "y-slabs over the GPUs with RCCL all-reduce + halo exchange, rest of the step replicated (strong)")
@@ -208,61 +332,92 @@ def main():
 
     for _ in range(args.warmup):
         run_unrolled(P, 1)
-    N.lib.piso_cg_profile_enable(1, 16)              # HIP-event sampling of every 16th K1 / K2 launch
+    for s_ in (P["ps"].stats, P["lin"].stats):
+        for k_ in s_:
+            s_[k_] = 0
+    N.lib.piso_cg_profile_enable(1, 16)              # HIP-event timing of every persistent segment / every 16th K1, K2 launch
+    clock = {}
     barrier()
     t0 = time.perf_counter()
-    grad, loss, warn = run_unrolled(P, args.steps)
+    grad, loss, warn = run_unrolled(P, args.steps, clock=clock)
     barrier()
     elapsed = time.perf_counter() - t0
     ms_sum = (C.c_double * 4)()
     cnt = (C.c_longlong * 4)()
     N.lib.piso_cg_profile_read(ms_sum, cnt)
     N.lib.piso_cg_profile_enable(0, 16)
+    fallbacks = int(N.lib.piso_cg_persist_fallbacks())
     from diffpiso.distributed import max_over_ranks
     elapsed = max_over_ranks(elapsed, device)
 
+    out = None
     if rank == 0:
         ncell = float(n) * n
         k1_ms = ms_sum[0] / max(cnt[0], 1)
         k2_ms = ms_sum[1] / max(cnt[1], 1)
         k1_gbs = K1_BYTES_PER_CELL * ncell / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         k2_gbs = K2_BYTES_PER_CELL * ncell / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
-        try:   # measured offline with rocprofv3 PMC passes of this same workload (profiles/traffic.json)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))[str(n)]
-        except Exception:
-            tj = {}
+        exchanges = N.get_option("cg_exchanges")
+        exchanges = exchanges if exchanges in (1, 2) else int(N.lib.piso_cg_default_exchanges())
         if cnt[2] > 0:
             # the CG iterations ran inside persistent segment launches (cg_persist.h): one launch = `its` iterations
             its = cnt[2] / max(cnt[3], 1)
             seg_ms = ms_sum[2] / max(cnt[3], 1)
             it_us = 1e3 * ms_sum[2] / cnt[2]
-            achieved = CG_BYTES_PER_CELL_ITER * ncell * its / (seg_ms * 1e-3) / 1e9
-            streamed = PERSIST_HBM_BYTES_PER_CELL_ITER * ncell * its / (seg_ms * 1e-3) / 1e9
-            traffic = tj.get("cg_persist", {}).get("bytes_per_iteration")
-            traffic = traffic * its if traffic else None
-            roofline = {"bound": "hbm", "kernel": "cg_persist (one launch = %.0f CG iterations: r, p in registers, x in LDS, "
-                                                  "coefficients streamed, 2 grid exchanges per iteration, fp64)" % its,
+            fabric_b = persist_fabric_bytes_per_cell(exchanges)
+            achieved = fabric_b * ncell * its / (seg_ms * 1e-3) / 1e9
+            alg = CG_BYTES_PER_CELL_ITER * ncell * its / (seg_ms * 1e-3) / 1e9
+            pmc, pmc_src = measured_traffic(n, "cg_persist")
+            floors = {"fabric_bytes_at_hbm_peak": fabric_b * ncell / (HBM_PEAK_GBS * 1e9) * 1e6,
+                      "fp64_valu_issue": FP64_INSTR_PER_CELL * ncell / 256 / 64 / 4 * FP64_ISSUE_CYCLES / (CLOCK_GHZ * 1e3),
+                      "grid_exchanges": exchanges * EXCHANGE_US}
+            serial_floor = floors["fp64_valu_issue"] + floors["grid_exchanges"]   # the exchange cannot overlap the arithmetic it feeds
+            roofline = {"bound": "hbm",
+                        "kernel": "cg_persist (one launch = %.0f CG iterations: r, p in registers, x in LDS, float coefficients "
+                                  "streamed, %d grid exchange%s per iteration, fp64)" % (its, exchanges, "" if exchanges == 1 else "s"),
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "avg_launch_ms": seg_ms, "launches_sampled": int(cnt[3]),
-                        "iterations_per_launch": its, "us_per_iteration": it_us,
-                        "algorithmic_bytes_per_launch": CG_BYTES_PER_CELL_ITER * ncell * its,
-                        "note": "algorithmic = SURVEY 8(d): 128 B per cell and iteration (5 matrix words + 11 vector words); the "
-                                "kernel keeps x, r and p on chip and recomputes z, so it only has to stream ~%.0f B per cell and "
-                                "iteration: frac > 1 is traffic avoided, not bandwidth above peak; the iteration is bound by "
-                                "its two grid-wide exchanges and fp64 issue, not by HBM" % PERSIST_HBM_BYTES_PER_CELL_ITER,
-                        "streamed_model": {"bytes_per_cell_iteration": PERSIST_HBM_BYTES_PER_CELL_ITER, "achieved": streamed,
-                                           "frac": streamed / HBM_PEAK_GBS},
+                        "traffic": (pmc["bytes_per_iteration"] * its) if pmc else None, "traffic_source": pmc_src,
+                        "bytes_counted": "%.1f B per cell and iteration: what this design must move through the memory fabric "
+                                         "(S, W float coefficient rows once per stencil pass, perimeters of the published vectors "
+                                         "out and back); the vectors themselves never leave the chip" % fabric_b,
+                        "bytes_per_launch": fabric_b * ncell * its,
+                        "avg_launch_ms": seg_ms, "launches_sampled": int(cnt[3]), "iterations_per_launch": its,
+                        "us_per_iteration": it_us,
+                        "algorithmic_equivalent": {"bytes_per_cell_iteration": CG_BYTES_PER_CELL_ITER, "GB/s": alg,
+                                                   "x_hbm_peak": alg / HBM_PEAK_GBS,
+                                                   "note": "SURVEY 8(d) textbook iteration (5 matrix + 11 vector fp64 words); a "
+                                                           "ratio above 1 is traffic this design avoids, not bandwidth"},
+                        "floors_us_per_iteration": floors, "binding_floor": "fp64_valu_issue + grid_exchanges (serial)",
+                        "frac_of_binding_floor": serial_floor / it_us,
                         "two_kernel_path": {"k1_avg_launch_ms": k1_ms, "k1_achieved": k1_gbs, "k1_launches_sampled": int(cnt[0]),
                                             "k2_avg_launch_ms": k2_ms, "k2_achieved": k2_gbs}}
+            cg_ms_total = ms_sum[2]
         else:
+            pmc, pmc_src = measured_traffic(n, "cg_k1")
             roofline = {"bound": "hbm", "kernel": "cg_k1 (fused x/p update + 5-point stencil + dots, fp64)",
                         "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k1_gbs / HBM_PEAK_GBS,
-                        "traffic": tj.get("cg_k1", {}).get("bytes"), "avg_launch_ms": k1_ms, "launches_sampled": int(cnt[0]),
+                        "traffic": pmc["bytes"] if pmc else None, "traffic_source": pmc_src,
+                        "avg_launch_ms": k1_ms, "launches_sampled": int(cnt[0]),
                         "algorithmic_bytes_per_launch": K1_BYTES_PER_CELL * ncell,
                         "k2": {"achieved": k2_gbs, "avg_launch_ms": k2_ms, "frac": k2_gbs / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_launch": K2_BYTES_PER_CELL * ncell}}
-        cg_it = P["ps"].last_iterations or 0
-        cg_it_adj = P["ps"].last_adjoint_iterations or 0
+            cg_ms_total = None
+        ps_stats, lin_stats = dict(P["ps"].stats), dict(P["lin"].stats)
+        cg_per_step = (ps_stats["iterations"] + ps_stats["adjoint_iterations"]) / float(args.steps)
+        phases = {"forward_ms_per_step": 1e3 * clock.get("fwd_s", 0.0) / args.steps,
+                  "adjoint_ms_per_step": 1e3 * clock.get("bwd_s", 0.0) / args.steps,
+                  "forward_only_steps_per_s": args.steps / clock["fwd_s"] if clock.get("fwd_s") else None,
+                  "cg_iterations_per_step": {"forward": ps_stats["iterations"] / float(args.steps),
+                                             "adjoint": ps_stats["adjoint_iterations"] / float(args.steps)},
+                  "cg_solves_at_iteration_cap": "adjoint solves stop at max_iterations = %d (absolute max-norm tolerance %g on an "
+                                                "O(1) cotangent, restart every %d): unconverged by the reference's own criterion"
+                                                % (args.max_iterations, args.tol, args.residual_reset)
+                  if ps_stats["adjoint_iterations"] >= args.max_iterations * ps_stats["adjoint_solves"] > 0 else None,
+                  "bicgstab_iterations_per_step": {"forward": lin_stats["iterations"] / float(args.steps),
+                                                   "adjoint": lin_stats["adjoint_iterations"] / float(args.steps)},
+                  "persistent_cg_ms_per_step": (cg_ms_total / args.steps) if cg_ms_total is not None else None,
+                  "persistent_cg_share_of_step": (cg_ms_total / (1e3 * elapsed)) if cg_ms_total is not None else None,
+                  "persistent_cg_fallbacks": fallbacks}
         out = {
             "metric": "PISO steps/s (fwd+adjoint) at %d^2 staggered grid" % n,
             "value": (1 if slab else world) * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
@@ -274,32 +429,80 @@ def main():
                                    "%s" % (n, args.steps, args.tol, args.max_iterations, args.residual_reset,
                                            ("slab-decomposed pressure CG over %d GPUs, rest replicated" % world) if slab else
                                            ("replicas only (one independent grid per GPU)" if world > 1 else "1 GPU")),
-                       "grid": [n, n], "last_cg_iterations_fwd": cg_it, "last_cg_iterations_adjoint": cg_it_adj,
+                       "grid": [n, n], "last_cg_iterations_fwd": P["ps"].last_iterations or 0,
+                       "last_cg_iterations_adjoint": P["ps"].last_adjoint_iterations or 0,
                        "last_bicgstab_iterations": list(P["lin"].last_iterations or ()),
                        "loss": loss, "warn": float(sum(float(w.detach().sum()) for w in warn))},
-            "roofline": roofline,
+            "roofline": roofline, "phases": phases,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            per_step = 2 * (cg_it + cg_it_adj) if cg_it else 4000
+        if world == 1 and not args.no_extras:
             try:
-                out["cpu_baseline"] = cpu_baseline(P, n, args.tol, per_step)
+                out["bicgstab"] = bicgstab_fixed_work(P, n)
+            except Exception as e:
+                out["bicgstab"] = {"error": repr(e)}
+            try:
+                out["other_configs"] = other_configs(device)
+            except Exception as e:
+                out["other_configs"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(P, n, args.tol, int(round(cg_per_step)) or 4000)
             except Exception as e:   # the baseline must never sink the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
+                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    rc = 0
     if world > 1 and not slab and os.environ.get("PISO_BENCH_SLAB_CHECK", "1") != "0":
-        # not part of the metric: exercise the slab-decomposed CG over RCCL on the real multi-GPU node (stderr only)
+        # not part of the metric: exercise the slab-decomposed CG over RCCL on the real multi-GPU node; the result travels
+        # INSIDE the JSON line (`slab_cg_self_check`), a failed or hung check makes the process exit non-zero
         import threading
-        threading.Timer(180.0, lambda: os._exit(0)).start()      # the result line is out; never hang the driver
+
+        def give_up():
+            if rank == 0 and out is not None:
+                out["slab_cg_self_check"] = {"ok": False, "error": "timed out after 180 s"}
+                print(json.dumps(out), flush=True)
+            sys.stderr.write("slab_cg_self_check timed out\n")
+            sys.stderr.flush()
+            os._exit(3)
+        timer = threading.Timer(180.0, give_up)
+        timer.daemon = True
+        timer.start()
         try:
             chk = slab_self_check(n, device, rank, world)
-            if rank == 0:
-                print("slab_cg_self_check " + json.dumps(chk), file=sys.stderr, flush=True)
         except Exception as e:
-            if rank == 0:
-                print("slab_cg_self_check failed: %r" % (e,), file=sys.stderr, flush=True)
-        os._exit(0)
+            chk = {"ok": False, "error": repr(e)}
+        timer.cancel()
+        if rank == 0:
+            out["slab_cg_self_check"] = chk
+        if not chk.get("ok"):
+            rc = 3
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    sys.exit(rc)
+
+
+def other_configs(device):
+    """Driver-visible timings of the smaller BASELINE.json configurations (extra keys, not the headline)."""
+    import torch
+    res = {}
+    P2 = build_problem(256, device, 1e-8, 10000, 1000)                  # config 2: 256^2 periodic, forward only, DNS tolerance
+    with torch.no_grad():
+        run_unrolled(P2, 2, backward=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_unrolled(P2, 10, backward=False)
+        torch.cuda.synchronize()
+        res["config2_256x256_forward_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / 10
+    res["config2_last_cg_iterations"] = P2["ps"].last_iterations
+    P3 = build_mixing_layer(256, 512, device, 1e-6, 10000, 1000)        # config 3: 512x256, fwd + adjoint, 4-step unroll
+    run_unrolled(P3, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_unrolled(P3, 4)
+    torch.cuda.synchronize()
+    res["config3_512x256_fwd_adjoint_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / 4
+    res["config3_last_cg_iterations_fwd_adjoint"] = [P3["ps"].last_iterations, P3["ps"].last_adjoint_iterations]
+    return res
 
 
 if __name__ == "__main__":

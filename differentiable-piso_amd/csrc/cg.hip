@@ -1,6 +1,7 @@
 // Host driver of the single-GPU pressure CG (kernels: cg_kernels.h).  See cg_kernels.h for the design.
 #include "cg_kernels.h"
 #include "cg_persist.h"
+#include "cg_persist1.h"
 #include "options.h"
 #include <cstdio>
 #include <vector>
@@ -16,13 +17,14 @@ struct CgProfile {
   long long count[4] = {0, 0, 0, 0};    // launches of K1, K2; ITERATIONS executed inside persistent segments; segment LAUNCHES
 };
 static CgProfile g_prof;
-constexpr size_t kPersistWsWords = (size_t)2 * kPersistMaxGrid * 16 + 64;   // records (2 x grid x 64 B) + error flag
+constexpr size_t kPersistWsWords = (size_t)2 * kPersistMaxGrid * 32 + 64;   // records (2 x grid x 128 B) + error flag
 
 struct HostPoll {
   CgState* pinned = nullptr;   // [2]
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipEvent_t seg_ev[2] = {nullptr, nullptr};   // timing events around persistent segments (profiling only; created once)
 };
+constexpr int kPersistDefaultExchanges = 1;   // grid-wide exchanges per persistent iteration when cg_exchanges is not set
 static int g_persist_fallbacks = 0;            // solves that were restarted on the two-kernel path after an exchange timed out
 static thread_local HostPoll tl_poll;
 
@@ -48,7 +50,15 @@ static size_t cg_workspace_bytes(int nx, int ny) {
 }
 
 template <typename T, typename CT, bool RECON, bool SYMV>
-static const void* persist_kernel(int R) {
+static const void* persist_kernel(int R, int exchanges) {
+  if (exchanges == 1) {
+    switch (R) {
+      case 2: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 2, RECON, SYMV>);
+      case 4: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 4, 2, RECON, SYMV>);
+      case 8: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 8, 2, RECON, SYMV>);
+      default: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 16, 1, RECON, SYMV>);
+    }
+  }
   switch (R) {
     case 2: return reinterpret_cast<const void*>(&cg_persist<T, CT, 2, 2, RECON, SYMV>);
     case 4: return reinterpret_cast<const void*>(&cg_persist<T, CT, 4, 2, RECON, SYMV>);
@@ -123,6 +133,8 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   PersistCtl pc;
   pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr;
   const int force = opt(OPT_CG_PERSIST), force_r = opt(OPT_CG_PERSIST_R);   // -1: automatic
+  int exchanges = (opt(OPT_CG_EXCHANGES) == 1 || opt(OPT_CG_EXCHANGES) == 2) ? opt(OPT_CG_EXCHANGES) : kPersistDefaultExchanges;
+  if (sizeof(T) != 8) exchanges = 2;   // cg_persist1 is tuned for fp64 state (the fp32 instantiations spill registers)
   if (V == 16 / (int)sizeof(T) && a.per_y != 2 && allow_persist && force != 0) {
     int dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
@@ -150,13 +162,14 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     }
     if (persist_R && n < 16384 && force != 1) persist_R = 0;    // tiny grids: two-kernel path
   }
+  if (persist_R == 8) exchanges = 2;   // (two regions of 8 rows per wave: cg_persist1 spills there; rare shape)
   if (persist_R) {
     // the exchanges spin: EVERY workgroup must be resident at the same time.  What the occupancy calculator says one CU can
     // hold (LDS, registers) times the CUs of the device must cover the grid; what it cannot see (another process, a CU mask)
     // is caught by the spin bound -> restart on the two-kernel path (below).
     constexpr bool kCanSymO = RECON && sizeof(CT) == 4;
-    const void* kfn = persist_kernel<T, CT, RECON, false>(persist_R);
-    if constexpr (kCanSymO) { if (symmetric) kfn = persist_kernel<T, CT, RECON, true>(persist_R); }
+    const void* kfn = persist_kernel<T, CT, RECON, false>(persist_R, exchanges);
+    if constexpr (kCanSymO) { if (symmetric) kfn = persist_kernel<T, CT, RECON, true>(persist_R, exchanges); }
     int per_cu = 0, dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -174,10 +187,16 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     }
   }
   auto launch_segment = [&](int kb, int ke) -> int {
-    PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 64, stream));   // epochs restart at 1 in every launch
+    PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 128, stream));   // epochs restart at 1 in every launch
     constexpr bool kCanSym = RECON && sizeof(CT) == 4;     // the symmetric variant exists for the compact coefficient path
 #define PISO_PERSIST_LAUNCH(SYMV)                                                                                            \
     do {                                                                                                                     \
+      if (exchanges == 1) {                                                                                                  \
+        if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);        \
+        else if (persist_R == 4) cg_persist1<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
+        else if (persist_R == 8) cg_persist1<T, CT, 8, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
+        else cg_persist1<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);                      \
+      } else                                                                                                                 \
       if (persist_R == 2) cg_persist<T, CT, 2, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);        \
       else if (persist_R == 4) cg_persist<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
       else if (persist_R == 8) cg_persist<T, CT, 8, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
@@ -282,7 +301,9 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     std::vector<unsigned long long> h(12 * persist_grid);
     PISO_HIP_CHECK(hipMemcpy(h.data(), pc.timing, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     PISO_HIP_CHECK(hipFree(pc.timing));
-    const char* names[5] = {"phaseA", "barrierA", "phaseB", "barrierB", "(halo loads alone, ablation 5)"};
+    const char* names2[5] = {"phaseA", "barrierA", "phaseB", "barrierB", "-"};
+    const char* names1[5] = {"D (p update, stencil, sums, publish)", "exchange", "U (stencil, x / r update, ring)", "-", "-"};
+    const char** names = exchanges == 1 ? names1 : names2;
     for (int q = 0; q < 5; ++q) {
       double s = 0, mn = 1e300, mx = 0;
       for (int b = 0; b < persist_grid; ++b) { const double v = (double)h[q * persist_grid + b]; s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
@@ -418,6 +439,7 @@ void piso_cg_profile_enable(int enable, int stride) {
 }
 
 int piso_cg_persist_fallbacks(void) { return g_persist_fallbacks; }
+int piso_cg_default_exchanges(void) { return kPersistDefaultExchanges; }
 
 void piso_cg_profile_read(double* ms_sum, long long* count) {
   for (int q = 0; q < 4; ++q) { ms_sum[q] = g_prof.ms[q]; count[q] = g_prof.count[q]; }

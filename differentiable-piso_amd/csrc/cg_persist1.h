@@ -1,0 +1,525 @@
+// Persistent CG segment kernel with ONE grid-wide exchange per iteration (cg_persist.h needs two).
+//
+// Same residency as cg_persist (r, p in registers, x in LDS, float coefficient rows streamed through a circular software
+// pipeline, one workgroup of 512 threads per CU) and the same per-cell arithmetic (zrow: summation order of calcZ_v4,
+// pressure_solve_op.cu.cc:81-90).  What changes is how the two dependent reductions of a CG iteration are obtained:
+//
+//   D(k)  p_k = r_k + beta_k p_{k-1};  z' = L p_k;  local sums  S p, p.r, p.z', r.z', z'.z', S z'
+//         the PERIMETER of z' is published (sc1 stores, ping-pong buffer k & 1)
+//   E(k)  one exchange of 8 sums per workgroup: the six above and  S r_k, #{|r_k| >= accuracy}  left over from U(k-1)
+//         -> alpha_k = p.r / (p.z' + vs S p)                                   (pressure_solve_op.cu.cc:301-302)
+//            r_{k+1}.z'_k = r.z' - alpha (z'.z' + vs S z'),  S r_{k+1} = S r_k - alpha (S z' + N vs)    [r_{k+1} = r_k - alpha (z' + vs)]
+//         -> beta_{k+1} = -(r_{k+1}.z'_k + vs S r_{k+1}) / pz                  (:351-352) without a second reduction
+//         -> the stopping test of iteration k (every 5th, device-flag cadence of :312-335) on #{|r_k| >= accuracy}: it is
+//            evaluated one exchange later than in cg_persist, BEFORE x and r move on, so a converged solve stops in exactly
+//            the reference's state (x_k, iterations = k)
+//   U(k)  z' = L p_k again (same registers, same instructions: bitwise the same);  x += alpha p_k;  r -= alpha (z' + vs);
+//         local  S r_{k+1}, #{|r_{k+1}| >= accuracy}
+//
+// Every region keeps copies of r and p on the ring of cells around it and advances them with the SAME fma's as their
+// owners (bitwise equal), using the published perimeter of z' - so one vector's perimeter crosses the fabric per iteration
+// instead of two, and nothing has to be visible between D and U of one iteration: one exchange.
+// The one-step recurrences start from directly summed quantities in every iteration (no drift); they replace two dot
+// products by algebraically equal expressions, so iterates differ from cg_k1 / cg_k2 at round-off level (like any two
+// summation orders); converged answers and the stopping cadence are the reference's.  A segment starts from and ends in the
+// global-memory state of the two-kernel path, exactly like cg_persist.
+#pragma once
+#include "cg_persist.h"
+
+namespace piso {
+
+constexpr int kX1Values = 8;                     // sums per exchange
+constexpr int kX1RecWords = 16;                  // 8-byte words per record: 2 per sum {32 payload bits | 32-bit epoch}
+
+// Exchange of kX1Values sums per workgroup; same protocol as grid_exchange (tagged 8-byte words, relaxed agent-scope atomics,
+// fixed summation order -> bitwise equal totals in every workgroup).  Measured: with one 128-byte record per LANE (64 cache
+// lines per load instruction) the exchange is bound by the number of fabric transactions (11 us per exchange at 256
+// workgroups).  Here the polling is COALESCED and spread over all 8 waves: lane l reads word l % 16 of record 4 i + l / 16, so
+// one load instruction covers four whole records (512 contiguous bytes); wave w polls records 32 w .. 32 w + 31 with 8 loads
+// per lane, one round trip once the records are there.  Lane pairs (2 q, 2 q + 1) hold the two halves of sum q.
+constexpr int kX1Sm = 160;                        // LDS words per parity: [8 sums][8 waves] | [8 waves][8 sums] | 8 flags
+template <typename T, int KEEP>
+__device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Values], unsigned epoch, T* smem) {
+  typedef unsigned long long u64;
+  constexpr int NV = kX1Values;
+  static_assert(kPersistMaxGrid == kPersistWaves * 32, "every wave polls 32 records");
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  T* sm = smem + (epoch & 1) * kX1Sm;                       // parity double buffer: two __syncthreads per exchange
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = (T)wave_sum_uniform((double)v[q]);
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) sm[q * kPersistWaves + wave] = v[q];
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");   // this wave's write-through stores have completed
+  __syncthreads();
+  u64* rec = c.rec + (size_t)(epoch & 1) * kPersistMaxGrid * kX1RecWords;
+  if (wave == 0) {
+    // lane l < 16 publishes word l: sum l / 2, low half (even l) or high half (odd l) - one store instruction, one cache line
+    const int vq = (lane >> 1) & (NV - 1);
+    T s = 0;
+    for (int w = 0; w < kPersistWaves; ++w) s += sm[vq * kPersistWaves + w];
+    const u64 bits = (u64)__double_as_longlong((double)s);
+    const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+    if (lane < kX1RecWords)
+      __hip_atomic_store(rec + (size_t)blockIdx.x * kX1RecWords + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  bool good = true;
+  {
+    const int wd = lane & 15, sub = lane >> 4;               // my word of the record, my record inside a group of four
+    u64 w[8];
+    bool okl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      w[i] = 0;
+      okl[i] = ((wave * 8 + i) * 4 + sub) >= (int)gridDim.x;  // records beyond the grid count as arrived (payload 0)
+    }
+    unsigned spins = 0;
+    while (true) {
+      bool ok = true;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (!okl[i]) w[i] = __hip_atomic_load(rec + (size_t)((wave * 8 + i) * 4 + sub) * kX1RecWords + wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (!okl[i]) okl[i] = (unsigned)(w[i] & 0xffffffffull) == epoch;
+        ok = ok && okl[i];
+      }
+      if (__all(ok)) break;
+      if (++spins > (1u << 22)) { good = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    // even lanes assemble their sum from their own word (low half) and the neighbour lane's (high half); records of a lane
+    // are added in order, then the four records-per-instruction rows, then (after the barrier) the eight waves
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned hi_other = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(w[i] >> 32), 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+      const u64 bits = (w[i] >> 32) | ((u64)hi_other << 32);
+      acc += __longlong_as_double((long long)bits);          // (odd lanes add garbage that nobody reads; absent records add 0)
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const double t = ((read_lane_c(acc, 2 * q) + read_lane_c(acc, 16 + 2 * q)) + read_lane_c(acc, 32 + 2 * q)) + read_lane_c(acc, 48 + 2 * q);
+      if (lane == 0) sm[64 + wave * NV + q] = (T)t;
+    }
+    if (lane == 0) {
+      sm[128 + wave] = good ? (T)0 : (T)1;
+      if (!good) *c.err = 1;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    T t = 0;
+    for (int w = 0; w < kPersistWaves; ++w) t += sm[64 + w * NV + q];
+    v[q] = uniform(t);
+  }
+  for (int w = 0; w < kPersistWaves; ++w) good = good && (uniform(sm[128 + w]) == (T)0);
+  return good;
+}
+
+template <typename T, typename CT, int R, int NQ, bool RECON, bool SYM>
+__global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, PersistCtl c, int k_begin, int k_end, int sv, int pend) {
+  constexpr int V = 16 / sizeof(T);                        // 16-byte lane accesses
+  static_assert(R * NQ <= 16 && 2 * R <= 64, "at most 16 rows per wave; the edge columns of a region fit one wave-wide load");
+  __shared__ T xs[kPersistWaves * NQ * R * 64 * V];        // the solution of my regions (128 KB at 16 rows per wave, fp64)
+  __shared__ T smem[2 * kX1Sm];
+  // the direction on the rows below / above my regions: parked in LDS (two reads per pass, one read-modify-write per iteration)
+  constexpr bool kParkHalos = (NQ * R < 16) || NQ == 1;     // (two regions of 8 rows: x already fills the LDS)
+  __shared__ T halo_s[kParkHalos ? kPersistWaves * NQ * 2 * 64 * V : 1];
+  const int nx = a.nx, ny = a.ny;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar branches, SGPRs
+  int wg = blockIdx.x;                                     // XCD-contiguous bands (block b is observed on XCD b % 8)
+  if (gridDim.x % kXcds == 0) wg = (blockIdx.x % kXcds) * (gridDim.x / kXcds) + blockIdx.x / kXcds;
+  int j0[NQ], tx0[NQ];
+  bool has[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int reg = (wg * kPersistWaves + wave) * NQ + q;
+    has[q] = reg < c.nreg;
+    const int ty = has[q] ? reg / c.ntx : 0;
+    tx0[q] = has[q] ? reg - ty * c.ntx : 0;
+    j0[q] = ty * R;
+  }
+  const unsigned nbytesT = (unsigned)((size_t)nx * ny * sizeof(T)), nbytesC = (unsigned)((size_t)nx * ny * sizeof(CT));
+  const unsigned rowT = (unsigned)(nx * sizeof(T)), rowC = (unsigned)(nx * sizeof(CT));
+  const rsrc_t Rr = make_rsrc(a.r, nbytesT), Rx = make_rsrc(a.x, nbytesT);
+  const rsrc_t RoS = make_rsrc(a.oS, nbytesC), RoW = make_rsrc(a.oW, nbytesC), RoE = make_rsrc(a.oE, nbytesC), RoN = make_rsrc(a.oN, nbytesC);
+  const rsrc_t RcC = make_rsrc(a.cC, nbytesT);
+  // p[0] / p[1]: the direction of the two-kernel path on entry and exit; in between the ping-pong buffers of the published z'
+  const rsrc_t Rp0 = make_rsrc(a.p[0], nbytesT), Rp1 = make_rsrc(a.p[1], nbytesT);
+  auto row_wrap = [&](int j, bool& valid) __attribute__((always_inline)) -> int {   // scalar: rows outside wrap or vanish
+    valid = true;
+    if (j < 0) { if (!a.per_y) valid = false; return ny - 1; }
+    if (j >= ny) { if (!a.per_y) valid = false; return 0; }
+    return j;
+  };
+
+  // ---- the state of the two-kernel path: r and the direction p_{k-1} of my regions into registers, x into LDS
+  const T alpha0 = pend ? uniform(a.scal[SC_ALPHA]) : (T)0;   // pend: x still lacks alpha p of the iteration before k_begin
+  Vec<T, V> rr[NQ][R], pp[NQ][R];
+  unsigned vT[NQ];
+  // copies of r (registers) and of the direction (LDS / registers, `edge`) on the ring around my regions
+  Vec<T, V> rhb[NQ], rha[NQ], pnb[NQ], pna[NQ];
+  T eR[NQ], edge[NQ];
+  bool vb[NQ], va[NQ], vl[NQ], vr[NQ];                      // is there a cell below / above / left / right of region q at all?
+  {
+    const rsrc_t Rp = (k_begin & 1) ? Rp1 : Rp0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int cq = (tx0[q] * 64 + lane) * V;
+      vT[q] = (unsigned)(cq * sizeof(T));
+      T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
+#pragma unroll
+      for (int jj = 0; jj < R; ++jj) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { rr[q][jj].v[e] = 0; pp[q][jj].v[e] = 0; }
+        if (has[q]) {
+          rr[q][jj] = bld<T, V>(Rr, vT[q], (unsigned)(j0[q] + jj) * rowT);
+          pp[q][jj] = bld<T, V>(Rp, vT[q], (unsigned)(j0[q] + jj) * rowT);
+          // (the two-kernel path defers x += alpha p of its last iteration to the next K1: applied here, on entry)
+          Vec<T, V> xv = bld<T, V>(Rx, vT[q], (unsigned)(j0[q] + jj) * rowT);
+#pragma unroll
+          for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha0, pp[q][jj].v[e], xv.v[e]);
+          stv<T, V>(xl + jj * 64 * V, xv);
+        }
+      }
+      // the ring: rows below / above (out of range beyond a wall -> 0) and the two neighbouring columns
+      // (lane l < R: left neighbour of row l, lane R + l: right neighbour; other lanes and walls read 0)
+      const int jb = row_wrap(j0[q] - 1, vb[q]), ja = row_wrap(j0[q] + R, va[q]);
+      const unsigned hb = (has[q] && vb[q]) ? vT[q] : 0xffffffffu, ha = (has[q] && va[q]) ? vT[q] : 0xffffffffu;
+      rhb[q] = bld<T, V>(Rr, hb, (unsigned)jb * rowT);
+      rha[q] = bld<T, V>(Rr, ha, (unsigned)ja * rowT);
+      pnb[q] = bld<T, V>(Rp, hb, (unsigned)jb * rowT);
+      pna[q] = bld<T, V>(Rp, ha, (unsigned)ja * rowT);
+      const int side = lane / R, er = lane - side * R;
+      int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
+      vl[q] = tx0[q] > 0 || a.per_x;
+      vr[q] = tx0[q] + 1 < c.ntx || a.per_x;
+      if (cc < 0) cc = a.per_x ? nx - 1 : -1;
+      else if (cc >= nx) cc = a.per_x ? 0 : -1;
+      const unsigned vo = (has[q] && side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
+      eR[q] = bld1<T>(Rr, vo, 0);
+      edge[q] = bld1<T>(Rp, vo, 0);
+    }
+  }
+  CgState st = a.state[sv & 1];
+  T pz = uniform(a.scal[SC_PZ]), vs = uniform(a.scal[SC_VS]), alpha = uniform(a.scal[SC_ALPHA]);
+  const T sc_c = uniform(a.scal[SC_C]);
+  const T ncells = (T)((double)nx * (double)ny);
+  // totals of the previous K2 (or previous segment): r.z', sum r, #cells with |r| >= accuracy
+  T tB[3];
+  {
+    T s[3] = {0, 0, 0};
+    if (wave == 0) {
+      for (int b = lane; b < a.nB; b += 64) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) s[q] += a.partsB[q * kMaxPartials + b];
+      }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) s[q] = wave_sum(s[q]);
+      if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) smem[q] = s[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) tB[q] = uniform(smem[q]);
+    __syncthreads();
+  }
+
+  // ---- coefficient pipeline (as in cg_persist): both passes of an iteration stream the coefficient rows of my regions in
+  // the same order; the loads of row t + D are issued when row t has been consumed, circularly.
+  constexpr int coef_regs = ((SYM ? 2 : 4) * (int)sizeof(CT) * V + (RECON ? 0 : (int)sizeof(T) * V)) / 4;   // VGPRs of a row in flight
+  constexpr int NT = NQ * R;
+  constexpr int budget = (NQ == 1 || NT < 16) ? 16 : 8;
+  constexpr int Dw = budget / coef_regs < 2 ? 2 : (budget / coef_regs > kPersistMaxDepth ? kPersistMaxDepth : budget / coef_regs);
+  constexpr int D = (NT >= Dw) ? Dw : NT;
+  constexpr int kBaseLoads = (SYM ? 2 : 4) + (RECON ? 0 : 1);          // vector loads every row issues (some rows one or two more)
+  Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT], cSh[NQ];
+  Vec<T, V> cD[NT];
+  CT eW[NQ];
+  auto coef_offset = [&](int q) __attribute__((always_inline)) -> unsigned {
+    unsigned o = vT[q];
+    asm volatile("" : "+v"(o));
+    return (unsigned)((unsigned long long)o * sizeof(CT) / sizeof(T));
+  };
+  auto issue_coef = [&](int t) __attribute__((always_inline)) {
+    const int q = t / R, jj = t - q * R;
+    const unsigned vCq = coef_offset(q);
+    const unsigned sT = (unsigned)(j0[q] + jj) * rowT, sC = (unsigned)(j0[q] + jj) * rowC;
+    cS[t] = bld<CT, V>(RoS, vCq, sC); cW[t] = bld<CT, V>(RoW, vCq, sC);
+    if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vCq, sC); cN[t] = bld<CT, V>(RoN, vCq, sC); }
+    if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
+    if constexpr (SYM) {
+      if (jj == 0) {                                       // W of the first column of the strip to the right: E of my last column
+        const int side = lane / R, er = lane - side * R;
+        int cc = (tx0[q] + 1) * 64 * V;
+        if (cc >= nx) cc = a.per_x ? 0 : -1;
+        const unsigned vo = (side == 1 && cc >= 0) ? (unsigned)(j0[q] + er) * rowC + (unsigned)(cc * sizeof(CT)) : 0xffffffffu;
+        eW[q] = bld1<CT>(RoW, vo, 0);
+      }
+      if (jj == R - 1) {                                   // S of the row above the region: N of my last row
+        bool valid;
+        const int jw = row_wrap(j0[q] + R, valid);
+        cSh[q] = bld<CT, V>(RoS, valid ? vCq : 0xffffffffu, (unsigned)jw * rowC);
+      }
+    }
+  };
+  // z' = L p of row t of my regions: summation order of calcZ_v4 (pressure_solve_op.cu.cc:81-90).  D and U both call this on
+  // the same registers, so they see bitwise the same z'.
+  auto zrow = [&](int t) __attribute__((always_inline)) -> Vec<T, V> {
+    const int q = t / R, jj = t - q * R;
+    T* hs = halo_s + (kParkHalos ? (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V : 0);
+    const Vec<T, V> behind = (jj > 0) ? pp[q][jj > 0 ? jj - 1 : 0] : (kParkHalos ? ldv<T, V>(hs) : pnb[q]);
+    const Vec<T, V> cur = pp[q][jj];
+    const Vec<T, V> ahead = (jj + 1 < R) ? pp[q][jj + 1 < R ? jj + 1 : jj] : (kParkHalos ? ldv<T, V>(hs + (kParkHalos ? 64 * V : 0)) : pna[q]);
+    const T left = shift_lane<true, T>(cur.v[V - 1], read_lane<T>(edge[q], jj));
+    const T right = shift_lane<false, T>(cur.v[0], read_lane<T>(edge[q], R + jj));
+    Vec<CT, V> kN, kE;
+    if constexpr (SYM) {
+      kN = (jj + 1 < R) ? cS[t + 1 < NT ? t + 1 : t] : cSh[q];
+#pragma unroll
+      for (int e = 0; e + 1 < V; ++e) kE.v[e] = cW[t].v[e + 1];
+      kE.v[V - 1] = shift_lane<false, CT>(cW[t].v[0], read_lane<CT>(eW[q], R + jj));
+    } else {
+      kN = cN[t]; kE = cE[t];
+    }
+    Vec<T, V> kC, z;
+    if constexpr (RECON) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        T d = 0;
+        d -= (T)cS[t].v[e]; d -= (T)kN.v[e]; d -= (T)cW[t].v[e]; d -= (T)kE.v[e];
+        kC.v[e] = d;
+      }
+    } else {
+      kC = cD[t];
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const T pw = (e == 0) ? left : cur.v[e > 0 ? e - 1 : 0];
+      const T pe = (e == V - 1) ? right : cur.v[e < V - 1 ? e + 1 : 0];
+      T tmp = 0;
+      tmp = fma((T)cS[t].v[e], behind.v[e], tmp);
+      tmp = fma((T)cW[t].v[e], pw, tmp);
+      tmp = fma(kC.v[e], cur.v[e], tmp);
+      tmp = fma((T)kE.v[e], pe, tmp);
+      tmp = fma((T)kN.v[e], ahead.v[e], tmp);
+      z.v[e] = tmp;
+    }
+    return z;
+  };
+  // perimeter of row jj of region q (what neighbouring regions read): the whole first / last row, else the two end cells
+  auto publish = [&](rsrc_t Rd, int q, int jj, const Vec<T, V>& val) __attribute__((always_inline)) {
+    const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
+    if (jj == 0 || jj == R - 1) {
+      bst<T, V, kAgent>(Rd, vT[q], sT, val);
+    } else {
+      if (lane == 0) bst1<T, kAgent>(Rd, vT[q], sT, val.v[0]);
+      if (lane == 63) bst1<T, kAgent>(Rd, vT[q] + (unsigned)((V - 1) * sizeof(T)), sT, val.v[V - 1]);
+    }
+  };
+  // ---- z' on the ring, as published by the neighbours (rows below / above, the two neighbouring columns): issued right after
+  // the exchange (every record seen = every perimeter store completed), consumed at the END of U - the row loop hides the trip
+  T eZ[NQ];
+  Vec<T, V> hbZ[NQ], haZ[NQ];
+  auto issue_halos = [&](rsrc_t Rz) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int side = lane / R, er = lane - side * R;
+      int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
+      if (cc < 0) cc = a.per_x ? nx - 1 : -1;
+      else if (cc >= nx) cc = a.per_x ? 0 : -1;
+      const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
+      eZ[q] = bld1<T, kAgent>(Rz, vo, 0);
+      bool vbq, vaq;
+      const int jb = row_wrap(j0[q] - 1, vbq), ja = row_wrap(j0[q] + R, vaq);
+      const unsigned hb = vbq ? vT[q] : 0xffffffffu, ha = vaq ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
+      hbZ[q] = bld<T, V, kAgent>(Rz, hb, (unsigned)jb * rowT);
+      haZ[q] = bld<T, V, kAgent>(Rz, ha, (unsigned)ja * rowT);
+    }
+  };
+  if (has[0]) {
+#pragma unroll
+    for (int t = 0; t < D; ++t) issue_coef(t);
+  }
+
+  unsigned epoch = 0;
+  bool healthy = true, first = true;
+  int k = k_begin;
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = (kPersistDiag && c.timing) ? wall_clock64() : 0;
+  auto tick = [&](int slot) __attribute__((always_inline)) {     // diagnostic builds only (-DPISO_PERSIST_DIAG): D / exchange / U clocks
+    if (kPersistDiag && c.timing) { const unsigned long long t = wall_clock64(); tacc[slot] += t - tlast; tlast = t; }
+  };
+  // the stopping test of iteration k_begin was left to this launch by the previous one (pressure_solve_op.cu.cc:312-335)
+  if (k > 0 && (k % 5) == 0) {
+    const int exceeded = tB[2] > 0;
+    if (st.flag && !exceeded) { st.done = 1; st.iterations = k; }
+    else st.flag = 1;
+  }
+  T rz_next = tB[0], sumr = tB[1], cnt_last = tB[2];          // r_k.z'_{k-1}, sum r_k, #{|r_k| >= accuracy} for the current k
+  T lU[2] = {0, 0};                                           // local sum r, count from the last U (for the next exchange)
+  const T accuracy = uniform((T)a.accuracy);
+  for (; k < k_end && healthy && !st.done; ++k) {
+    // z'_k is published into p[(k + 1) & 1]: at entry p[k_begin & 1] still holds the direction other workgroups may be loading;
+    // consecutive iterations alternate buffers (a neighbour's loads of z'_k are consumed before it publishes its record k + 1,
+    // which everybody needs before writing the same buffer again in iteration k + 2)
+    const rsrc_t Rz = (k & 1) ? Rp0 : Rp1;
+    const T beta = uniform(-(rz_next + vs * sumr) / pz);     // (:351-352), unguarded as coded
+    // ---- D(k): p = r + beta p on my cells and on the ring; z' = L p; sums; the perimeter of z' goes out
+    T sD[kX1Values] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (has[0]) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) pp[q][jj].v[e] = fma(beta, pp[q][jj].v[e], rr[q][jj].v[e]);
+        }
+        edge[q] = fma(beta, edge[q], eR[q]);
+        T* hs = halo_s + (kParkHalos ? (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V : 0);
+        if constexpr (kParkHalos) {
+          if (!first) { pnb[q] = ldv<T, V>(hs); pna[q] = ldv<T, V>(hs + 64 * V); }
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          pnb[q].v[e] = fma(beta, pnb[q].v[e], rhb[q].v[e]);
+          pna[q].v[e] = fma(beta, pna[q].v[e], rha[q].v[e]);
+        }
+        if constexpr (kParkHalos) {
+          stv<T, V>(hs, pnb[q]);
+          stv<T, V>(hs + 64 * V, pna[q]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int q = t / R, jj = t - q * R;
+        const Vec<T, V> z = zrow(t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          sD[0] += pp[q][jj].v[e];
+          sD[1] = fma(pp[q][jj].v[e], rr[q][jj].v[e], sD[1]);
+          sD[2] = fma(pp[q][jj].v[e], z.v[e], sD[2]);
+          sD[3] = fma(rr[q][jj].v[e], z.v[e], sD[3]);
+          sD[4] = fma(z.v[e], z.v[e], sD[4]);
+          sD[5] += z.v[e];
+        }
+        publish(Rz, q, jj, z);
+        PISO_SB_A1;
+        if constexpr (D < NT) issue_coef(t + D < NT ? t + D : t + D - NT);   // wraps: rows 0 .. D-1 again, for U
+        PISO_SB_A2;
+      }
+    }
+    sD[6] = lU[0]; sD[7] = lU[1];
+    ++epoch;
+    tick(0);
+    // (the last row's perimeter store is followed by exactly one row of coefficient loads)
+    healthy = grid_exchange8<T, (D < NT) ? kBaseLoads : 0>(c, sD, epoch, smem);
+    tick(1);
+    if (!healthy) break;
+    // ---- the stopping test of iteration k, one exchange late but before anything moves (x = x_k): (:312-335)
+    if (!first) {
+      sumr = sD[6]; cnt_last = sD[7];
+      if (k > 0 && (k % 5) == 0) {
+        const int exceeded = cnt_last > 0;
+        if (st.flag && !exceeded) { st.done = 1; st.iterations = k; }
+        else st.flag = 1;
+      }
+      if (st.done) break;
+    }
+    first = false;
+    // ---- alpha (:301-302) and, by one-step recurrences from the direct sums, what beta of the next iteration needs
+    vs = uniform(sc_c * sD[0]);
+    pz = uniform(sD[2] + vs * sD[0]);
+    alpha = uniform((absval(pz) > 0) ? sD[1] / pz : (T)0);
+    rz_next = uniform(sD[3] - alpha * (sD[4] + vs * sD[5]));
+    sumr = uniform(sumr - alpha * (sD[5] + ncells * vs));
+    // ---- U(k): z' again, x += alpha p, r -= alpha (z' + vs) on my cells and on the ring
+    lU[0] = 0; lU[1] = 0;
+    if (has[0]) {
+      issue_halos(Rz);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int q = t / R, jj = t - q * R;
+        T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V + jj * 64 * V;
+        Vec<T, V> xv = ldv<T, V>(xl);                        // x += alpha p (:303); the LDS latency hides under the stencil
+        const Vec<T, V> z = zrow(t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha, pp[q][jj].v[e], xv.v[e]);
+        stv<T, V>(xl, xv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const T rn = fma(-alpha, z.v[e] + vs, rr[q][jj].v[e]);
+          rr[q][jj].v[e] = rn;
+          lU[0] += rn;
+          lU[1] += (absval(rn) < accuracy) ? (T)0 : (T)1;
+        }
+        PISO_SB_B1;
+        if constexpr (D < NT) issue_coef(t + D < NT ? t + D : t + D - NT);   // wraps: rows 0 .. D-1 for D of the next iteration
+        PISO_SB_B2;
+      }
+      // the ring: the same update with the neighbours' z' (beyond a wall there is no cell: the copies stay 0)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const T vsb = vb[q] ? vs : (T)0, vsa = va[q] ? vs : (T)0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          rhb[q].v[e] = fma(-alpha, hbZ[q].v[e] + vsb, rhb[q].v[e]);
+          rha[q].v[e] = fma(-alpha, haZ[q].v[e] + vsa, rha[q].v[e]);
+        }
+        const int side = lane / R;
+        const T vse = (side == 0) ? (vl[q] ? vs : (T)0) : ((side == 1) ? (vr[q] ? vs : (T)0) : (T)0);
+        eR[q] = fma(-alpha, eZ[q] + vse, eR[q]);
+      }
+    }
+    tick(2);
+  }
+  if (kPersistDiag && c.timing && threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) c.timing[q * gridDim.x + blockIdx.x] += tacc[q];
+  }
+  // ---- the last U's sum r and count are only known per workgroup: one more exchange (once per segment)
+  T tOut[3] = {rz_next, sumr, cnt_last};
+  if (!first && healthy && !st.done) {
+    T sX[kX1Values] = {0, 0, 0, 0, 0, 0, lU[0], lU[1]};
+    ++epoch;
+    healthy = grid_exchange8<T, 0>(c, sX, epoch, smem);
+    tOut[1] = sX[6]; tOut[2] = sX[7];
+  }
+
+  // ---- back to the global-memory state of the two-kernel path (iteration k reads its direction from p[k & 1])
+  {
+    const rsrc_t Rp = (k & 1) ? Rp1 : Rp0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      if (has[q]) {
+        T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) {
+          const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
+          bst<T, V>(Rr, vT[q], sT, rr[q][jj]);
+          bst<T, V>(Rp, vT[q], sT, pp[q][jj]);
+          bst<T, V>(Rx, vT[q], sT, ldv<T, V>(xl + jj * 64 * V));
+        }
+      }
+  }
+  if (blockIdx.x == 0) {
+    // the next launch (cg_k1 with do_check, or another segment) finds the last K2-totals in record 0 of partsB
+    for (int b = threadIdx.x; b < a.nB; b += kPersistThreads) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a.partsB[q * kMaxPartials + b] = (b == 0) ? tOut[q] : (T)0;
+    }
+    if (threadIdx.x == 0) {
+      a.scal[SC_PZ] = pz; a.scal[SC_VS] = vs; a.scal[SC_ALPHA] = alpha;
+      a.state[0] = st; a.state[1] = st;
+      if (!healthy) *c.err = 1;
+    }
+  }
+}
+
+}  // namespace piso

@@ -31,6 +31,7 @@ lib.piso_set_option.restype = _i
 lib.piso_get_option.argtypes = [C.c_char_p, _ip]
 lib.piso_get_option.restype = _i
 lib.piso_cg_persist_fallbacks.restype = _i
+lib.piso_cg_default_exchanges.restype = _i
 lib.piso_csr_nnz.argtypes = [_i, _i, _i, _i, _ip, _ip]
 lib.piso_csr_nnz.restype = None
 lib.piso_assemble_csr.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _f, _vp]
@@ -57,6 +58,23 @@ for _n in ("piso_multi_bicgstab_ilu_f32", "piso_multi_bicgstab_ilu_f64"):
 lib.piso_csr_matvec_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]
 lib.piso_csr_matvec_f32.restype = _i
 
+
+lib.piso_pad_velocity.argtypes = [_vp, _vp, _i, _i, _i, _i, _vp]
+lib.piso_pad_velocity.restype = _i
+lib.piso_a0_vfirst.argtypes = [_vp, _vp, _i, _i, _f, _f, _vp]
+lib.piso_a0_vfirst.restype = _i
+lib.piso_face_forward.argtypes = [_i, _i, _i, _ip, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+lib.piso_face_forward.restype = _i
+lib.piso_face_backward.argtypes = [_i, _i, _i, _ip, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+lib.piso_face_backward.restype = _i
+lib.piso_divergence.argtypes = [_vp, _vp, _i, _i, _f, _f, _f, _vp]
+lib.piso_divergence.restype = _i
+lib.piso_divergence_adjoint.argtypes = [_vp, _vp, _i, _i, _i, _i, _f, _f, _f, _vp]
+lib.piso_divergence_adjoint.restype = _i
+lib.piso_h_contribution.argtypes = [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]
+lib.piso_h_contribution.restype = _i
+lib.piso_h_contribution_adjoint.argtypes = [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]
+lib.piso_h_contribution_adjoint.restype = _i
 
 lib.piso_comm_unique_id.argtypes = [_vp]
 lib.piso_comm_unique_id.restype = _i

@@ -111,6 +111,8 @@ class _LinearSolveFn(torch.autograd.Function):
         x, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, solver.max_iterations,
                                            transpose, solver.band_rows, warn)
         solver.last_iterations = its
+        solver.stats["solves"] += 1
+        solver.stats["iterations"] += max(its)
         # the reference's backward op receives the SAME warn buffer the forward op aliased and mutated
         # (linear_solver.py:165-173, multi_bicgstab_ilu_linear_solve_op.cc:136-140): a forward warning zeroes the gradient
         ctx.save_for_backward(values, row_ptr, col_indices, x0, warn.clone())
@@ -126,6 +128,8 @@ class _LinearSolveFn(torch.autograd.Function):
         df, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, ds.to(values.dtype), x0, nx, ny, tol,
                                             solver.max_iterations, not transpose, solver.band_rows, warn_b)
         solver.last_adjoint_iterations = its
+        solver.stats["adjoint_solves"] += 1
+        solver.stats["adjoint_iterations"] += max(its)
         df = df.to(torch.float32) * (1.0 - warn_b.to(torch.float32)[0])
         return df, None, None, None, None, None, None, None, None, None
 
@@ -144,6 +148,7 @@ class LinearSolverCudaMultiBicgstabILU(LinearSolver):
         self.band_rows = band_rows
         self.last_iterations = None
         self.last_adjoint_iterations = None
+        self.stats = dict(solves=0, iterations=0, adjoint_solves=0, adjoint_iterations=0)   # cumulative (max over u, v per solve)
 
     def solve(self, matrix_values, row_ptr, col_indices, rhs, staggered_shape, initial_guess=None, offset=0,
               transpose=False, unrolling_step=0, warn=None):
@@ -214,6 +219,8 @@ class _PressureSolveFn(torch.autograd.Function):
         x, it = solver._cg(nx, ny, per_x, per_y, L, divergence, _scalar(solver.accuracy), solver.max_iterations,
                            rank_deficient, solver.residual_reset)
         solver.last_iterations = it
+        solver.stats["solves"] += 1
+        solver.stats["iterations"] += it
         ctx.save_for_backward(L)
         ctx.meta = (solver, nx, ny, per_x, per_y, rank_deficient, divergence.shape)
         iterations = torch.tensor([it], dtype=torch.int32, device=divergence.device)
@@ -226,6 +233,8 @@ class _PressureSolveFn(torch.autograd.Function):
         g, it = solver._cg(nx, ny, per_x, per_y, L, dp.reshape(-1), _scalar(solver.accuracy), solver.max_iterations,
                            rank_deficient, solver.residual_reset)
         solver.last_adjoint_iterations = it
+        solver.stats["adjoint_solves"] += 1
+        solver.stats["adjoint_iterations"] += it
         return g.reshape(shape).to(torch.float32), None, None, None, None, None, None, None
 
 
@@ -252,6 +261,7 @@ class PisoPressureSolverCudaCustom(PoissonSolver):
         self.last_iterations = None
         self.last_adjoint_iterations = None
         self.slab_comm = None        # distributed.SlabCommunicator: decompose the CG into y-slabs over the ranks (fp64 only)
+        self.stats = dict(solves=0, iterations=0, adjoint_solves=0, adjoint_iterations=0)   # cumulative; callers may reset
 
     def _cg(self, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient, residual_reset):
         if self.slab_comm is not None and self.slab_comm.world > 1 and L.dtype == torch.float64:

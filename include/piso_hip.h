@@ -98,6 +98,39 @@ int piso_csr_matvec_f32(const float* csr_val, const int* csr_rowptr, const int* 
                         int nx, int ny, int transpose, piso_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Fused stencil glue of the step on the flat "u-first" face layout, forward and reverse mode (csrc/glue.hip).  Replaces the
+ * TensorFlow / PhiFlow-math ops of diffpiso/piso_tf.py:36-73 and diffpiso/piso_helpers.py:35-55 (custom_padded), :169-172
+ * (arrange_rhs_term_tf), :226-274 (finite_volume_gradient_tensor, circular_padded_gradient), :277-310
+ * (finite_volume_divergence) and :223 (the H combination).  The reverse-mode entries implement the reference's custom
+ * gradients, including their deviations from the exact transpose.
+ *   pad_modes   int[4] = pressure extrapolation (x_lo, x_hi, y_lo, y_hi): 0 'constant' (zero), 1 'boundary' (edge), 2 'periodic'
+ *   accessible  [(ny+2)(nx+2)] padded cell mask of the gradient (piso_helpers.py:255-265) or NULL (no mask)
+ *   a_flat      [n_u+n_v] the "A" array of piso_assemble_csr;  dirichlet [n_u+n_v] bytes or NULL;  hx, hy = (dx, dy)
+ * piso_face_forward, by mode (G = masked finite-volume pressure gradient on the faces):
+ *   0 RHS    out0 = dirichlet ? -in2 : in0 * beta - G(p) [+ in1 * dxdy]     in0 velocity, in1 forcing or NULL, in2 Dirichlet values
+ *   1 CORR1  out0 = in0 - (G(p) / (beta - A)) / dxdy ; out1 = out0 - in0     in0 = u*
+ *   2 FINAL  out0 = in0 + (in1 - G(p) / dxdy) / (beta - A)                   in0 = u**, in1 = H
+ * piso_face_backward: d_in* and d_p from d_out0 [, d_out1]; NULL d_in1 / d_in2 are skipped.
+ * ------------------------------------------------------------------------------------------------------------- */
+int piso_pad_velocity(const float* vel_flat, float* vel_pad, int nx, int ny, int periodic_x, int periodic_y, piso_stream_t stream);
+int piso_a0_vfirst(const float* a_flat, float* a0_vfirst, int nx, int ny, float beta, float dx_factor, piso_stream_t stream);
+int piso_face_forward(int mode, int nx, int ny, const int* pad_modes, float dxdy, float hx, float hy, float beta, const float* p,
+                      const float* accessible, const float* a_flat, const float* in0, const float* in1, const float* in2,
+                      const uint8_t* dirichlet, float* out0, float* out1, piso_stream_t stream);
+int piso_face_backward(int mode, int nx, int ny, const int* pad_modes, float dxdy, float hx, float hy, float beta,
+                       const float* accessible, const float* a_flat, const uint8_t* dirichlet, const float* d_out0,
+                       const float* d_out1, float* d_in0, float* d_in1, float* d_in2, float* d_p, piso_stream_t stream);
+int piso_divergence(const float* faces, float* div, int nx, int ny, float dxdy, float hx, float hy, piso_stream_t stream);
+int piso_divergence_adjoint(const float* d_div, float* d_faces, int nx, int ny, int periodic_x, int periodic_y, float dxdy, float hx,
+                            float hy, piso_stream_t stream);
+/* h = m_delta - (A - beta) delta ; h_over_bma = h / (beta - A)   (piso_helpers.py:223, piso_tf.py:66) and its reverse mode:
+ * d_m_delta = d_h + d_h_over_bma / (beta - A) ; d_delta = -(A - beta) d_m_delta   (d_h may be NULL) */
+int piso_h_contribution(const float* m_delta, const float* delta, const float* a_flat, float beta, float* h, float* h_over_bma, int nx,
+                        int ny, piso_stream_t stream);
+int piso_h_contribution_adjoint(const float* d_h, const float* d_h_over_bma, const float* a_flat, float beta, float* d_m_delta,
+                                float* d_delta, int nx, int ny, piso_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Pressure matrix.  Replaces LaplaceMatrixKernelLauncher (CUDAsrc/pressure_solve_op.cc:78-84,
  * CUDAsrc/laplace_op.cu.cc:79-239).
  * ------------------------------------------------------------------------------------------------------------- */
@@ -140,6 +173,11 @@ int piso_cg_fixed_iterations_f64(int nx, int ny, int periodic_x, int periodic_y,
  * them), [3] count[3] = number of segment launches (ms_sum[3] unused). */
 void piso_cg_profile_enable(int enable, int stride);
 void piso_cg_profile_read(double* ms_sum, long long* count);
+/* Solves (since load) that were restarted on the two-kernel path because a grid-wide exchange of the persistent kernel timed
+ * out (workgroups not co-resident: CU mask, another process on the GPU).  0 on a dedicated GPU. */
+int piso_cg_persist_fallbacks(void);
+/* Grid-wide exchanges per iteration of the persistent kernel when the option cg_exchanges is not set (1 or 2). */
+int piso_cg_default_exchanges(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Slab-decomposed pressure CG (no counterpart in the reference, which is single-GPU).

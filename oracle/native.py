@@ -23,7 +23,49 @@ def build(force=False):
     return _LIB
 
 
+_LIB_OMP = os.path.join(_HERE, "_build", "libpiso_oracle_omp.so")
+_SRC_OMP = os.path.join(_HERE, "piso_oracle_omp.c")
+
+
+def build_omp(force=False):
+    """Compile the OpenMP variant of the oracle CG. Output: oracle/_build/libpiso_oracle_omp.so."""
+    os.makedirs(os.path.dirname(_LIB_OMP), exist_ok=True)
+    if force or not os.path.isfile(_LIB_OMP) or os.path.getmtime(_LIB_OMP) < os.path.getmtime(_SRC_OMP):
+        subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-fvisibility=hidden", "-fopenmp",
+                               "-ffp-contract=off", _SRC_OMP, "-o", _LIB_OMP, "-lm"])
+    return _LIB_OMP
+
+
 _lib = None
+_lib_omp = None
+
+
+def lib_omp():
+    global _lib_omp
+    if _lib_omp is None:
+        _lib_omp = C.CDLL(build_omp())
+    return _lib_omp
+
+
+def omp_threads():
+    return int(lib_omp().oracle_omp_max_threads())
+
+
+def cg_solve_omp(nx, ny, per_x, per_y, L, b, accuracy, max_iterations, rank_deficient, reset_steps, threads=None,
+                 history=False):
+    """oracle_cg_f64 on all host cores (deterministic chunked reductions). Returns (x, iterations[, max|r| history])."""
+    N = nx * ny
+    L = np.ascontiguousarray(L, np.float64).ravel()
+    b = np.ascontiguousarray(b, np.float64).ravel()
+    x, p, z, r = (np.zeros(N, np.float64) for _ in range(4))
+    if threads:
+        lib_omp().oracle_omp_set_threads(int(threads))
+    hist = np.zeros(max_iterations, np.float64) if history else None
+    ct = C.c_double
+    it = lib_omp().oracle_cg_f64_omp(nx, ny, int(per_x), int(per_y), _p(L, ct), _p(b, ct), _p(x, ct), _p(p, ct), _p(z, ct),
+                                     _p(r, ct), C.c_float(accuracy), int(max_iterations), int(rank_deficient), int(reset_steps),
+                                     _p(hist, ct) if history else None)
+    return (x, it, hist[:it]) if history else (x, it)
 
 
 def lib():

@@ -18,6 +18,16 @@ from . import native
 
 f32 = np.float32
 
+# Which C oracle runs the pressure CG: the single-threaded one (default) or its OpenMP twin (full-size fixtures,
+# tests/golden/make_golden_configs.py; same algorithm and control flow, deterministic chunked reductions).
+USE_OMP_CG = False
+
+
+def _cg(nx, ny, per_x, per_y, L, b, tol, max_it, rank_deficient, reset, dt):
+    if USE_OMP_CG and dt == np.float64:
+        return native.cg_solve_omp(nx, ny, per_x, per_y, L, b, tol, max_it, rank_deficient, reset)
+    return native.cg_solve(nx, ny, per_x, per_y, L, b, tol, max_it, rank_deficient, reset, dt)
+
 
 # ------------------------------------------------------------------------------------------------ layout
 def unstack_staggered(t):
@@ -274,8 +284,8 @@ def pressure_solve(setup, a0_t, div):
     dt = np.float64 if s.p_double else np.float32
     a0 = flatten_staggered(np.asarray(a0_t, f32), coord_flip=False)
     L = native.laplace_matrix(s.nx, s.ny, s.active, s.accessible, a0, dt)
-    x, it = native.cg_solve(s.nx, s.ny, s.periodic_yx[1], s.periodic_yx[0], L, np.asarray(div).astype(dt).ravel(),
-                            s.p_tol, s.p_max_it, s.rank_deficient, s.p_reset, dt)
+    x, it = _cg(s.nx, s.ny, s.periodic_yx[1], s.periodic_yx[0], L, np.asarray(div).astype(dt).ravel(),
+                s.p_tol, s.p_max_it, s.rank_deficient, s.p_reset, dt)
     return x.reshape(s.ny, s.nx).astype(f32), it, L
 
 
@@ -332,8 +342,9 @@ def piso_step_backward(setup, tape, d_vel_new_t, d_p_new):
 
     def psolve_adj(dp):
         dt = np.float64 if s.p_double else np.float32
-        x, _ = native.cg_solve(s.nx, s.ny, s.periodic_yx[1], s.periodic_yx[0], T["L1"], dp.astype(dt).ravel(),
-                               s.p_tol, s.p_max_it, s.rank_deficient, s.p_reset, dt)
+        x, it = _cg(s.nx, s.ny, s.periodic_yx[1], s.periodic_yx[0], T["L1"], dp.astype(dt).ravel(),
+                    s.p_tol, s.p_max_it, s.rank_deficient, s.p_reset, dt)
+        T.setdefault("adjoint_its", []).append(it)
         return x.reshape(s.ny, s.nx).astype(f32)
 
     d_p = dPn.copy()

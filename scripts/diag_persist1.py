@@ -1,0 +1,39 @@
+"""persist1 (one exchange) vs two-kernel path: where does the difference appear?  Usage: python scripts/diag_persist1.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
+import torch
+import diffpiso._native as N
+from diffpiso.solvers import cg_solve_native, laplace_matrix_native
+
+def case(nx, ny, walls=False, seed=11):
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu"); g.manual_seed(seed)
+    a0 = 0.5 + torch.rand(nx * (ny + 1) + (nx + 1) * ny, generator=g)
+    a0v = a0[:nx * (ny + 1)].view(ny + 1, nx); a0u = a0[nx * (ny + 1):].view(ny, nx + 1)
+    a0v[ny] = a0v[0]; a0u[:, nx] = a0u[:, 0]
+    a0 = a0.to(dev)
+    act = torch.ones((ny + 2, nx + 2))
+    if walls:
+        act[0, :] = 0; act[-1, :] = 0; act[:, 0] = 0; act[:, -1] = 0
+    act = act.reshape(-1).to(dev)
+    L = laplace_matrix_native(nx, ny, act, act, a0, torch.float64)
+    b = torch.randn(nx * ny, generator=g, dtype=torch.float64).to(dev); b -= b.mean()
+    return L, b
+
+import itertools
+for (nx, ny, rows) in [(2048, 2048, 16), (1024, 2048, 16), (2048, 512, 16), (1024, 1024, 2), (2048, 1024, 4), (512, 512, 2)]:
+    L, b = case(nx, ny)
+    for seg in (1000, 7):
+        out = []
+        for nit in (1, 2, 3, 5, 10, 40, 150):
+            N.set_option("cg_persist", 0)
+            xa, _ = cg_solve_native(nx, ny, True, True, L, b, 1e-30, nit, False, 1000)
+            res = []
+            for ex in (2, 1):
+                N.set_option("cg_persist", 1); N.set_option("cg_persist_r", rows); N.set_option("cg_segment", seg); N.set_option("cg_exchanges", ex)
+                xb, _ = cg_solve_native(nx, ny, True, True, L, b, 1e-30, nit, False, 1000)
+                res.append(float((xa - xb).abs().max() / xa.abs().max()))
+            out.append("%d: %.1e/%.1e" % (nit, res[0], res[1]))
+        print("grid %dx%d R=%d seg=%d  [nit: diff 2-exchange / 1-exchange]  " % (nx, ny, rows, seg) + "  ".join(out), flush=True)
+print("fallbacks", N.lib.piso_cg_persist_fallbacks())

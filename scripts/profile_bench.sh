@@ -1,14 +1,23 @@
 #!/bin/bash
-# Run on the GPU box via gpurun: rocprofv3 kernel-trace stats of the default bench + PMC passes (HBM bytes) on a shortened run.
-# Raw traces stay in /tmp on the box; only summaries are copied to gpurun_out/ (64 MiB cap).
+# Run on the GPU box via gpurun: the profiling recipe behind profiles/.
+#   1. rocprofv3 --kernel-trace --stats of the default bench (1 step)                     -> <tag>_bench2048_kernel_stats.csv
+#   2. PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, kernel-trace only) on a run shortened with --max-iterations 150
+#   3. the same two PMC passes on scripts/_bin/pmc_calib (known byte counts per launch: calibration of the counters)
+#   4. rocprofv3 --kernel-trace --stats of a fixed-work BiCGStab run (scripts/bench_bicg.py)  -> <tag>_bicgstab2048_kernel_stats.csv
+#   5. scripts/make_traffic_json.py condenses 2 + 3 into traffic.json (with the sha of the kernel sources it was measured on)
+# Raw traces stay in /tmp on the box; only summaries are copied to gpurun_out/prof/ (64 MiB cap).  Usage: profile_bench.sh <tag>
 R=$GRAFT_REPO_ROOT
+TAG=${1:-rXX}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/stats_run.log 2>&1
-find /tmp/prof_stats -type f | head -20 > $OUT/stats_files.txt
-for f in $(find /tmp/prof_stats -name "*stats*.csv"); do cp $f $OUT/; done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --max-iterations 150 > $OUT/fetch_run.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --max-iterations 150 > $OUT/write_run.log 2>&1
-find /tmp/prof_fetch /tmp/prof_write -type f | head -20 >> $OUT/stats_files.txt
-python3 $R/scripts/summarize_pmc.py /tmp/prof_fetch /tmp/prof_write > $OUT/pmc_summary.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_stats_run.log 2>&1
+for f in $(find /tmp/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/${TAG}_bench2048_kernel_stats.csv; done
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --max-iterations 150 > $OUT/${TAG}_fetch_run.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --max-iterations 150 > $OUT/${TAG}_write_run.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/calib_fetch -o calib -- $R/scripts/_bin/pmc_calib > $OUT/${TAG}_calib_fetch_run.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/calib_write -o calib -- $R/scripts/_bin/pmc_calib > $OUT/${TAG}_calib_write_run.log 2>&1
+python3 $R/scripts/summarize_pmc.py /tmp/prof_fetch /tmp/prof_write /tmp/calib_fetch /tmp/calib_write > $OUT/${TAG}_bench2048_pmc_fetch_write_summary.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bicg -o bicg -- python3 $R/scripts/bench_bicg.py 2048 > $OUT/${TAG}_bicg_run.log 2>&1
+for f in $(find /tmp/prof_bicg -name "*kernel_stats.csv"); do cp $f $OUT/${TAG}_bicgstab2048_kernel_stats.csv; done
+python3 $R/scripts/make_traffic_json.py $OUT/${TAG}_bench2048_pmc_fetch_write_summary.txt $TAG > $OUT/traffic.json 2> $OUT/${TAG}_traffic.log

@@ -157,7 +157,8 @@ def _persist_iterations():
 @pytest.mark.parametrize("shape,reset,segment,rows", [((16, 128), 1000, 7, 2), ((64, 256), 200, 16, 8), ((36, 384), 1000, 1000, 2),
                                                       ((32, 128), 1000, 30, 4), ((16, 256), 25, 1000, 8),
                                                       ((32, 128), 1000, 9, 16), ((64, 256), 300, 1000, 16)])
-def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, piso_option):
+@pytest.mark.parametrize("exchanges", [2, 1])
+def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, exchanges, piso_option):
     """The persistent segment kernel (cg_persist.h: r / z' in registers, x in LDS, grid-wide exchanges instead of launches)
     is the path the 2048^2 benchmark runs; force it on small grids and hold it to the same bar as the two-kernel path:
     round-off level agreement with the oracle along the trajectory, across segment boundaries and residual resets, and the
@@ -169,6 +170,7 @@ def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, 
     piso_option("cg_persist", 1)
     piso_option("cg_segment", segment)
     piso_option("cg_persist_r", rows)     # region height (2 / 4 / 8 / 16 rows): four kernel instantiations
+    piso_option("cg_exchanges", exchanges)   # cg_persist (two grid exchanges per iteration) / cg_persist1 (one; 8-row regions keep two)
     N.lib.piso_cg_profile_enable(1, 8)
     try:
         for nit in (2, 3, 9, 23, 47):
@@ -210,10 +212,12 @@ def test_cg_persistent_symmetric_streaming_is_bitwise_neutral(name, piso_option)
     assert np.abs(x1.cpu().numpy() - xo).max() <= 1e-6 * np.abs(xo).max()
 
 
-def test_cg_persistent_shift_nan_and_float32(piso_option):
+@pytest.mark.parametrize("exchanges", [2, 1])
+def test_cg_persistent_shift_nan_and_float32(exchanges, piso_option):
     from diffpiso.solvers import cg_solve_native
     from diffpiso import _native as N
     piso_option("cg_persist", 1)
+    piso_option("cg_exchanges", exchanges)
     piso_option("cg_segment", 25)
     s, L, b = _laplace_case("periodic", 32, 256, seed=2)
     N.lib.piso_cg_profile_enable(1, 8)

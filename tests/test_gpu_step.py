@@ -119,8 +119,9 @@ def test_unrolled_adjoint_matches_oracle(name, steps, cut):
         assert vel_t.grad is None or float(vel_t.grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("exchanges", [2, 1])
 @pytest.mark.parametrize("name,shape", [("periodic", (32, 128)), ("xper_ywall", (32, 128))])
-def test_unrolled_16_steps_adjoint_through_persistent_cg(name, shape, piso_option):
+def test_unrolled_16_steps_adjoint_through_persistent_cg(name, shape, exchanges, piso_option):
     """The north star's bar itself: forward + 16-step unrolled adjoint within 1e-5 relative L2 of the reference algorithm,
     with every pressure solve (forward and adjoint) running inside the persistent CG kernel that the 2048^2 benchmark uses
     (forced here: the grid is small)."""
@@ -128,6 +129,7 @@ def test_unrolled_16_steps_adjoint_through_persistent_cg(name, shape, piso_optio
     import diffpiso as dp
     from diffpiso import _native as N
     piso_option("cg_persist", 1)
+    piso_option("cg_exchanges", exchanges)
     steps = 16
     c = make_case(name, shape[0], shape[1], seed=8)
     kw = dict(SOLVER, lin_double=True, lin_tol=1e-10)
@@ -200,8 +202,8 @@ def test_run_piso_steps_reference_call_returns_nine_values():
             dirichlet_update_fn=lambda i, _: dv_of(i))
     finally:
         sim.dirichlet_values = c["dirichlet_values"]
-    for a, b in zip(vel_arrays, v2):
-        assert torch.equal(a, b.staggered_tensor())
+    for a, b in zip(vel_arrays, v2):      # (not bitwise: MIOpen may pick another convolution algorithm on the second evaluation)
+        assert torch.allclose(a, b.staggered_tensor(), rtol=1e-5, atol=1e-6)
     # the inlet faces of step i carry bcx + bc_placeholders[i]
     for i in range(steps):
         np.testing.assert_allclose(vel_arrays[i][0, :ny, 0, 1].detach().cpu().numpy(), (bcx + pert[i])[0, 1:-1, 0, 0], atol=1e-6)
