@@ -86,6 +86,38 @@ def pressure_extrapolation(boundaries):
     return Material.accessible_extrapolation_mode(boundaries)
 
 
+def assemble_from_padded(vel_pad, nx, ny, dx_yx, per_x, per_y, dirichlet_mask_flat, active_mask, viscosity, no_slip_wall_mask, beta):
+    """The CentralDifferenceMatrixCsr call of advection_matrix_cuda (piso_tf.py:95-123) on an already padded, flattened
+    velocity.  Returns (matrix_values, row_pointers, column_indices, A_flat, matrix_nnz)."""
+    dev = vel_pad.device
+    dx = dx_yx
+    grid_spacing = np.array([dx[1], dx[0]], dtype=np.float32)               # :96
+    cell_area = (np.prod(dx) / np.array([dx[1], dx[0]], dtype=np.float32)).astype(np.float32)   # :97
+    nnz_u, nnz_v = C.c_int(0), C.c_int(0)
+    N.lib.piso_csr_nnz(nx, ny, int(per_x), int(per_y), C.byref(nnz_u), C.byref(nnz_v))
+    n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
+    nnz = nnz_u.value + nnz_v.value
+    csr_val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    csr_col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    csr_row = torch.empty(n_u + n_v + 2, dtype=torch.int32, device=dev)
+    diag = torch.empty(n_u + n_v, dtype=torch.float32, device=dev)
+    visc = as_tensor(viscosity, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    is_field = int(visc.numel() > 1)
+    if is_field and visc.numel() != n_u + n_v:
+        raise ValueError("viscosity field must have n_u + n_v entries (u first)")
+    dmask = dirichlet_mask_flat if dirichlet_mask_flat.dtype == torch.uint8 else dirichlet_mask_flat.ne(0).to(torch.uint8)
+    act = as_tensor(active_mask, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    if act.numel() != (nx + 2) * (ny + 2):
+        raise ValueError("active_mask must have shape [1, Ny+2, Nx+2, 1]")
+    st = N.lib.piso_assemble_csr(N.ptr(vel_pad), N.ptr(csr_val), N.ptr(csr_col), N.ptr(csr_row), N.ptr(diag),
+                                 N.ptr(dmask.contiguous()), N.ptr(act), N.ptr(visc), is_field, nx, ny, int(per_x),
+                                 int(per_y), C.c_float(cell_area[0]), C.c_float(cell_area[1]),
+                                 C.c_float(grid_spacing[0]), C.c_float(grid_spacing[1]),
+                                 N.ptr(no_slip_wall_mask), C.c_float(np.float32(beta)), N.stream_ptr())
+    N.check(st, "piso_assemble_csr")
+    return csr_val, csr_row, csr_col, diag, np.array([nnz_u.value, nnz_v.value])
+
+
 def advection_matrix_cuda(velocity, dirichlet_mask_flat, viscosity, beta=0, no_slip_wall_mask=None, bool_periodic=None,
                           active_mask=None, accessible_mask=None, unrolling_step=0):
     """diffpiso/piso_tf.py:85-137 (the name is kept for drop-in use; the kernel is HIP).  No gradient flows through it
@@ -96,35 +128,11 @@ def advection_matrix_cuda(velocity, dirichlet_mask_flat, viscosity, beta=0, no_s
             bool_periodic = (False, False)
         per_y, per_x = bool(bool_periodic[0]), bool(bool_periodic[1])          # given (y, x); the op wants (x, y) (:89)
         vel_pad = padded_velocity_flat(velocity).to(torch.float32).contiguous()
-        dev = vel_pad.device
-        dx = velocity.dx
-        grid_spacing = np.array([dx[1], dx[0]], dtype=np.float32)               # :96
-        cell_area = (np.prod(dx) / np.array([dx[1], dx[0]], dtype=np.float32)).astype(np.float32)   # :97
-        nnz_u, nnz_v = C.c_int(0), C.c_int(0)
-        N.lib.piso_csr_nnz(nx, ny, int(per_x), int(per_y), C.byref(nnz_u), C.byref(nnz_v))
-        n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
-        nnz = nnz_u.value + nnz_v.value
-        csr_val = torch.empty(nnz, dtype=torch.float32, device=dev)
-        csr_col = torch.empty(nnz, dtype=torch.int32, device=dev)
-        csr_row = torch.empty(n_u + n_v + 2, dtype=torch.int32, device=dev)
-        diag = torch.empty(n_u + n_v, dtype=torch.float32, device=dev)
-        visc = as_tensor(viscosity, dtype=torch.float32, device=dev).reshape(-1).contiguous()
-        is_field = int(visc.numel() > 1)
-        if is_field and visc.numel() != n_u + n_v:
-            raise ValueError("viscosity field must have n_u + n_v entries (u first)")
-        dmask = dirichlet_mask_flat if dirichlet_mask_flat.dtype == torch.uint8 else dirichlet_mask_flat.ne(0).to(torch.uint8)
-        act = as_tensor(active_mask, dtype=torch.float32, device=dev).reshape(-1).contiguous()
-        if act.numel() != (nx + 2) * (ny + 2):
-            raise ValueError("active_mask must have shape [1, Ny+2, Nx+2, 1]")
-        st = N.lib.piso_assemble_csr(N.ptr(vel_pad), N.ptr(csr_val), N.ptr(csr_col), N.ptr(csr_row), N.ptr(diag),
-                                     N.ptr(dmask.contiguous()), N.ptr(act), N.ptr(visc), is_field, nx, ny, int(per_x),
-                                     int(per_y), C.c_float(cell_area[0]), C.c_float(cell_area[1]),
-                                     C.c_float(grid_spacing[0]), C.c_float(grid_spacing[1]),
-                                     N.ptr(no_slip_wall_mask), C.c_float(np.float32(beta)), N.stream_ptr())
-        N.check(st, "piso_assemble_csr")
+        csr_val, csr_row, csr_col, diag, nnz = assemble_from_padded(vel_pad, nx, ny, velocity.dx, per_x, per_y, dirichlet_mask_flat,
+                                                                    active_mask, viscosity, no_slip_wall_mask, beta)
         shape = (1, ny + 1, nx + 1, 2)
         A = stagger_flattened_data(diag, shape, coord_flip=True)
-    return csr_val, csr_row, csr_col, A, np.array([nnz_u.value, nnz_v.value]), diag
+    return csr_val, csr_row, csr_col, A, nnz, diag
 
 
 class _CsrMatVec(torch.autograd.Function):
@@ -161,8 +169,25 @@ def explicit_H_csr(matrix_values, row_pointers, column_indices, velocity, stagge
     return stagger_flattened_data(prod, staggered_shape, coord_flip=True) - (A - beta) * velocity.staggered_tensor()
 
 
+FUSED_GLUE = True     # piso_step runs its stencil glue on the fused HIP kernels of csrc/glue.hip (fused.py); False: torch ops
+
+
 def piso_step(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_physics, dirichlet_values,
               viscosity_field=None, forcing_term=None, unrolling_step=0, warn=None, full_output=False, **kwargs):
+    """diffpiso/piso_tf.py:11-81.  Two implementations of the same statements: `_piso_step_reference` below (torch ops, one per
+    TensorFlow / PhiFlow op of the reference: the readable transcription, pinned by the golden vectors of the reference's own
+    helpers) and `fused.piso_step_fused` (one HIP launch per statement; tests hold it to the transcription)."""
+    from . import stencils
+    if FUSED_GLUE and stencils.REFERENCE_ADJOINTS and velocity.data[0].data.is_cuda:
+        from .fused import piso_step_fused
+        return piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_physics, dirichlet_values,
+                               viscosity_field, forcing_term, unrolling_step, warn, full_output)
+    return _piso_step_reference(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_physics, dirichlet_values,
+                                viscosity_field, forcing_term, unrolling_step, warn, full_output)
+
+
+def _piso_step_reference(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_physics, dirichlet_values,
+                         viscosity_field=None, forcing_term=None, unrolling_step=0, warn=None, full_output=False):
     """diffpiso/piso_tf.py:11-81, statement by statement."""
     staggered_shape = tuple(velocity.staggered_tensor().shape)
     sim = simulation_physics

@@ -273,10 +273,15 @@ class PisoPressureSolverCudaCustom(PoissonSolver):
     def solve(self, scaling_field, divergence, guess, enable_backprop, simulation_physics, offset=0, unrolling_step=0):
         # `guess` is ignored exactly like in the reference (init_with_zeros=True, piso_cuda_pressure_solver.py:95)
         scaling_field = scaling_field if isinstance(scaling_field, StaggeredGrid) else StaggeredGrid(scaling_field)
+        a0 = flatten_staggered_data(scaling_field, coord_flip=False).detach().to(torch.float32)   # v first (:70)
+        return self.solve_flat(a0, divergence, simulation_physics, unrolling_step=unrolling_step)
+
+    def solve_flat(self, a0_vfirst, divergence, simulation_physics, unrolling_step=0):
+        """`solve` with the face coefficients already in the op's layout (flat, v faces first, :70); used by the fused step."""
         dt = torch.float64 if self.cast_to_double else torch.float32
         ny, nx = int(divergence.shape[1]), int(divergence.shape[2])
         dev = divergence.device
-        a0 = flatten_staggered_data(scaling_field, coord_flip=False).detach().to(torch.float32)   # v first (:70)
+        a0 = a0_vfirst
         active = simulation_physics.active_mask_tensor(dev)
         accessible = simulation_physics.accessible_mask_tensor(dev)
         if self.laplace_rank_deficient is None:                                     # :84-87
