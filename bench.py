@@ -46,11 +46,11 @@ BICG_BYTES_PER_ROW_ONCE = 148.0  # ILU0 factor 88 + initial residual 60
 # the S and W float off-diagonals once per stencil pass (2 passes x 8 B), the perimeters of the published vectors written and
 # read back by the neighbours (2 vectors x 2 x (2/16 + 2/128) x 8 B), the extra coefficient row / column per region (~0.6 B).
 PERSIST_STENCIL_PASSES = 2
-PERSIST_PUBLISHED_VECTORS = {1: 3, 2: 2}   # exchanges per iteration -> vectors whose perimeters are published (r, p [, z])
+PERSIST_PUBLISHED_VECTORS = {1: 1, 2: 2}   # exchanges per iteration -> vectors whose perimeters are published (2: r and p; 1: z')
 # floors of one persistent iteration (scripts/barrier_bench.hip, scripts/fp64_rate.hip measured on MI355X)
 EXCHANGE_US = 4.4            # one tagged-record grid exchange over 256 workgroups
 FP64_ISSUE_CYCLES = 4.75     # cycles per fp64 VALU instruction per SIMD with two waves resident
-FP64_INSTR_PER_CELL = 38     # two stencil passes (2 x 13) + vector updates / sums (12)
+FP64_INSTR_PER_CELL = {1: 40, 2: 38}   # two stencil passes (2 x 13: 4 cvt, 4 diagonal, 5 fma) + vector updates / sums (14 | 12)
 CLOCK_GHZ = 2.4
 
 
@@ -369,7 +369,7 @@ def main():
             alg = CG_BYTES_PER_CELL_ITER * ncell * its / (seg_ms * 1e-3) / 1e9
             pmc, pmc_src = measured_traffic(n, "cg_persist")
             floors = {"fabric_bytes_at_hbm_peak": fabric_b * ncell / (HBM_PEAK_GBS * 1e9) * 1e6,
-                      "fp64_valu_issue": FP64_INSTR_PER_CELL * ncell / 256 / 64 / 4 * FP64_ISSUE_CYCLES / (CLOCK_GHZ * 1e3),
+                      "fp64_valu_issue": FP64_INSTR_PER_CELL[exchanges] * ncell / 256 / 64 / 4 * FP64_ISSUE_CYCLES / (CLOCK_GHZ * 1e3),
                       "grid_exchanges": exchanges * EXCHANGE_US}
             serial_floor = floors["fp64_valu_issue"] + floors["grid_exchanges"]   # the exchange cannot overlap the arithmetic it feeds
             roofline = {"bound": "hbm",

@@ -80,6 +80,8 @@ int piso_assemble_csr(const float* vel_pad, float* csr_val, int* csr_col, int* c
  *   band_rows  rows of faces per preconditioner block: < 0  = one block (global structured ILU0),
  *              0 = automatic, > 0 = that many.  See DESIGN.md "structured block ILU0".
  *   warning    device byte, set to 1 on NaN input (never cleared);  iterations_out: host int[2] or NULL
+ * Scope limits: 4 <= nx <= 8191, ny >= 4; the CSR must be the 5-point staggered-grid pattern piso_assemble_csr produces
+ * (any other matrix: PISO_ERR_UNSUPPORTED_PATTERN) -- this is not a general CSR solver.
  * ------------------------------------------------------------------------------------------------------------- */
 size_t piso_bicgstab_workspace_bytes(int nx, int ny, int elem_size);
 

@@ -1,4 +1,4 @@
-"""SURVEY.md 8(f) rows 2-4 on the CPU: LES strain / Smagorinsky viscosity and the numpy energy spectrum against fixtures
+"""SURVEY.md 8(f) rows 2-4, on the CPU and (marked gpu) on device tensors: LES strain / Smagorinsky viscosity and the numpy energy spectrum against fixtures
 generated from the reference's own Python (tests/golden/eval_les.npz, make_golden_eval.py); the differentiable spectrum and
 the four training losses against the loop-style numpy restatement in oracle/eval_ref.py (TensorFlow arithmetic: parity
 unpinned, see its header) and against the pinned numpy spectrum where the two must coincide; frame-file round trip."""
@@ -16,82 +16,88 @@ CASES = ["periodic", "xper_ywall", "spatial_ml", "closed"]
 TOL = dict(rtol=3e-6, atol=3e-6)
 
 
+@pytest.fixture(params=["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def device(request):
+    """Every tensor test runs on host tensors here and, on the GPU box (-m gpu), on device tensors."""
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def gold(golden_dir):
     return np.load(os.path.join(golden_dir, "eval_les.npz"))
 
 
-def _grid(gold, name):
+def _grid(gold, name, device="cpu"):
     ny, nx = gold[name + "/resolution"]
     ly, lx = gold[name + "/box"]
     ext = ast.literal_eval(str(gold[name + "/velocity_extrapolation"]))
-    return dp.StaggeredGrid(torch.tensor(gold[name + "/vel_in"]), dp.box[0:ly, 0:lx], extrapolation=ext)
+    return dp.StaggeredGrid(torch.tensor(gold[name + "/vel_in"], device=device), dp.box[0:ly, 0:lx], extrapolation=ext)
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_les_strain_and_smagorinsky_against_reference_golden(gold, name):
-    vel = _grid(gold, name)
+def test_les_strain_and_smagorinsky_against_reference_golden(gold, name, device):
+    vel = _grid(gold, name, device)
     for i, s in enumerate(dp.strain_tensor(vel)):
-        np.testing.assert_allclose(s.numpy(), gold[name + "/strain_%d" % i], **TOL)
+        np.testing.assert_allclose(s.detach().cpu().numpy(), gold[name + "/strain_%d" % i], **TOL)
     for i, s in enumerate(dp.strain_tensor_centered(vel)):
-        np.testing.assert_allclose(s.numpy(), gold[name + "/strain_centered_%d" % i], **TOL)
-    np.testing.assert_allclose(dp.smagorinsky_eddy_viscosity(vel, 0.17).numpy(), gold[name + "/smagorinsky_0p17"], **TOL)
-    np.testing.assert_allclose(dp.vorticity(vel).numpy(), gold[name + "/vorticity"], **TOL)
+        np.testing.assert_allclose(s.detach().cpu().numpy(), gold[name + "/strain_centered_%d" % i], **TOL)
+    np.testing.assert_allclose(dp.smagorinsky_eddy_viscosity(vel, 0.17).detach().cpu().numpy(), gold[name + "/smagorinsky_0p17"], **TOL)
+    np.testing.assert_allclose(dp.vorticity(vel).detach().cpu().numpy(), gold[name + "/vorticity"], **TOL)
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_loss_building_blocks_against_reference_golden(gold, name):
+def test_loss_building_blocks_against_reference_golden(gold, name, device):
     """What losses.py does through PhiFlow: StaggeredGrid(tensor) with default box / extrapolation, at_centers, forward
     gradients of the component arrays -- and the oracle's own restatement of the same pieces."""
     from diffpiso.les import forward_gradient
-    t = torch.tensor(gold[name + "/vel_in"])
+    t = torch.tensor(gold[name + "/vel_in"], device=device)
     sg = dp.StaggeredGrid(t)
-    np.testing.assert_allclose(sg.staggered_tensor().numpy(), gold[name + "/default_grid_staggered_tensor"], **TOL)
-    np.testing.assert_allclose(sg.at_centers().data.numpy(), gold[name + "/default_grid_at_centers"], **TOL)
+    np.testing.assert_allclose(sg.staggered_tensor().detach().cpu().numpy(), gold[name + "/default_grid_staggered_tensor"], **TOL)
+    np.testing.assert_allclose(sg.at_centers().data.detach().cpu().numpy(), gold[name + "/default_grid_at_centers"], **TOL)
     np.testing.assert_allclose(E.staggered_tensor(gold[name + "/vel_in"]), gold[name + "/default_grid_staggered_tensor"], **TOL)
     np.testing.assert_allclose(E.at_centers(gold[name + "/vel_in"]), gold[name + "/default_grid_at_centers"], **TOL)
-    vel = _grid(gold, name)
+    vel = _grid(gold, name, device)
     for i in range(2):
         ref = gold[name + "/fwd_gradient_comp%d" % i]
-        np.testing.assert_allclose(forward_gradient(vel.data[i].data, vel.dx).numpy(), ref, **TOL)
+        np.testing.assert_allclose(forward_gradient(vel.data[i].data, vel.dx).detach().cpu().numpy(), ref, **TOL)
         np.testing.assert_allclose(E._fwd(E.split_staggered(gold[name + "/vel_in"])[i].astype(np.float64), vel.dx), ref, **TOL)
 
 
 @pytest.mark.parametrize("tag", ["sq", "rect"])
-def test_energy_spectra(gold, tag):
+def test_energy_spectra(gold, tag, device):
     vc = gold["spectrum_%s/velocity_centered" % tag]
     k, e = dp.EK_spectrum_2D(vc, None)
     np.testing.assert_allclose(k, gold["spectrum_%s/wavenumbers" % tag])
     np.testing.assert_allclose(e, gold["spectrum_%s/energy" % tag], rtol=1e-10, atol=1e-18)
     # the differentiable (TF) version: equals the pinned numpy spectrum on even-sized domains (up to its cutoff), and the
     # loop restatement everywhere
-    et = dp.EK_spectrum_2D_tf(torch.tensor(vc)).numpy()
+    et = dp.EK_spectrum_2D_tf(torch.tensor(vc, device=device)).detach().cpu().numpy()
     n = min(len(et), len(e))
     np.testing.assert_allclose(et[:n], e[:n], rtol=1e-6, atol=1e-12)
     np.testing.assert_allclose(et, E.spectrum_2d_tf(vc), rtol=1e-9, atol=1e-15)
     odd = np.random.default_rng(0).standard_normal((9, 13, 2))
-    np.testing.assert_allclose(dp.EK_spectrum_2D_tf(torch.tensor(odd)).numpy(), E.spectrum_2d_tf(odd), rtol=1e-9, atol=1e-15)
-    e1 = dp.EK_spectrum_1D_tf(torch.tensor(vc), 1).numpy()
+    np.testing.assert_allclose(dp.EK_spectrum_2D_tf(torch.tensor(odd, device=device)).detach().cpu().numpy(), E.spectrum_2d_tf(odd), rtol=1e-9, atol=1e-15)
+    e1 = dp.EK_spectrum_1D_tf(torch.tensor(vc, device=device), 1).detach().cpu().numpy()
     ref1 = (np.abs(np.fft.fft(vc[..., 1], axis=1)) ** 2 + np.abs(np.fft.fft(vc[..., 0], axis=1)) ** 2).sum(0)[:vc.shape[1] // 2 + 1]
     np.testing.assert_allclose(e1, ref1, rtol=1e-9)
 
 
-def _sequences(ny=12, nx=16, steps=5, seed=3):
+def _sequences(ny=12, nx=16, steps=5, seed=3, device="cpu"):
     rng = np.random.default_rng(seed)
     gt = rng.standard_normal((1, steps, ny + 1, nx + 1, 2)).astype(np.float32)
     pred = [(gt[:, s] + 0.3 * rng.standard_normal((1, ny + 1, nx + 1, 2))).astype(np.float32) for s in range(steps)]
     box = dp.box[0:ny * 0.5, 0:nx * 0.25]
-    leaves = [torch.tensor(p, dtype=torch.float64).requires_grad_(True) for p in pred]
+    leaves = [torch.tensor(p, dtype=torch.float64, device=device).requires_grad_(True) for p in pred]
     grids = [dp.StaggeredGrid(t, box, extrapolation="periodic") for t in leaves]
     return gt, pred, grids, leaves
 
 
-def test_losses_against_numpy_restatement():
-    gt, pred, grids, leaves = _sequences()
-    gtt = torch.tensor(gt, dtype=torch.float64)
+def test_losses_against_numpy_restatement(device):
+    gt, pred, grids, leaves = _sequences(device=device)
+    gtt = torch.tensor(gt, dtype=torch.float64, device=device)
     steps, bw = len(pred), [[1, 2], [2, 1]]
     lf = [0.5 + 0.1 * s for s in range(steps)]
-    zero = torch.zeros((), dtype=torch.float64)
+    zero = torch.zeros((), dtype=torch.float64, device=device)
     tot, c = dp.L2_field_loss(zero, [grids], [gtt], steps, bw, lf, 0)
     assert float(c) == pytest.approx(E.l2_field_loss([pred], [gt], [0, steps], bw, lf, 0), rel=3e-6)
     tot, c = dp.L2_field_loss(zero + 2.0, [grids], [gtt], [1, 4], None, 0.7, 0)
@@ -166,25 +172,25 @@ def test_spatial_mixing_layer_setup_objects():
     np.testing.assert_allclose(dv[0, :ny, 0, 1], bcx[0, 1:-1, 0, 0])
     assert dm[0, 0, :nx, 0].all() and dm[0, ny, :nx, 0].all() and float(np.abs(dv[..., 0]).max()) == 0.0
     assert sp.bool_periodic == (False, False) and ps.dx == pytest.approx(0.5)
-    flat = visc.numpy()
+    flat = visc.detach().cpu().numpy()
     assert flat.min() == pytest.approx(2e-3) and flat.max() == pytest.approx(2e-3 + 2e-3 * 20.0, rel=1e-6)
 
 
 @pytest.mark.parametrize("tag", ["r2", "r4", "r1p5"])
-def test_resampling_of_data_frames_against_reference_golden(golden_dir, tag):
+def test_resampling_of_data_frames_against_reference_golden(golden_dir, tag, device):
     """StaggeredGrid(hr).at(lr_velocity) / CenteredGrid(hr_p).at(lr_pressure) (combined_training_integrated.py:169-174)."""
     g = np.load(os.path.join(golden_dir, "resample.npz"))
     lr, size = g[tag + "/lr_res"], g[tag + "/box"]
     box = dp.box[0:size[0], 0:size[1]]
     dom = dp.Domain([int(lr[0]), int(lr[1])], box=box, boundaries=((dp.OPEN, dp.OPEN), (dp.OPEN, dp.CLOSED)))
-    lr_vel = dp.StaggeredGrid.sample(torch.zeros((1, lr[0] + 1, lr[1] + 1, 2)), domain=dom)
-    lr_p = dp.CenteredGrid(torch.zeros((1, lr[0], lr[1], 1)), box=box)
-    v = dp.StaggeredGrid(torch.tensor(g[tag + "/hr_velocity"]), box).at(lr_vel)
-    np.testing.assert_allclose(v.staggered_tensor().numpy(), g[tag + "/lr_velocity"], **TOL)
-    p = dp.CenteredGrid(torch.tensor(g[tag + "/hr_pressure"]), box).at(lr_p)
-    np.testing.assert_allclose(p.data.numpy(), g[tag + "/lr_pressure"], **TOL)
+    lr_vel = dp.StaggeredGrid.sample(torch.zeros((1, lr[0] + 1, lr[1] + 1, 2), device=device), domain=dom)
+    lr_p = dp.CenteredGrid(torch.zeros((1, lr[0], lr[1], 1), device=device), box=box)
+    v = dp.StaggeredGrid(torch.tensor(g[tag + "/hr_velocity"], device=device), box).at(lr_vel)
+    np.testing.assert_allclose(v.staggered_tensor().detach().cpu().numpy(), g[tag + "/lr_velocity"], **TOL)
+    p = dp.CenteredGrid(torch.tensor(g[tag + "/hr_pressure"], device=device), box).at(lr_p)
+    np.testing.assert_allclose(p.data.detach().cpu().numpy(), g[tag + "/lr_pressure"], **TOL)
     # the set-up's own use: cell-centred viscosity to the faces equals sponge_viscosity_field
     visc = np.ones((1, int(lr[0]), int(lr[1]), 1), np.float32) * 2e-3
     visc[:, :, 3:, :] += np.linspace(0, 0.1, int(lr[1]) - 3, dtype=np.float32)[None, None, :, None]
-    flat = dp.flatten_staggered_data(dp.CenteredGrid(torch.tensor(visc), box).at(lr_vel), coord_flip=True)
-    np.testing.assert_allclose(flat.numpy(), dp.sponge_viscosity_field(lr, 2e-3, 3, 0.1), rtol=1e-6, atol=1e-9)
+    flat = dp.flatten_staggered_data(dp.CenteredGrid(torch.tensor(visc, device=device), box).at(lr_vel), coord_flip=True)
+    np.testing.assert_allclose(flat.detach().cpu().numpy(), dp.sponge_viscosity_field(lr, 2e-3, 3, 0.1), rtol=1e-6, atol=1e-9)
