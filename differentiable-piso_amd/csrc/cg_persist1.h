@@ -28,6 +28,14 @@
 
 namespace piso {
 
+// coefficient rows in flight per wave (A/B builds: -DPISO_PERSIST1_DEPTH=n + scripts/sweep_libs.sh).  Measured at 2048^2 / 1024^2:
+// 16-row regions 4 rows 17.8 us (15 spilled VGPRs), 3 rows 17.2 us (6), 2 rows 21.1 us; small regions 4 rows 7.05, 3 rows 8.2 us
+#ifndef PISO_PERSIST1_DEPTH
+#define PISO_PERSIST1_DEPTH ((NQ == 1) ? 3 : kPersistMaxDepth)
+#endif
+#ifndef PISO_PERSIST1_POLL_SLEEP
+#define PISO_PERSIST1_POLL_SLEEP 1              // s_sleep units (64 cycles) between two polling passes
+#endif
 constexpr int kX1Values = 8;                     // sums per exchange
 constexpr int kX1RecWords = 16;                  // 8-byte words per record: 2 per sum {32 payload bits | 32-bit epoch}
 
@@ -87,7 +95,7 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
       }
       if (__all(ok)) break;
       if (++spins > (1u << 22)) { good = false; break; }
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_SLEEP);
     }
     // even lanes assemble their sum from their own word (low half) and the neighbour lane's (high half); records of a lane
     // are added in order, then the four records-per-instruction rows, then (after the barrier) the eight waves
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   constexpr int coef_regs = ((SYM ? 2 : 4) * (int)sizeof(CT) * V + (RECON ? 0 : (int)sizeof(T) * V)) / 4;   // VGPRs of a row in flight
   constexpr int NT = NQ * R;
   constexpr int budget = (NQ == 1 || NT < 16) ? 16 : 8;
-  constexpr int Dw = budget / coef_regs < 2 ? 2 : (budget / coef_regs > kPersistMaxDepth ? kPersistMaxDepth : budget / coef_regs);
+  constexpr int Dw = budget / coef_regs < 2 ? 2 : (budget / coef_regs > PISO_PERSIST1_DEPTH ? PISO_PERSIST1_DEPTH : budget / coef_regs);
   constexpr int D = (NT >= Dw) ? Dw : NT;
   constexpr int kBaseLoads = (SYM ? 2 : 4) + (RECON ? 0 : 1);          // vector loads every row issues (some rows one or two more)
   Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT], cSh[NQ];
