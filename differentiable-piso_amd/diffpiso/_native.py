@@ -76,6 +76,15 @@ lib.piso_h_contribution.restype = _i
 lib.piso_h_contribution_adjoint.argtypes = [_vp, _vp, _vp, _f, _vp, _vp, _i, _i, _vp]
 lib.piso_h_contribution_adjoint.restype = _i
 
+lib.piso_conv2d_weight_elems.argtypes = [_i, _i, _i]
+lib.piso_conv2d_weight_elems.restype = _sz
+lib.piso_conv2d_wgrad_workspace_bytes.argtypes = [_i, _i, _i]
+lib.piso_conv2d_wgrad_workspace_bytes.restype = _sz
+lib.piso_conv2d_forward.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]
+lib.piso_conv2d_forward.restype = _i
+lib.piso_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
+lib.piso_conv2d_wgrad.restype = _i
+
 lib.piso_comm_unique_id.argtypes = [_vp]
 lib.piso_comm_unique_id.restype = _i
 lib.piso_comm_create.argtypes = [_vp, _i, _i, C.POINTER(_vp)]

@@ -3,7 +3,9 @@
 Mirror of diffpiso/networks.py (fullyconv_network / initialise_fullyconv_network) and of the coupling code in
 diffpiso/combined_training_integrated.py:399-411, 443-454: network input = cell-centred velocity (+ central pressure gradient),
 network output (2 channels at cell centres) resampled to the faces as the forcing term of piso_step.
-The convolutions run through torch (MIOpen / MFMA); a hand-written MFMA kernel is a later round's item.
+On the GPU the convolutions run on hand-written MFMA kernels (csrc/conv.hip: exact fp32 v_mfma_f32_16x16x4_f32, NHWC, fused
+leaky ReLU, forward / input gradient / weight gradient) behind `conv2d_leaky`; host tensors (the oracle chain of the
+tests) go through torch's conv2d.
 The field-algebra pieces (at_centers, gradient, centre -> face resampling) are pinned by tests/golden (PhiFlow numpy backend).
 """
 import numpy as np
@@ -12,6 +14,100 @@ import torch.nn.functional as F
 
 from .grids import CenteredGrid, StaggeredGrid, axis_extrapolation, stack_staggered_components
 from .stencils import pad_axis, pad_axis_sides
+
+USE_MFMA_CONV = True      # device tensors: csrc/conv.hip; False: torch.nn.functional.conv2d (MIOpen)
+
+
+def _laid_out(w_hwio):
+    """HWIO weights -> the operand layout of piso_conv2d_forward (include/piso_hip.h), zero padded."""
+    k, _, cin, cout = w_hwio.shape
+    cop = -(-cout // 16) * 16
+    if cin <= 4:
+        out = torch.zeros((k, k, 4, cop), dtype=torch.float32, device=w_hwio.device)
+        out[:, :, :cin, :cout] = w_hwio
+        return out
+    assert cin % 16 == 0
+    out = torch.zeros((k, k, cin, cop), dtype=torch.float32, device=w_hwio.device)
+    out[..., :cout] = w_hwio
+    # [tap][blk][q][j][co] -> [tap][blk][q][co][j]
+    return out.view(k, k, cin // 16, 4, 4, cop).permute(0, 1, 2, 3, 5, 4).contiguous()
+
+
+_layout_cache = {}
+
+
+def _cached_layouts(w_oihw):
+    """(forward layout, input-gradient layout) of a weight tensor, recomputed only when the parameter changes (an unrolled
+    training iteration evaluates the network 2 x step_count times with the same weights)."""
+    key = (w_oihw.data_ptr(), w_oihw._version, tuple(w_oihw.shape))
+    hit = _layout_cache.get(id(w_oihw))
+    if hit is None or hit[0] != key:
+        wd = w_oihw.detach()
+        hit = (key, _laid_out(wd.permute(2, 3, 1, 0)), _laid_out(wd.flip(2, 3).permute(2, 3, 0, 1)))
+        if len(_layout_cache) > 64:
+            _layout_cache.clear()
+        _layout_cache[id(w_oihw)] = hit
+    return hit[1], hit[2]
+
+
+class _Conv2dLeaky(torch.autograd.Function):
+    """One layer of the closure on the matrix cores: out = [leaky_relu_0.2](conv2d(x, w)), NHWC, batch 1, stride 1, no bias
+    (tf.nn.conv2d + tf.nn.leaky_relu of networks.py:21-44).  Reverse mode: g' = g * leaky'(out) (leaky ReLU has a positive slope:
+    the sign of the saved output is the sign of the pre-activation); input gradient = the same kernel with flipped, transposed
+    weights on g'; weight gradient = piso_conv2d_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w_oihw, pad, leaky):
+        from . import _native as N
+        x = x.contiguous()
+        cout, cin, k, _ = w_oihw.shape
+        _, H, W, _ = x.shape
+        wl, _ = _cached_layouts(w_oihw)
+        Ho, Wo = H + 2 * pad - k + 1, W + 2 * pad - k + 1
+        out = torch.empty((1, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+        N.check(N.lib.piso_conv2d_forward(N.ptr(x), N.ptr(wl), N.ptr(out), H, W, cin, cout, k, pad, int(leaky), N.stream_ptr()),
+                "piso_conv2d_forward")
+        ctx.save_for_backward(x, w_oihw, out if leaky else None)
+        ctx.meta = (pad, leaky, Ho, Wo)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes as C
+        from . import _native as N
+        x, w_oihw, out = ctx.saved_tensors
+        pad, leaky, Ho, Wo = ctx.meta
+        cout, cin, k, _ = w_oihw.shape
+        _, H, W, _ = x.shape
+        g = (torch.where(out > 0, g, 0.2 * g) if leaky else g).contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            # dx = conv(g', Wd), Wd[ky][kx][co][ci] = W[k-1-ky][k-1-kx][ci][co], zero padding k - 1 - pad
+            gp, cop = g, cout
+            if cout > 4 and cout % 16 != 0:
+                raise N.PisoNativeError("conv2d input gradient: output channels must be <= 4 or a multiple of 16")
+            _, wd = _cached_layouts(w_oihw)
+            dx = torch.empty_like(x)
+            N.check(N.lib.piso_conv2d_forward(N.ptr(gp), N.ptr(wd), N.ptr(dx), Ho, Wo, cop, cin, k, k - 1 - pad, 0, N.stream_ptr()),
+                    "piso_conv2d_forward (input gradient)")
+        if ctx.needs_input_grad[1]:
+            ws = N.workspace(N.lib.piso_conv2d_wgrad_workspace_bytes(k, cin, cout), x.device, "conv_wgrad")
+            dw_hwio = torch.empty((k, k, cin, cout), dtype=torch.float32, device=x.device)
+            N.check(N.lib.piso_conv2d_wgrad(N.ptr(x), N.ptr(g), N.ptr(dw_hwio), H, W, cin, cout, k, pad, N.ptr(ws),
+                                            C.c_size_t(ws.numel()), N.stream_ptr()), "piso_conv2d_wgrad")
+            dw = dw_hwio.permute(3, 2, 0, 1).contiguous()
+        return dx, dw, None, None
+
+
+def conv2d_leaky(x_nhwc, w_oihw, pad, leaky):
+    """NHWC convolution (+ leaky ReLU 0.2) of the closure: MFMA kernels for float32 device tensors of batch 1, torch otherwise."""
+    if USE_MFMA_CONV and x_nhwc.is_cuda and x_nhwc.dtype == torch.float32 and x_nhwc.shape[0] == 1 and w_oihw.dtype == torch.float32:
+        return _Conv2dLeaky.apply(x_nhwc, w_oihw, int(pad), bool(leaky))
+    y = F.conv2d(x_nhwc.permute(0, 3, 1, 2), w_oihw, padding=int(pad))
+    if leaky:
+        y = F.leaky_relu(y, 0.2)
+    return y.permute(0, 2, 3, 1)
+
 
 _KERNELS = [(7, 4, 16), (5, 16, 16), (5, 16, 32), (3, 32, 64), (3, 64, 64), (1, 64, 64), (1, 64, 2)]   # networks.py:62-69
 
@@ -42,13 +138,11 @@ class FullyConvNetwork(torch.nn.Module):
             sh = fields.shape
             fields = fields[:, bw[0][0]:sh[1] - bw[0][1], bw[1][0]:sh[2] - bw[1][1], :]
         target = fields.shape
-        x = fields.permute(0, 3, 1, 2)
+        x = fields
         same = self.padding == "SAME"
         for i, w in enumerate(self.weights):
-            x = F.conv2d(x, w, padding=(w.shape[-1] // 2 if same else 0))
-            if i < len(self.weights) - 1:
-                x = F.leaky_relu(x, 0.2)
-        out = x.permute(0, 2, 3, 1)
+            x = conv2d_leaky(x, w, w.shape[-1] // 2 if same else 0, leaky=i < len(self.weights) - 1)
+        out = x
         if not same and bw is not None and self.restore_shape:
             pn = self.reduced_buffer_width
             out = F.pad(out, (0, 0, pn, target[2] - out.shape[2] - pn, pn, target[1] - out.shape[1] - pn))

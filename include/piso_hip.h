@@ -182,6 +182,27 @@ int piso_cg_persist_fallbacks(void);
 int piso_cg_default_exchanges(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Convolutions of the CNN turbulence closure on the matrix cores (csrc/conv.hip; exact fp32 MFMA).  Replaces the
+ * tf.nn.conv2d / tf.nn.leaky_relu calls of diffpiso/networks.py:3-57 (NHWC activations, batch 1, stride 1, no bias, kernel
+ * sizes and channel counts of the closure: 7x7 4->16, 5x5 16->16, 5x5 16->32, 3x3 32->64, 3x3 64->64, 1x1 64->64, 1x1 64->2 and
+ * the transposed shapes of the input-gradient pass).
+ *   in [H][W][cin], out [Ho][Wo][cout] with Ho = H + 2 pad - ks + 1; leaky_out != 0: leaky ReLU (slope 0.2) on the output.
+ *   w_laid_out: the HWIO weights in the kernel's operand layout, zero filled beyond the true channel counts
+ *   (piso_conv2d_weight_elems floats, COUTP = round_up(cout, 16)):
+ *     cin <= 4: [ks][ks][4][COUTP];   cin > 4 (a multiple of 16): [ks][ks][cin/16][4][COUTP][4] with
+ *     element [tap][blk][q][co][j] = W[tap][16 blk + 4 q + j][co]   (every MFMA operand is then one 16-byte load).
+ * Input gradient = piso_conv2d_forward(grad of the pre-activation output, flipped + transposed weights, pad = ks - 1 - pad).
+ * piso_conv2d_wgrad: dw [ks][ks][cin][cout] (HWIO, true sizes) = sum over pixels of in (x) grad_out (pre-activation);
+ * deterministic two-stage reduction through the caller's workspace.
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t piso_conv2d_weight_elems(int ks, int cin, int cout);
+size_t piso_conv2d_wgrad_workspace_bytes(int ks, int cin, int cout);
+int piso_conv2d_forward(const float* in, const float* w_laid_out, float* out, int H, int W, int cin, int cout, int ks, int pad,
+                        int leaky_out, piso_stream_t stream);
+int piso_conv2d_wgrad(const float* in, const float* grad_out, float* dw, int H, int W, int cin, int cout, int ks, int pad,
+                      void* workspace, size_t workspace_bytes, piso_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Slab-decomposed pressure CG (no counterpart in the reference, which is single-GPU).
  * The grid is cut along y into `world` slabs of ny_local rows, one rank per GPU.  Per iteration: K1, a 3-double all-reduce,
  * K2, a 3-double all-reduce and a one-row halo exchange of the residual -- all stream-ordered RCCL calls, no host sync.
