@@ -54,12 +54,17 @@ def test_forward_step_matches_oracle(name, shape):
         assert abs(P["ps"].last_iterations - tape["it2"]) <= 5
 
 
+@pytest.mark.parametrize("lin_double", [True, False])
 @pytest.mark.parametrize("name", ["periodic", "xper_ywall", "cavity", "spatial_ml"])
-def test_backward_step_matches_oracle(name):
+def test_backward_step_matches_oracle(name, lin_double):
+    """lin_double=False is the reference's (and the benchmark's) setting: advection solve and its transposed adjoint solve in
+    float32 (cast_to_double=False, linear_solver.py:116); the float64 variant isolates the glue from float32 solver round-off."""
     c = make_case(name, 16, 12, seed=4)
-    kw = dict(SOLVER, lin_double=True, lin_tol=1e-10)
+    kw = dict(SOLVER, lin_double=True, lin_tol=1e-10) if lin_double else dict(SOLVER, lin_double=False, lin_tol=1e-8)
     if name == "cavity":
         kw["p_tol"] = 1e-6      # stay above the float32 inconsistency floor of the shifted system (tests/test_oracle_step.py)
+        if not lin_double:
+            pytest.skip("float32 transposed solve of the cavity is borderline at this tolerance: zero-on-failure on either side")
     s = oracle_setup(c, **kw)
     P = product_setup(c, **kw)
     rng = np.random.default_rng(2)
@@ -88,11 +93,12 @@ def test_backward_step_matches_oracle(name):
     assert max(e) < tol, e
 
 
+@pytest.mark.parametrize("lin_double", [True, False])
 @pytest.mark.parametrize("name,steps,cut", [("periodic", 4, None), ("xper_ywall", 4, 2), ("spatial_ml", 3, None)])
-def test_unrolled_adjoint_matches_oracle(name, steps, cut):
+def test_unrolled_adjoint_matches_oracle(name, steps, cut, lin_double):
     import diffpiso as dp
     c = make_case(name, 16, 16, seed=6)
-    kw = dict(SOLVER, lin_double=True, lin_tol=1e-10)
+    kw = dict(SOLVER, lin_double=True, lin_tol=1e-10) if lin_double else dict(SOLVER, lin_double=False, lin_tol=1e-8)
     s = oracle_setup(c, **kw)
     P = product_setup(c, **kw)
     vels, ps, tapes = R.run_steps(s, c["vel"], c["p"], c["dt"], c["dirichlet_values"], steps)

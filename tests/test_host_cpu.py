@@ -236,3 +236,23 @@ def test_frame_file_format(tmp_path):
     assert [float(vel[0, t, 0, 0, 0]) for t in range(3)] == [2.0, 4.0, 6.0] and ch.shape == (1, 2)
     lists = dp.data_path_assembler([d], ["velocity"], [7.5], [0], [6], [2])
     assert len(lists[0]) == 4 and lists[1] == [7.5] * 4
+
+
+def test_build_from_a_tree_without_binaries(tmp_path):
+    """__graft_entry__.build() must produce libpiso_hip.so (hipcc, gfx950) and the oracle libraries from sources alone: run it in
+    a copy of the tree that holds no .so / .o file (the tree gpurun ships contains prebuilt ones, which proves nothing)."""
+    import shutil
+    import subprocess
+    import sys
+    dst = tmp_path / "tree"
+    ignore = shutil.ignore_patterns("*.so", "*.o", "_obj", "_build", "_bin", "gpurun_out", ".git", "__pycache__", "profiles", "golden")
+    shutil.copytree(ROOT, dst, ignore=ignore)
+    assert not list(dst.rglob("*.so"))
+    code = "import __graft_entry__ as g; g.build(); import diffpiso._native as N; print(N.LIB_PATH)"
+    out = subprocess.run([sys.executable, "-c", code], cwd=dst, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    built = out.stdout.strip().splitlines()[-1]
+    assert built.startswith(str(dst)) and os.path.isfile(built)
+    assert os.path.isfile(dst / "oracle" / "_build" / "libpiso_oracle.so") and os.path.isfile(dst / "oracle" / "_build" / "libpiso_oracle_omp.so")
+    lib = ctypes.CDLL(built)
+    assert b"gfx950" in ctypes.cast(lib.piso_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()
