@@ -170,8 +170,7 @@ def make_cfg4():
 BENCH_SOLVER = dict(lin_tol=1e-6, lin_max_it=10000, lin_double=False, p_tol=1e-6, p_max_it=10000, p_reset=1000)
 # the same workload solved TIGHTLY (parity needs converged solves: two correct solvers agree to ~ tolerance x condition number,
 # SURVEY.md 7 "hard parts"): pressure 1e-8, advection 1e-8.  The restart every 1000 iterations stays: WITHOUT it the shifted
-# (indefinite) operator never converges at 2048^2 (60000 iterations tried), at 1024^2 the converged adjoint solves take minutes
-# on the CPU, at 2048^2 hours - so the converged fixture is the benchmark workload at 1024^2.
+# (indefinite) operator never converges at 2048^2 (60000 iterations tried).  Converged fixtures: 1024^2 (95 s here) and 2048^2.
 TIGHT_SOLVER = dict(lin_tol=1e-8, lin_max_it=300, lin_double=False, p_tol=1e-8, p_max_it=200000, p_reset=1000)
 
 
@@ -212,6 +211,8 @@ if __name__ == "__main__":
         make_bench2048()
     if "bench1024_tight" in which:
         make_bench2048(1024, TIGHT_SOLVER, "bench%d_tight_step")
+    if "bench2048_tight" in which:       # (~20 min on 8 cores)
+        make_bench2048(2048, TIGHT_SOLVER, "bench%d_tight_step")
     if "bench512_tight" in which:
         make_bench2048(512, TIGHT_SOLVER, "bench%d_tight_step")
     if "bench512" in which:       # quick look at the workload at a small size (not committed)
