@@ -1,4 +1,5 @@
 // Host driver of the single-GPU pressure CG (kernels: cg_kernels.h).  See cg_kernels.h for the design.
+#include <atomic>
 #include "cg_kernels.h"
 #include "cg_persist.h"
 #include "cg_persist1.h"
@@ -25,6 +26,7 @@ struct HostPoll {
   hipEvent_t seg_ev[2] = {nullptr, nullptr};   // timing events around persistent segments (profiling only; created once)
 };
 constexpr int kPersistDefaultExchanges = 1;   // grid-wide exchanges per persistent iteration when cg_exchanges is not set
+static std::atomic<unsigned> g_persist_launches{0};   // persistent launches so far: the high half of their exchange tags
 static int g_persist_fallbacks = 0;            // solves that were restarted on the two-kernel path after an exchange timed out
 static thread_local HostPoll tl_poll;
 
@@ -41,7 +43,7 @@ template <typename T>
 static size_t cg_workspace_bytes(int nx, int ny) {
   const size_t n = (size_t)nx * ny;
   size_t b = 0;
-  b += 9 * align_up(n * sizeof(T), 256);                 // diag + 4 off-diagonal arrays (T) + r, z, p0, p1
+  b += 11 * align_up(n * sizeof(T), 256);                // diag + 4 off-diagonal arrays (T) + r, z, p0, p1 + the two z' perimeter buffers
   b += align_up(4 * n * sizeof(float), 256) + 256;        // float copy of the off-diagonals + flag
   b += 3 * align_up(3 * kMaxPartials * sizeof(T), 256);
   b += align_up(SC_COUNT * sizeof(T), 256) + align_up(2 * sizeof(CgState), 256) + 512;
@@ -131,7 +133,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   // ---- persistent segments (cg_persist.h): applicable when every wave's region fits on chip
   int persist_R = 0, persist_NQ = 0, persist_grid = 0;
   PersistCtl pc;
-  pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr;
+  pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr; pc.epoch0 = 0;
   const int force = opt(OPT_CG_PERSIST), force_r = opt(OPT_CG_PERSIST_R);   // -1: automatic
   int exchanges = (opt(OPT_CG_EXCHANGES) == 1 || opt(OPT_CG_EXCHANGES) == 2) ? opt(OPT_CG_EXCHANGES) : kPersistDefaultExchanges;
   if (sizeof(T) != 8) exchanges = 2;   // cg_persist1 is tuned for fp64 state (the fp32 instantiations spill registers)
@@ -187,7 +189,11 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     }
   }
   auto launch_segment = [&](int kb, int ke) -> int {
-    PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 128, stream));   // epochs restart at 1 in every launch
+    // Tags are unique per launch (a 16-bit launch counter above a 16-bit exchange counter; a segment has < 2^15 exchanges): a
+    // record left by an earlier launch - in memory or in some XCD's L2 - can never pass for one of this launch.  The records are
+    // zeroed as well, which covers the counter's wrap.
+    pc.epoch0 = (g_persist_launches.fetch_add(1, std::memory_order_relaxed) & 0xffffu) << 16;
+    PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 128, stream));
     constexpr bool kCanSym = RECON && sizeof(CT) == 4;     // the symmetric variant exists for the compact coefficient path
 #define PISO_PERSIST_LAUNCH(SYMV)                                                                                            \
     do {                                                                                                                     \
@@ -302,9 +308,11 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     PISO_HIP_CHECK(hipMemcpy(h.data(), pc.timing, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     PISO_HIP_CHECK(hipFree(pc.timing));
     const char* names2[5] = {"phaseA", "barrierA", "phaseB", "barrierB", "-"};
-    const char* names1[5] = {"D (p update, stencil, sums, publish)", "exchange", "U (stencil, x / r update, ring)", "-", "-"};
+    const char* names1[9] = {"D (p update, stencil, sums, publish)", "exchange", "U (stencil, x / r update, ring)", "-", "-",
+                             "  exchange: wave sums + drain of the perimeter stores", "  exchange: first barrier", "  exchange: publish + polling",
+                             "  exchange: record sums + second barrier"};
     const char** names = exchanges == 1 ? names1 : names2;
-    for (int q = 0; q < 5; ++q) {
+    for (int q = 0; q < (exchanges == 1 ? 9 : 5); ++q) {
       double s = 0, mn = 1e300, mx = 0;
       for (int b = 0; b < persist_grid; ++b) { const double v = (double)h[q * persist_grid + b]; s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
       fprintf(stderr, "cg_persist %s: avg %.2f us/iter  min %.2f  max %.2f\n", names[q], 0.01 * s / persist_grid / (double)(k_last > 0 ? k_last : 1),
@@ -356,6 +364,7 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   a.cC = cC;
   a.b = b; a.x = x_out;
   a.r = ar.take<T>(n); a.z = ar.take<T>(n); a.p[0] = ar.take<T>(n); a.p[1] = ar.take<T>(n);
+  a.zp[0] = ar.take<T>(n); a.zp[1] = ar.take<T>(n);
   a.partsA = ar.take<T>(3 * kMaxPartials); a.partsB = ar.take<T>(3 * kMaxPartials); a.partsS = ar.take<T>(kMaxPartials);
   a.scal = ar.take<T>(SC_COUNT);
   a.state = ar.take<CgState>(2);

@@ -44,6 +44,7 @@ struct CgArgs {
   const T* b;
   T *x, *r, *z;
   T* p[2];                           // ping-pong search direction
+  T* zp[2];                          // cg_persist1: ping-pong buffers of the published z' perimeters (agent-scope accesses ONLY)
   T* partsA;                         // K1 partials  [3][kMaxPartials]: sum p, p.r, p.z'
   T* partsB;                         // K2 partials  [3][kMaxPartials]: r.z', sum r, max|r|
   T* partsS;                         // setup partials [kMaxPartials]: sum |diag|

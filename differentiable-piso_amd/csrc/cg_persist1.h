@@ -46,11 +46,19 @@ constexpr int kX1RecWords = 16;                  // 8-byte words per record: 2 p
 // one load instruction covers four whole records (512 contiguous bytes); wave w polls records 32 w .. 32 w + 31 with 8 loads
 // per lane, one round trip once the records are there.  Lane pairs (2 q, 2 q + 1) hold the two halves of sum q.
 constexpr int kX1Sm = 160;                        // LDS words per parity: [8 sums][8 waves] | [8 waves][8 sums] | 8 flags
-template <typename T, int KEEP>
-__device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Values], unsigned epoch, T* smem) {
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+template <typename T, typename F = NoPrefetch>
+__device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Values], unsigned epoch, T* smem,
+                                               F after_drain = F(), unsigned long long* tsub = nullptr) {
+  // tsub (diagnostic builds): clocks of [0] reduction + drain of this wave's stores, [1] first barrier, [2] publish + polling,
+  // [3] wave sums + second barrier
+  unsigned long long t0 = (kPersistDiag && tsub) ? wall_clock64() : 0;
+  auto tsplit = [&](int q) __attribute__((always_inline)) {
+    if (kPersistDiag && tsub) { const unsigned long long t = wall_clock64(); tsub[q] += t - t0; t0 = t; }
+  };
   typedef unsigned long long u64;
   constexpr int NV = kX1Values;
-  static_assert(kPersistMaxGrid == kPersistWaves * 32, "every wave polls 32 records");
+  static_assert(kPersistMaxGrid == kPersistWaves * 32 && (kPersistWaves & (kPersistWaves - 1)) == 0, "every wave polls 32 records");
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   T* sm = smem + (epoch & 1) * kX1Sm;                       // parity double buffer: two __syncthreads per exchange
 #pragma unroll
@@ -59,8 +67,14 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
 #pragma unroll
     for (int q = 0; q < NV; ++q) sm[q * kPersistWaves + wave] = v[q];
   }
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");   // this wave's write-through stores have completed
-  __syncthreads();
+  // EVERY vector-memory operation of this wave has completed - in particular its write-through perimeter stores - before the
+  // workgroup's record says so.  (A counted wait that lets the two prefetch loads issued behind the last store stay in flight
+  // would save ~0.4 us; it relies on loads and stores retiring in one order, which is not promised.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  after_drain();
+  tsplit(0);
+  __syncthreads();                                            // every wave of the workgroup has drained its stores
+  tsplit(1);
   u64* rec = c.rec + (size_t)(epoch & 1) * kPersistMaxGrid * kX1RecWords;
   if (wave == 0) {
     // lane l < 16 publishes word l: sum l / 2, low half (even l) or high half (odd l) - one store instruction, one cache line
@@ -72,6 +86,9 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
     if (lane < kX1RecWords)
       __hip_atomic_store(rec + (size_t)blockIdx.x * kX1RecWords + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // (Tried: no barrier here - every wave counts itself in through LDS and the LAST one publishes.  Wave 0 waits 2.3 us of a 7 us
+  // exchange in this barrier, but without it the exchange took 8.3 us and the row loops slowed down - 21 us per iteration
+  // against 17: the waves that arrive early poll, and their polling competes with the stores of the ones still working.)
   bool good = true;
   {
     const int wd = lane & 15, sub = lane >> 4;               // my word of the record, my record inside a group of four
@@ -80,7 +97,7 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       w[i] = 0;
-      okl[i] = ((wave * 8 + i) * 4 + sub) >= (int)gridDim.x;  // records beyond the grid count as arrived (payload 0)
+      okl[i] = ((wave * 8 + i) * 4 + sub) >= (int)gridDim.x;   // records beyond the grid count as arrived (payload 0)
     }
     unsigned spins = 0;
     while (true) {
@@ -97,6 +114,7 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
       if (++spins > (1u << 22)) { good = false; break; }
       __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_SLEEP);
     }
+    tsplit(2);
     // even lanes assemble their sum from their own word (low half) and the neighbour lane's (high half); records of a lane
     // are added in order, then the four records-per-instruction rows, then (after the barrier) the eight waves
     double acc = 0;
@@ -117,6 +135,7 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
     }
   }
   __syncthreads();
+  tsplit(3);
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     T t = 0;
@@ -156,8 +175,11 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   const rsrc_t Rr = make_rsrc(a.r, nbytesT), Rx = make_rsrc(a.x, nbytesT);
   const rsrc_t RoS = make_rsrc(a.oS, nbytesC), RoW = make_rsrc(a.oW, nbytesC), RoE = make_rsrc(a.oE, nbytesC), RoN = make_rsrc(a.oN, nbytesC);
   const rsrc_t RcC = make_rsrc(a.cC, nbytesT);
-  // p[0] / p[1]: the direction of the two-kernel path on entry and exit; in between the ping-pong buffers of the published z'
+  // p[0] / p[1]: the direction of the two-kernel path, read on entry and written on exit.  zp[0] / zp[1]: the published z'
+  // perimeters, touched by agent-scope (sc1) stores and loads only - never by a plain load, whose copy of a line in the reader
+  // XCD's L2 another XCD's write-through store does not invalidate.
   const rsrc_t Rp0 = make_rsrc(a.p[0], nbytesT), Rp1 = make_rsrc(a.p[1], nbytesT);
+  const rsrc_t Rz0 = make_rsrc(a.zp[0], nbytesT), Rz1 = make_rsrc(a.zp[1], nbytesT);
   auto row_wrap = [&](int j, bool& valid) __attribute__((always_inline)) -> int {   // scalar: rows outside wrap or vanish
     valid = true;
     if (j < 0) { if (!a.per_y) valid = false; return ny - 1; }
@@ -356,10 +378,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     for (int t = 0; t < D; ++t) issue_coef(t);
   }
 
-  unsigned epoch = 0;
+  unsigned epoch = c.epoch0;
   bool healthy = true, first = true;
   int k = k_begin;
-  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tlast = (kPersistDiag && c.timing) ? wall_clock64() : 0;
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tsub[4] = {0, 0, 0, 0}, tlast = (kPersistDiag && c.timing) ? wall_clock64() : 0;
   auto tick = [&](int slot) __attribute__((always_inline)) {     // diagnostic builds only (-DPISO_PERSIST_DIAG): D / exchange / U clocks
     if (kPersistDiag && c.timing) { const unsigned long long t = wall_clock64(); tacc[slot] += t - tlast; tlast = t; }
   };
@@ -373,10 +395,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   T lU[2] = {0, 0};                                           // local sum r, count from the last U (for the next exchange)
   const T accuracy = uniform((T)a.accuracy);
   for (; k < k_end && healthy && !st.done; ++k) {
-    // z'_k is published into p[(k + 1) & 1]: at entry p[k_begin & 1] still holds the direction other workgroups may be loading;
-    // consecutive iterations alternate buffers (a neighbour's loads of z'_k are consumed before it publishes its record k + 1,
-    // which everybody needs before writing the same buffer again in iteration k + 2)
-    const rsrc_t Rz = (k & 1) ? Rp0 : Rp1;
+    // consecutive iterations alternate buffers: a neighbour's loads of z'_k are consumed before it publishes its record k + 1,
+    // which everybody needs before writing the same buffer again in iteration k + 2
+    const rsrc_t Rz = (k & 1) ? Rz1 : Rz0;
     const T beta = uniform(-(rz_next + vs * sumr) / pz);     // (:351-352), unguarded as coded
     // ---- D(k): p = r + beta p on my cells and on the ring; z' = L p; sums; the perimeter of z' goes out
     T sD[kX1Values] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -426,8 +447,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     sD[6] = lU[0]; sD[7] = lU[1];
     ++epoch;
     tick(0);
-    // (the last row's perimeter store is followed by exactly one row of coefficient loads)
-    healthy = grid_exchange8<T, (D < NT) ? kBaseLoads : 0>(c, sD, epoch, smem);
+    healthy = grid_exchange8<T>(c, sD, epoch, smem, NoPrefetch(), (kPersistDiag && c.timing) ? tsub : nullptr);
     tick(1);
     if (!healthy) break;
     // ---- the stopping test of iteration k, one exchange late but before anything moves (x = x_k): (:312-335)
@@ -490,13 +510,15 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   if (kPersistDiag && c.timing && threadIdx.x == 0) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) c.timing[q * gridDim.x + blockIdx.x] += tacc[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) c.timing[(5 + q) * gridDim.x + blockIdx.x] += tsub[q];
   }
   // ---- the last U's sum r and count are only known per workgroup: one more exchange (once per segment)
   T tOut[3] = {rz_next, sumr, cnt_last};
   if (!first && healthy && !st.done) {
     T sX[kX1Values] = {0, 0, 0, 0, 0, 0, lU[0], lU[1]};
     ++epoch;
-    healthy = grid_exchange8<T, 0>(c, sX, epoch, smem);
+    healthy = grid_exchange8<T>(c, sX, epoch, smem);
     tOut[1] = sX[6]; tOut[2] = sX[7];
   }
 

@@ -277,6 +277,7 @@ static int slab_solve(std::vector<SlabRank<T>>& R, Comm<T>& comm, int nx, int ny
     k.rbase = ar.take<T>(nh); k.pbase[0] = ar.take<T>(nh); k.pbase[1] = ar.take<T>(nh); k.xbase = ar.take<T>(nh);
     CgArgs<T>& a = k.a;
     a.z = ar.take<T>(n);
+    a.zp[0] = a.zp[1] = nullptr;              // (the slab solver runs the two-kernel iteration)
     a.partsA = ar.take<T>(3 * kMaxPartials); a.partsB = ar.take<T>(3 * kMaxPartials); a.partsS = ar.take<T>(kMaxPartials);
     a.scal = ar.take<T>(SC_COUNT);
     a.state = ar.take<CgState>(2);

@@ -63,6 +63,34 @@ def test_persistent_cg_equals_two_kernel_path_2048(walls, exchanges, piso_option
     assert Nn.lib.piso_cg_persist_fallbacks() == f0, "a grid exchange timed out and the solve fell back to the two-kernel path"
 
 
+@pytest.mark.parametrize("exchanges", [1, 2])
+def test_persistent_cg_first_iterations_back_to_back_launches_2048(exchanges, piso_option):
+    """Short solves queued back to back (no host synchronisation in between, device copies in flight when the persistent kernel
+    starts) against the two-kernel iteration after 3, 4 and 6 iterations: agreement to round-off (measured 2e-16 .. 5e-16).
+    Regression for a buffer-store data hazard: a 16-byte perimeter store whose row offset sat in an SGPR was followed directly by
+    a VALU write of its first data register; with the memory pipeline busy the last lanes stored the low dword of the NEW value
+    (errors of 1e-12 after the third iteration, 1e-7 after the fourth - only when launches followed each other closely)."""
+    from diffpiso.solvers import cg_solve_native
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from diag_persist1 import case
+    L, b = case(N, N)
+    for nit in (3, 4, 6):
+        piso_option("cg_persist", 0)
+        xa, _ = cg_solve_native(N, N, True, True, L, b, 1e-30, nit, False, 1000)
+        piso_option("cg_persist", 1)
+        piso_option("cg_persist_r", 16)
+        piso_option("cg_exchanges", exchanges)
+        outs = []
+        for rep in range(6):
+            xb, _ = cg_solve_native(N, N, True, True, L, b, 1e-30, nit, False, 1000)
+            outs.append(xb.clone())
+            junk = [xb.clone() for _ in range(4)]          # keeps the copy engines / CUs busy while the next solve starts
+        scale = xa.abs().max()
+        errs = [float((xa - xb).abs().max() / scale) for xb in outs]
+        assert max(errs) < 1e-13, (nit, errs)
+
+
 def test_cg_manufactured_solution_2048():
     """b = (L + c 11^T) x_true  ->  the solver must return x_true (the shift pins the mean)."""
     from diffpiso.solvers import cg_solve_native, laplace_matrix_native
