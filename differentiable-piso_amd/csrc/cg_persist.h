@@ -439,21 +439,22 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
     cS[t] = bld<CT, V>(RoS, vCq, sC); cW[t] = bld<CT, V>(RoW, vCq, sC);
     if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vCq, sC); cN[t] = bld<CT, V>(RoN, vCq, sC); }
     if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
-    if constexpr (SYM) {
-      if (jj == 0) {                                       // W of the first column of the strip to the right: E of my last column
-        const int side = lane / R, er = lane - side * R;
-        int cc = (tx0[q] + 1) * 64 * V;
-        if (cc >= nx) cc = a.per_x ? 0 : -1;
-        const unsigned vo = (side == 1 && cc >= 0) ? (unsigned)(j0[q] + er) * rowC + (unsigned)(cc * sizeof(CT)) : 0xffffffffu;
-        eW[q] = bld1<CT>(RoW, vo, 0);
-      }
-      if (jj == R - 1) {                                   // S of the row above the region: N of my last row
-        bool valid;
-        const int jw = row_wrap(j0[q] + R, valid);
-        cSh[q] = bld<CT, V>(RoS, valid ? vCq : 0xffffffffu, (unsigned)jw * rowC);
-      }
-    }
   };
+  // SYM: W of the first column of the strip to the right (E of my last column; lane R + jj: row jj) and S of the row above the
+  // region (N of my last row): constants of the launch, loaded once (not with rows 0 / R-1 of every pass)
+  if constexpr (SYM) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int side = lane / R, er = lane - side * R;
+      int cc = (tx0[q] + 1) * 64 * V;
+      if (cc >= nx) cc = a.per_x ? 0 : -1;
+      const unsigned vo = (has[q] && side == 1 && cc >= 0) ? (unsigned)(j0[q] + er) * rowC + (unsigned)(cc * sizeof(CT)) : 0xffffffffu;
+      eW[q] = bld1<CT>(RoW, vo, 0);
+      bool valid;
+      const int jw = row_wrap(j0[q] + R, valid);
+      cSh[q] = bld<CT, V>(RoS, (has[q] && valid) ? coef_offset(q) : 0xffffffffu, (unsigned)jw * rowC);
+    }
+  }
   // p_new on the cells around a region, rebuilt from what the neighbours published (perimeters of r and of the old p):
   // pnb / pna = the rows below / above, edge = the two columns next to the strip (lane l < R: left neighbour of row l,
   // lane R + l: right neighbour).  Kept from phase A to phase B.

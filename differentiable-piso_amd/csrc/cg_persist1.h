@@ -284,21 +284,23 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     cS[t] = bld<CT, V>(RoS, vCq, sC); cW[t] = bld<CT, V>(RoW, vCq, sC);
     if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vCq, sC); cN[t] = bld<CT, V>(RoN, vCq, sC); }
     if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
-    if constexpr (SYM) {
-      if (jj == 0) {                                       // W of the first column of the strip to the right: E of my last column
-        const int side = lane / R, er = lane - side * R;
-        int cc = (tx0[q] + 1) * 64 * V;
-        if (cc >= nx) cc = a.per_x ? 0 : -1;
-        const unsigned vo = (side == 1 && cc >= 0) ? (unsigned)(j0[q] + er) * rowC + (unsigned)(cc * sizeof(CT)) : 0xffffffffu;
-        eW[q] = bld1<CT>(RoW, vo, 0);
-      }
-      if (jj == R - 1) {                                   // S of the row above the region: N of my last row
-        bool valid;
-        const int jw = row_wrap(j0[q] + R, valid);
-        cSh[q] = bld<CT, V>(RoS, valid ? vCq : 0xffffffffu, (unsigned)jw * rowC);
-      }
-    }
   };
+  // SYM: W of the first column of the strip to the right (E of my last column; lane R + jj: row jj) and S of the row above the
+  // region (N of my last row).  Constants of the launch: loaded ONCE - reloading them with rows 0 / R-1 of every pass put a full
+  // memory trip in front of the rows that still used them (0.55 us per iteration at 2048^2).
+  if constexpr (SYM) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int side = lane / R, er = lane - side * R;
+      int cc = (tx0[q] + 1) * 64 * V;
+      if (cc >= nx) cc = a.per_x ? 0 : -1;
+      const unsigned vo = (has[q] && side == 1 && cc >= 0) ? (unsigned)(j0[q] + er) * rowC + (unsigned)(cc * sizeof(CT)) : 0xffffffffu;
+      eW[q] = bld1<CT>(RoW, vo, 0);
+      bool valid;
+      const int jw = row_wrap(j0[q] + R, valid);
+      cSh[q] = bld<CT, V>(RoS, (has[q] && valid) ? coef_offset(q) : 0xffffffffu, (unsigned)jw * rowC);
+    }
+  }
   // z' = L p of row t of my regions: summation order of calcZ_v4 (pressure_solve_op.cu.cc:81-90).  D and U both call this on
   // the same registers, so they see bitwise the same z'.
   auto zrow = [&](int t) __attribute__((always_inline)) -> Vec<T, V> {

@@ -15,6 +15,8 @@ __global__ void rate(T* out, int iters, unsigned long long* cycles) {
     for (int c = 0; c < CHAINS; ++c) {
       if (OP == 0) a[c] = __builtin_fma(a[c], m, b);
       if (OP == 1) a[c] = a[c] + b;
+      if (OP == 2) { float f = (float)threadIdx.x + c; asm volatile("" : "+v"(f)); a[c] = a[c] + (T)f; }          // v_cvt_f64_f32 + v_add_f64
+      if (OP == 3) { int lo = (int)i + c; asm volatile("" : "+v"(lo)); lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, false); a[c] = a[c] + (T)__int_as_float(lo & 0x3f800000); }   // + wave_shr DPP (+ and, cvt)
     }
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
@@ -45,5 +47,7 @@ int main() {
   run<double, 2, 0>("v_fma_f64", 512); run<double, 1, 0>("v_fma_f64", 512);
   run<double, 8, 1>("v_add_f64", 512); run<double, 1, 1>("v_add_f64", 512);
   run<float, 8, 0>("v_fma_f32", 512); run<float, 1, 0>("v_fma_f32", 512);
+  run<double, 8, 2>("v_cvt_f64_f32 + v_add_f64", 512); run<double, 8, 2>("v_cvt_f64_f32 + v_add_f64", 256);
+  run<double, 8, 3>("dpp + and + cvt + add", 512);
   return 0;
 }
