@@ -66,3 +66,29 @@ def test_rccl_path_with_one_rank():
         assert np.abs(xs.cpu().numpy() - x1.cpu().numpy()).max() <= 1e-6 * np.abs(x1.cpu().numpy()).max()
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("walls", [False, True])
+@pytest.mark.parametrize("slabs", [2, 4, 8])
+def test_emulated_slabs_1024(slabs, walls):
+    """The slab decomposition at a production size (1024^2, slabs of 512 / 256 / 128 rows): G virtual ranks in lock-step with the
+    loopback all-reduce and halo exchange against the single-GPU solver - short fixed runs to round-off (only the grouping of the
+    partial sums differs) and a converged solve to the tolerance."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from diag_persist1 import case
+    from diffpiso.distributed import cg_solve_slab_emulated
+    from diffpiso.solvers import cg_solve_native
+    n = 1024
+    L, b = case(n, n, walls=walls)
+    per = not walls
+    for nit in (1, 2, 7, 45, 150):
+        xa, _ = cg_solve_native(n, n, per, per, L, b, 1e-30, nit, False, 1000)
+        xb, itb = cg_solve_slab_emulated(slabs, n, n, per, per, L, b, 1e-30, nit, False, 1000)
+        assert itb == nit
+        assert float((xa - xb).abs().max() / xa.abs().max()) <= 1e-9, nit
+    xa, ita = cg_solve_native(n, n, per, per, L, b, 1e-7, 20000, False, 1000)
+    xb, itb = cg_solve_slab_emulated(slabs, n, n, per, per, L, b, 1e-7, 20000, False, 1000)
+    assert ita < 20000 and itb < 20000 and abs(ita - itb) <= max(10, 0.1 * ita), (ita, itb)
+    # both stop at max|r| < 1e-7: the iterates agree to (tolerance / smallest eigenvalue)
+    assert float((xa - xb).abs().max() / xa.abs().max()) <= 1e-3
