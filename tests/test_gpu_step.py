@@ -120,7 +120,19 @@ def test_unrolled_adjoint_matches_oracle(name, steps, cut, lin_double):
     if cut is None or (steps - 1) // cut * cut == 0:
         e = (rel(vel_t.grad.cpu().numpy(), d_vel), rel(p_t.grad[0, :, :, 0].cpu().numpy(), d_p))
         print("unrolled backward rel-L2 (d_vel, d_p):", name, steps, e)
-        assert max(e) < 2 * TOL, e
+        assert e[0] < 2 * TOL, e
+        # dL/dp0 = G^T(adjoint of the predictor) is a difference of neighbouring faces: |d_p| is 20-400 x smaller than |d_vel|
+        # and inherits the ABSOLUTE round-off of the float32 transposed solve.  The floor is measured, not assumed: how far
+        # the oracle's own d_p moves between a float32 and a float64 advection solve (6.5e-5 for spatial_ml, 2e-6 periodic);
+        # two float32 implementations cannot agree better than that.
+        floor = 0.0
+        if not lin_double:
+            s64 = oracle_setup(c, **dict(SOLVER, lin_double=True, lin_tol=1e-10))
+            v64, p64, t64 = R.run_steps(s64, c["vel"], c["p"], c["dt"], c["dirichlet_values"], steps)
+            _, d_p64, _ = R.run_steps_backward(s64, t64 if cut is None else t64[(steps - 1) // cut * cut:], v64[-1], np.zeros_like(p64[-1]))
+            floor = rel(d_p, d_p64)
+            print("float32-advection floor of d_p (oracle f32 vs f64):", floor)
+        assert e[1] < 2 * TOL + 2 * floor, (e, floor)
     else:
         assert vel_t.grad is None or float(vel_t.grad.abs().max()) == 0.0
 
