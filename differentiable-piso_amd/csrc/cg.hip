@@ -141,27 +141,8 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     int dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int ntx = nx / (64 * V);
-    if (nx % (64 * V) == 0) {                               // every lane of a strip has cells
-      // one region of 16 rows per wave has the smallest halo overhead; taken when it keeps at least 3/4 of the waves busy
-      if (ny % 16 == 0 && (force_r <= 0 || force_r == 16)) {
-        const long long nreg = (long long)ntx * (ny / 16);
-        if (nreg <= (long long)cus * kPersistWaves && (force_r > 0 || 4 * nreg >= 3LL * cus * kPersistWaves)) {
-          persist_R = 16; persist_NQ = 1; pc.nreg = (int)nreg; pc.ntx = ntx;
-          persist_grid = (int)((nreg + kPersistWaves - 1) / kPersistWaves);
-        }
-      }
-      for (int R : {2, 4, 8}) {
-        if (persist_R) break;
-        if (force_r > 0 && force_r != R) continue;
-        if (ny % R != 0) continue;                          // every region has R rows
-        const long long nreg = (long long)ntx * (ny / R);
-        if (nreg % 2 == 0 && nreg <= (long long)cus * kPersistWaves * 2) {   // a wave owns 2 regions or none
-          persist_R = R; persist_NQ = 2; pc.nreg = (int)nreg; pc.ntx = ntx;
-          persist_grid = (int)((nreg + kPersistWaves * 2 - 1) / (kPersistWaves * 2));
-        }
-      }
-    }
+    const PersistShape shape = persist_shape(nx, ny, V, cus, force_r);
+    persist_R = shape.R; persist_NQ = shape.NQ; persist_grid = shape.grid; pc.nreg = shape.nreg; pc.ntx = shape.ntx;
     if (persist_R && n < 16384 && force != 1) persist_R = 0;    // tiny grids: two-kernel path
   }
   if (persist_R == 8) exchanges = 2;   // (two regions of 8 rows per wave: cg_persist1 spills there; rare shape)

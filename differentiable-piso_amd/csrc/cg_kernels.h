@@ -511,7 +511,8 @@ __global__ __launch_bounds__(kBlock) void cg_reset_residual(CgArgs<T> a, int sv)
 // :165-168); flags[0] is set if some off-diagonal is not exactly representable as float (then the T arrays are used),
 // flags[1] if some diagonal is not bit-for-bit -(S + N + W + E) of the float off-diagonals (then it is read, not recomputed).
 // flags[2] is set unless the matrix is symmetric bit for bit: N of a cell equals S of the cell above, E equals W of the cell to
-// the right (periodic wrap, or 0 at a wall); nx = 0 skips the check and sets the flag (slab solver: the neighbour is remote).
+// the right (periodic wrap, or 0 at a wall); nx = 0 skips the check and sets the flag; per_y = 2 (one slab of a decomposed grid)
+// checks the pairs inside the slab only.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void cg_setup_coeffs(const T* __restrict__ L, T* cC, T* oT, float* oF, T* parts,
                                                            int* flags, size_t n, int nx = 0, int ny = 0, int per_x = 0,
@@ -524,8 +525,8 @@ __global__ __launch_bounds__(kBlock) void cg_setup_coeffs(const T* __restrict__ 
     if (nx > 0) {
       const int ci = (int)(i % (size_t)nx), cj = (int)(i / (size_t)nx);
       const T e_nb = (ci + 1 < nx) ? L[(i + 1) * 5 + 1] : (per_x ? L[(i - (size_t)(nx - 1)) * 5 + 1] : (T)0);
-      const T n_nb = (cj + 1 < ny) ? L[(i + (size_t)nx) * 5 + 0] : (per_y ? L[(size_t)ci * 5 + 0] : (T)0);
-      bad_sym |= !(row[3] == e_nb) || !(row[4] == n_nb);
+      const T n_nb = (cj + 1 < ny) ? L[(i + (size_t)nx) * 5 + 0] : (per_y == 1 ? L[(size_t)ci * 5 + 0] : (per_y == 2 ? row[4] : (T)0));
+      bad_sym |= !(row[3] == e_nb) || !(row[4] == n_nb);      // (per_y = 2, a slab: the last row's N pairs with a remote S - not checked)
     }
     const T o[4] = {row[0], row[1], row[3], row[4]};
     cC[i] = row[2];

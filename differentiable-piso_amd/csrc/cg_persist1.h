@@ -24,9 +24,53 @@
 // summation orders); converged answers and the stopping cadence are the reference's.  A segment starts from and ends in the
 // global-memory state of the two-kernel path, exactly like cg_persist.
 #pragma once
+#include <type_traits>
+
 #include "cg_persist.h"
+#include "peer.h"
 
 namespace piso {
+
+// SLAB = true: the kernel works on ONE y-slab of a grid that is cut over the GPUs of a node (cg_slab.hip).  What changes:
+//   * the rows just below / above the slab belong to the neighbouring GPU: the edge regions publish their first / last row of z'
+//     ALSO into that neighbour's mailbox (peer-mapped memory, system-scope stores over xGMI) and read the neighbour's row from
+//     their own mailbox; r, p[] and x carry one halo row below (row -1) and above (row ny) as in the two-kernel slab path - the
+//     ring copies start from them and are written back to them when the segment ends;
+//   * the exchange has a second level: workgroup 0 publishes the GPU's totals to every peer's mailbox, every workgroup adds the
+//     GPUs' records in rank order (bitwise the same totals on every GPU, so every GPU takes the same decisions);
+//   * N of the slab's last row comes from the N array (its S twin lives on the neighbour), sums of the previous K2 from a.gB.
+struct NoSlab {};
+// region shape of the persistent kernels for an nx x ny grid (V cells per lane, `cus` compute units): one region of 16 rows per
+// wave has the smallest halo overhead and is taken when it keeps at least 3/4 of the waves busy (or when forced); else two
+// regions of 2 / 4 / 8 rows per wave.  R = 0: the grid cannot be tiled (two-kernel iteration).
+struct PersistShape { int R = 0, NQ = 0, nreg = 0, ntx = 0, grid = 0; };
+inline PersistShape persist_shape(int nx, int ny, int V, int cus, int force_r) {
+  PersistShape s;
+  if (nx % (64 * V) != 0) return s;                         // every lane of a strip has cells
+  const int ntx = nx / (64 * V);
+  if (ny % 16 == 0 && (force_r <= 0 || force_r == 16)) {
+    const long long nreg = (long long)ntx * (ny / 16);
+    if (nreg <= (long long)cus * kPersistWaves && (force_r > 0 || 4 * nreg >= 3LL * cus * kPersistWaves)) {
+      s.R = 16; s.NQ = 1; s.nreg = (int)nreg; s.ntx = ntx;
+      s.grid = (int)((nreg + kPersistWaves - 1) / kPersistWaves);
+    }
+  }
+  for (int R : {2, 4, 8}) {
+    if (s.R) break;
+    if (force_r > 0 && force_r != R) continue;
+    if (ny % R != 0) continue;                              // every region has R rows
+    const long long nreg = (long long)ntx * (ny / R);
+    if (nreg % 2 == 0 && nreg <= (long long)cus * kPersistWaves * 2) {   // a wave owns 2 regions or none
+      s.R = R; s.NQ = 2; s.nreg = (int)nreg; s.ntx = ntx;
+      s.grid = (int)((nreg + kPersistWaves * 2 - 1) / (kPersistWaves * 2));
+    }
+  }
+  return s;
+}
+struct SlabCtl {
+  PeerView pv;
+  double ncells;           // cells of the GLOBAL grid
+};
 
 // coefficient rows in flight per wave (A/B builds: -DPISO_PERSIST1_DEPTH=n + scripts/sweep_libs.sh).  Measured at 2048^2 / 1024^2:
 // 16-row regions 4 rows 17.8 us (15 spilled VGPRs), 3 rows 17.2 us (6), 2 rows 21.1 us; small regions 4 rows 7.05, 3 rows 8.2 us
@@ -146,12 +190,76 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
   return good;
 }
 
-template <typename T, typename CT, int R, int NQ, bool RECON, bool SYM>
-__global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, PersistCtl c, int k_begin, int k_end, int sv, int pend) {
+// Second level of the exchange (SLAB): the GPU's totals (bitwise the same in all of its workgroups after grid_exchange8) go to
+// every peer's mailbox as one tagged record, written by workgroup 0; wave 0 of EVERY workgroup polls the `world` records of its
+// own mailbox (lane l: word l % 16 of rank l / 16 [+ 4]) and adds them in a fixed order.  A record that carries the tag also says
+// "every perimeter row this GPU stored into a peer's mailbox has completed": the workgroups drained their stores (vmcnt(0))
+// before they published their local records, and workgroup 0 saw all of those before it wrote this one.
+constexpr int kX1SmX = 16;                        // LDS words of the second level: 8 totals, 1 flag
+template <typename T>
+__device__ __forceinline__ bool xgpu_exchange8(const PeerView& pv, T (&v)[kX1Values], unsigned epoch, T* smx2) {
+  T* smx = smx2 + (epoch & 1) * kX1SmX;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  bool good = true;
+  if (wave == 0) {
+    if (blockIdx.x == 0 && lane < kPeerRecWords) {
+      double mine = 0;
+#pragma unroll
+      for (int q = 0; q < kX1Values; ++q) mine = ((lane >> 1) == q) ? (double)v[q] : mine;
+      const peer_u64 word = peer_tagged(mine, lane & 1, epoch);
+      for (int p = 0; p < pv.world; ++p)
+        peer_store(reinterpret_cast<peer_u64*>(pv.mbox[p] + PeerLayout::x_rec(epoch & 1, pv.rank)) + lane, word);
+    }
+    const int wd = lane & 15, sub = lane >> 4;
+    peer_u64 w[2] = {0, 0};
+    bool okl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) okl[i] = (i * 4 + sub) >= pv.world;     // absent ranks count as arrived (payload 0)
+    unsigned spins = 0;
+    while (true) {
+      bool ok = true;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (!okl[i]) w[i] = peer_load(reinterpret_cast<const peer_u64*>(pv.mbox[pv.rank] + PeerLayout::x_rec(epoch & 1, i * 4 + sub)) + wd);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (!okl[i]) okl[i] = (unsigned)(w[i] & 0xffffffffull) == epoch;
+        ok = ok && okl[i];
+      }
+      if (__all(ok)) break;
+      if (++spins > kPeerSpinLimit) { good = false; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned hi_other = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(w[i] >> 32), 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+      acc += __longlong_as_double((long long)((w[i] >> 32) | ((peer_u64)hi_other << 32)));   // (odd lanes: garbage nobody reads)
+    }
+#pragma unroll
+    for (int q = 0; q < kX1Values; ++q) {
+      const double t = ((read_lane_c(acc, 2 * q) + read_lane_c(acc, 16 + 2 * q)) + read_lane_c(acc, 32 + 2 * q)) + read_lane_c(acc, 48 + 2 * q);
+      if (lane == 0) smx[q] = (T)t;
+    }
+    if (lane == 0) smx[kX1Values] = good ? (T)0 : (T)1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kX1Values; ++q) v[q] = uniform(smx[q]);
+  good = uniform(smx[kX1Values]) == (T)0;
+  return good;       // (smx alternates by epoch parity: the barriers of the next exchange separate these reads from the next writes)
+}
+
+constexpr int kSystem = 17;                       // buffer cache policy sc0 | sc1: system scope (peer-mapped mailboxes)
+
+template <typename T, typename CT, int R, int NQ, bool RECON, bool SYM, bool SLAB = false>
+__global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, PersistCtl c, int k_begin, int k_end, int sv, int pend,
+                                                               std::conditional_t<SLAB, SlabCtl, NoSlab> sl = {}) {
   constexpr int V = 16 / sizeof(T);                        // 16-byte lane accesses
   static_assert(R * NQ <= 16 && 2 * R <= 64, "at most 16 rows per wave; the edge columns of a region fit one wave-wide load");
+  static_assert(!SLAB || sizeof(T) == 8, "mailbox rows hold 8-byte elements");
   __shared__ T xs[kPersistWaves * NQ * R * 64 * V];        // the solution of my regions (128 KB at 16 rows per wave, fp64)
-  __shared__ T smem[2 * kX1Sm];
+  __shared__ T smem[2 * kX1Sm + (SLAB ? 2 * kX1SmX : 0)];
   // the direction on the rows below / above my regions: parked in LDS (two reads per pass, one read-modify-write per iteration)
   constexpr bool kParkHalos = (NQ * R < 16) || NQ == 1;     // (two regions of 8 rows: x already fills the LDS)
   __shared__ T halo_s[kParkHalos ? kPersistWaves * NQ * 2 * 64 * V : 1];
@@ -172,6 +280,25 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   }
   const unsigned nbytesT = (unsigned)((size_t)nx * ny * sizeof(T)), nbytesC = (unsigned)((size_t)nx * ny * sizeof(CT));
   const unsigned rowT = (unsigned)(nx * sizeof(T)), rowC = (unsigned)(nx * sizeof(CT));
+  // SLAB: does region q touch the lower / upper edge of the slab, and is there a GPU beyond it (else: a wall of the global grid)?
+  bool bot[NQ], top[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) { bot[q] = SLAB && has[q] && j0[q] == 0; top[q] = SLAB && has[q] && j0[q] + R == ny; }
+  bool nb_lo = false, nb_hi = false;
+  rsrc_t Rmb, Rmlo, Rmhi;                                   // the rows of my mailbox and of the neighbours' mailboxes
+  const unsigned nbytesH = nbytesT + 2 * rowT;              // r / p[] including their halo rows (resources built where they are used)
+  if constexpr (SLAB) {
+    nb_lo = sl.pv.lower >= 0; nb_hi = sl.pv.upper >= 0;
+    const unsigned mbz = (unsigned)(8 * sl.pv.row_cap * 8);  // the eight rows of a mailbox (host-level exchange + z' halos)
+    Rmb = make_rsrc(sl.pv.mbox[sl.pv.rank] + PeerLayout::kRows, mbz);
+    Rmlo = make_rsrc(sl.pv.mbox[nb_lo ? sl.pv.lower : sl.pv.rank] + PeerLayout::kRows, mbz);
+    Rmhi = make_rsrc(sl.pv.mbox[nb_hi ? sl.pv.upper : sl.pv.rank] + PeerLayout::kRows, mbz);
+  }
+  // byte offset of z' halo row (parity, side) inside the rows of a mailbox
+  auto zrow_off = [&](int parity, int side) __attribute__((always_inline)) -> unsigned {
+    if constexpr (SLAB) return (unsigned)((4 + parity * 2 + side) * sl.pv.row_cap * 8);
+    else return 0u;
+  };
   const rsrc_t Rr = make_rsrc(a.r, nbytesT), Rx = make_rsrc(a.x, nbytesT);
   const rsrc_t RoS = make_rsrc(a.oS, nbytesC), RoW = make_rsrc(a.oW, nbytesC), RoE = make_rsrc(a.oE, nbytesC), RoN = make_rsrc(a.oN, nbytesC);
   const rsrc_t RcC = make_rsrc(a.cC, nbytesT);
@@ -219,11 +346,31 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       // the ring: rows below / above (out of range beyond a wall -> 0) and the two neighbouring columns
       // (lane l < R: left neighbour of row l, lane R + l: right neighbour; other lanes and walls read 0)
       const int jb = row_wrap(j0[q] - 1, vb[q]), ja = row_wrap(j0[q] + R, va[q]);
+      if constexpr (SLAB) {                                  // no wrap inside a slab: beyond its edges lies a neighbour's row (or a wall)
+        vb[q] = !bot[q] || nb_lo; va[q] = !top[q] || nb_hi;
+        const unsigned hb = (has[q] && vb[q]) ? vT[q] : 0xffffffffu, ha = (has[q] && va[q]) ? vT[q] : 0xffffffffu;
+        const rsrc_t RrH = make_rsrc(a.r - nx, nbytesH), RpH = make_rsrc(a.p[k_begin & 1] - nx, nbytesH);
+        rhb[q] = bld<T, V>(RrH, hb, (unsigned)j0[q] * rowT);            // (the halo-based resources start one row lower)
+        rha[q] = bld<T, V>(RrH, ha, (unsigned)(j0[q] + R + 1) * rowT);
+        pnb[q] = bld<T, V>(RpH, hb, (unsigned)j0[q] * rowT);
+        pna[q] = bld<T, V>(RpH, ha, (unsigned)(j0[q] + R + 1) * rowT);
+        if constexpr (kParkHalos) {                          // parked at once: no register of the entry survives into the loop
+          T* hs = halo_s + (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V;
+          stv<T, V>(hs, pnb[q]);
+          stv<T, V>(hs + 64 * V, pna[q]);
+        }
+      } else {
       const unsigned hb = (has[q] && vb[q]) ? vT[q] : 0xffffffffu, ha = (has[q] && va[q]) ? vT[q] : 0xffffffffu;
       rhb[q] = bld<T, V>(Rr, hb, (unsigned)jb * rowT);
       rha[q] = bld<T, V>(Rr, ha, (unsigned)ja * rowT);
       pnb[q] = bld<T, V>(Rp, hb, (unsigned)jb * rowT);
       pna[q] = bld<T, V>(Rp, ha, (unsigned)ja * rowT);
+      if constexpr (kParkHalos) {
+        T* hs = halo_s + (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V;
+        stv<T, V>(hs, pnb[q]);
+        stv<T, V>(hs + 64 * V, pna[q]);
+      }
+      }
       const int side = lane / R, er = lane - side * R;
       int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
       vl[q] = tx0[q] > 0 || a.per_x;
@@ -238,7 +385,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   CgState st = a.state[sv & 1];
   T pz = uniform(a.scal[SC_PZ]), vs = uniform(a.scal[SC_VS]), alpha = uniform(a.scal[SC_ALPHA]);
   const T sc_c = uniform(a.scal[SC_C]);
-  const T ncells = (T)((double)nx * (double)ny);
+  T ncells = (T)((double)nx * (double)ny);
+  if constexpr (SLAB) ncells = (T)sl.ncells;
   // totals of the previous K2 (or previous segment): r.z', sum r, #cells with |r| >= accuracy
   T tB[3];
   {
@@ -259,6 +407,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
 #pragma unroll
     for (int q = 0; q < 3; ++q) tB[q] = uniform(smem[q]);
     __syncthreads();
+    if constexpr (SLAB) {                                   // the all-reduced totals of the previous K2 / segment
+#pragma unroll
+      for (int q = 0; q < 3; ++q) tB[q] = uniform(a.gB[q]);
+    }
   }
 
   // ---- coefficient pipeline (as in cg_persist): both passes of an iteration stream the coefficient rows of my regions in
@@ -298,6 +450,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       eW[q] = bld1<CT>(RoW, vo, 0);
       bool valid;
       const int jw = row_wrap(j0[q] + R, valid);
+      if (SLAB && top[q]) cSh[q] = bld<CT, V>(RoN, has[q] ? coef_offset(q) : 0xffffffffu, (unsigned)(ny - 1) * rowC);   // N of my last row
+      else
       cSh[q] = bld<CT, V>(RoS, (has[q] && valid) ? coef_offset(q) : 0xffffffffu, (unsigned)jw * rowC);
     }
   }
@@ -345,11 +499,17 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     }
     return z;
   };
+  unsigned zoff_lo = 0, zoff_hi = 0, zoff_b = 0, zoff_a = 0;   // SLAB: this iteration's rows in the neighbours' / my mailbox
   // perimeter of row jj of region q (what neighbouring regions read): the whole first / last row, else the two end cells
   auto publish = [&](rsrc_t Rd, int q, int jj, const Vec<T, V>& val) __attribute__((always_inline)) {
     const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
     if (jj == 0 || jj == R - 1) {
       bst<T, V, kAgent>(Rd, vT[q], sT, val);
+      if constexpr (SLAB) {
+        // my first row is the row ABOVE the lower neighbour's slab (its side 1), my last row the row BELOW the upper one's (side 0)
+        if (jj == 0 && bot[q] && nb_lo) bst<T, V, kSystem>(Rmlo, vT[q], zoff_lo, val);
+        if (jj == R - 1 && top[q] && nb_hi) bst<T, V, kSystem>(Rmhi, vT[q], zoff_hi, val);
+      }
     } else {
       if (lane == 0) bst1<T, kAgent>(Rd, vT[q], sT, val.v[0]);
       if (lane == 63) bst1<T, kAgent>(Rd, vT[q] + (unsigned)((V - 1) * sizeof(T)), sT, val.v[V - 1]);
@@ -371,8 +531,17 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       bool vbq, vaq;
       const int jb = row_wrap(j0[q] - 1, vbq), ja = row_wrap(j0[q] + R, vaq);
       const unsigned hb = vbq ? vT[q] : 0xffffffffu, ha = vaq ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
+      if constexpr (SLAB) {                                  // (wave-uniform branches: no per-lane offset registers to keep)
+#pragma unroll
+        for (int e = 0; e < V; ++e) { hbZ[q].v[e] = 0; haZ[q].v[e] = 0; }
+        if (!bot[q]) hbZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] - 1) * rowT);
+        else if (nb_lo) hbZ[q] = bld<T, V, kSystem>(Rmb, vT[q], zoff_b);
+        if (!top[q]) haZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] + R) * rowT);
+        else if (nb_hi) haZ[q] = bld<T, V, kSystem>(Rmb, vT[q], zoff_a);
+      } else {
       hbZ[q] = bld<T, V, kAgent>(Rz, hb, (unsigned)jb * rowT);
       haZ[q] = bld<T, V, kAgent>(Rz, ha, (unsigned)ja * rowT);
+      }
     }
   };
   if (has[0]) {
@@ -400,6 +569,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     // consecutive iterations alternate buffers: a neighbour's loads of z'_k are consumed before it publishes its record k + 1,
     // which everybody needs before writing the same buffer again in iteration k + 2
     const rsrc_t Rz = (k & 1) ? Rz1 : Rz0;
+    if constexpr (SLAB) { zoff_lo = zrow_off(k & 1, 1); zoff_hi = zrow_off(k & 1, 0); zoff_b = zrow_off(k & 1, 0); zoff_a = zrow_off(k & 1, 1); }
     const T beta = uniform(-(rz_next + vs * sumr) / pz);     // (:351-352), unguarded as coded
     // ---- D(k): p = r + beta p on my cells and on the ring; z' = L p; sums; the perimeter of z' goes out
     T sD[kX1Values] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -414,7 +584,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         edge[q] = fma(beta, edge[q], eR[q]);
         T* hs = halo_s + (kParkHalos ? (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V : 0);
         if constexpr (kParkHalos) {
-          if (!first) { pnb[q] = ldv<T, V>(hs); pna[q] = ldv<T, V>(hs + 64 * V); }
+          pnb[q] = ldv<T, V>(hs); pna[q] = ldv<T, V>(hs + 64 * V);
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -450,6 +620,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     ++epoch;
     tick(0);
     healthy = grid_exchange8<T>(c, sD, epoch, smem, NoPrefetch(), (kPersistDiag && c.timing) ? tsub : nullptr);
+#ifndef PISO_SLAB_NO_XGPU
+    if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl.pv, sD, epoch, smem + 2 * kX1Sm); }
+#endif
     tick(1);
     if (!healthy) break;
     // ---- the stopping test of iteration k, one exchange late but before anything moves (x = x_k): (:312-335)
@@ -521,6 +694,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     T sX[kX1Values] = {0, 0, 0, 0, 0, 0, lU[0], lU[1]};
     ++epoch;
     healthy = grid_exchange8<T>(c, sX, epoch, smem);
+    if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl.pv, sX, epoch, smem + 2 * kX1Sm); }
     tOut[1] = sX[6]; tOut[2] = sX[7];
   }
 
@@ -538,6 +712,13 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           bst<T, V>(Rp, vT[q], sT, pp[q][jj]);
           bst<T, V>(Rx, vT[q], sT, ldv<T, V>(xl + jj * 64 * V));
         }
+        if constexpr (SLAB) {                               // the two-kernel slab path continues from the halo rows of r and p
+          const rsrc_t RrH = make_rsrc(a.r - nx, nbytesH), RpH = make_rsrc(a.p[k & 1] - nx, nbytesH);
+          T* hs = halo_s + (kParkHalos ? (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V : 0);
+          if constexpr (kParkHalos) { pnb[q] = ldv<T, V>(hs); pna[q] = ldv<T, V>(hs + 64 * V); }
+          if (bot[q] && nb_lo) { bst<T, V>(RrH, vT[q], 0u, rhb[q]); bst<T, V>(RpH, vT[q], 0u, pnb[q]); }
+          if (top[q] && nb_hi) { bst<T, V>(RrH, vT[q], (unsigned)(ny + 1) * rowT, rha[q]); bst<T, V>(RpH, vT[q], (unsigned)(ny + 1) * rowT, pna[q]); }
+        }
       }
   }
   if (blockIdx.x == 0) {
@@ -545,6 +726,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     for (int b = threadIdx.x; b < a.nB; b += kPersistThreads) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) a.partsB[q * kMaxPartials + b] = (b == 0) ? tOut[q] : (T)0;
+    }
+    if constexpr (SLAB) {
+      if (threadIdx.x == 0) { T* g = const_cast<T*>(a.gB); g[0] = tOut[0]; g[1] = tOut[1]; g[2] = tOut[2]; }   // (already summed over all GPUs)
     }
     if (threadIdx.x == 0) {
       a.scal[SC_PZ] = pz; a.scal[SC_VS] = vs; a.scal[SC_ALPHA] = alpha;

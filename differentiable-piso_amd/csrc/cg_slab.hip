@@ -8,16 +8,26 @@
 //   * per-block partial sums are collapsed to 3 scalars on the device, all-reduced over RCCL (xGMI), and read back by the
 //     next kernel's prologue -- no host round trip; every rank evaluates the same stopping test on the same numbers;
 //   * the rank-1 shift uses the global sum |diag| and the global cell count.
-// Communication goes through a tiny interface with two implementations: RCCL (librccl is dlopen'ed on first use, so the
-// library has no link-time dependency on it) and an in-process LOOPBACK that runs G virtual ranks on one device in
-// lock-step -- the test harness for the multi-rank index logic on a single-GPU box (tests/test_gpu_slab.py).
+// Communication goes through a tiny interface with three implementations:
+//   * PEER (default inside a node): every rank owns a peer-mapped mailbox (peer.h); reductions and halo rows are written by
+//     small kernels straight into the consumers' mailboxes - no library call, no host round trip.  With this transport the
+//     NORMAL iterations run inside the persistent kernel cg_persist1<..., SLAB = true>: r, p, x of the slab stay on chip, the
+//     perimeter rows at the slab edges and the per-GPU totals cross xGMI from inside the kernel (one extra hop per iteration);
+//     resets, the first iteration and shapes the kernel cannot tile use the two-kernel iteration below;
+//   * RCCL (librccl is dlopen'ed on first use, so the library has no link-time dependency on it): two-kernel iteration only;
+//   * an in-process LOOPBACK that runs G virtual ranks on one device in lock-step -- the test harness for the multi-rank index
+//     logic on a single-GPU box (tests/test_gpu_slab.py).
+// The peer transport is exercised on a single-GPU box as well: several PROCESSES share the device, export their mailboxes
+// through hipIpc handles and run their kernels concurrently (tests/test_gpu_multiproc.py).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <vector>
 
 #include "cg_kernels.h"
+#include "cg_persist1.h"
 #include "options.h"
+#include "peer.h"
 
 namespace piso {
 
@@ -65,10 +75,30 @@ static int load_rccl() {
     }                                                                           \
   } while (0)
 
+enum { TRANSPORT_RCCL = 1, TRANSPORT_PEER = 2 };
 struct PisoComm {
-  ncclComm_t comm;
-  int rank, world;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  int transport = TRANSPORT_RCCL;
+  // peer transport
+  char* mbox[kMaxRanks] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool connected = false;
+  size_t row_cap = 0, mbox_bytes = 0;
+  unsigned seq_ar = 0, seq_ex = 0;    // sequence numbers of the host-level collectives (advance identically on every rank)
+  unsigned launches = 0;              // persistent slab launches so far: the high half of their exchange tags
+  int* err = nullptr;                 // device flag: a wait on a peer gave up
+  int persist_fallbacks = 0;          // solves restarted on the two-kernel iteration after a persistent segment failed
+  long long persist_iterations = 0;   // CG iterations executed inside persistent slab segments
 };
+
+static PeerView make_view(const PisoComm* pc, bool periodic_y) {
+  PeerView v;
+  for (int r = 0; r < kMaxRanks; ++r) v.mbox[r] = pc->mbox[r];
+  v.rank = pc->rank; v.world = pc->world; v.row_cap = pc->row_cap;
+  v.lower = (pc->rank > 0) ? pc->rank - 1 : (periodic_y ? pc->world - 1 : -1);
+  v.upper = (pc->rank < pc->world - 1) ? pc->rank + 1 : (periodic_y ? 0 : -1);
+  return v;
+}
 
 // ------------------------------------------------------------------------------------------------ per-rank context
 template <typename T>
@@ -81,6 +111,7 @@ struct SlabRank {
   const T* L;
   T* x_out;             // owned rows of the caller's output
   int rank;             // position in the slab ring
+  unsigned* persist_ws; // exchange records + error flag of the persistent kernel
 };
 
 // collapse per-block partial records into `count` scalars (fixed order)
@@ -96,8 +127,14 @@ __global__ __launch_bounds__(kBlock) void slab_collapse(const T* __restrict__ pa
 }
 template <typename T>
 __global__ void slab_flags_to_sums(const int* flags, T* out) {
-  if (threadIdx.x == 0) { out[1] = (T)flags[0]; out[2] = (T)flags[1]; }
+  if (threadIdx.x == 0) { out[1] = (T)flags[0]; out[2] = (T)flags[1]; out[3] = (T)flags[2]; }
 }
+// error flags of a persistent segment (its own exchanges, the waits of the host-level collectives) as a summable value
+template <typename T>
+__global__ void slab_err_to_sum(const int* seg_err, const int* comm_err, T* out) {
+  if (threadIdx.x == 0) out[0] = (T)((*seg_err != 0 || *comm_err != 0) ? 1 : 0);
+}
+constexpr size_t kSlabPersistWsWords = (size_t)2 * kPersistMaxGrid * 32 + 64;   // exchange records (2 x grid x 128 B) + error flag
 // loopback all-reduce: bufs of the G virtual ranks live `stride` apart; sum in rank order, write to all
 template <typename T>
 __global__ void loop_allreduce(T* base, int G, size_t stride, int count) {
@@ -112,17 +149,93 @@ __global__ void slab_copy_rows(const T* __restrict__ src, T* __restrict__ dst, s
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// ---- peer transport: one wave sums `count` <= 8 values of every rank.  Lane l < 2 count carries half l & 1 of value l / 2 as a
+// tagged word to every rank's mailbox (mine included), then polls the `world` records of its own mailbox and adds them in
+// rank order: every rank obtains bitwise the same sums.
+__global__ void peer_allreduce(PeerView pv, double* g, int count, unsigned seq, int* err) {
+  const int lane = threadIdx.x;
+  const bool active = lane < 2 * count;
+  const peer_u64 word = peer_tagged(active ? g[lane >> 1] : 0.0, lane & 1, seq);
+  if (active)
+    for (int p = 0; p < pv.world; ++p)
+      peer_store(reinterpret_cast<peer_u64*>(pv.mbox[p] + PeerLayout::ar_rec(seq & 1, pv.rank)) + lane, word);
+  double acc = 0;
+  bool good = true;
+  for (int r = 0; r < pv.world; ++r) {
+    peer_u64 w = 0;
+    unsigned spins = 0;
+    while (true) {
+      if (active) w = peer_load(reinterpret_cast<const peer_u64*>(pv.mbox[pv.rank] + PeerLayout::ar_rec(seq & 1, r)) + lane);
+      if (__all(!active || (unsigned)(w & 0xffffffffull) == seq)) break;
+      if (++spins > kPeerSpinLimit) { good = false; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const peer_u64 wo = __shfl_down(w, 1, 64);
+    acc += peer_untag(w, wo);
+  }
+  if (active && (lane & 1) == 0) g[lane >> 1] = acc;
+  if (!good && lane == 0) *err = 1;
+}
+
+// ---- peer transport: halo rows.  Block 0 writes my top row into the upper neighbour's mailbox (the row BELOW its slab, side 0),
+// block 1 my bottom row into the lower neighbour's (the row ABOVE its slab, side 1); a system-scope release store of the
+// sequence number follows the data.  Then block 0 waits for the row below my slab, block 1 for the row above it, and copies it
+// to the halo row.  Every rank pushes before it waits: no ordering between ranks is needed.
+__global__ __launch_bounds__(kBlock) void peer_exchange_rows(PeerView pv, const double* bottom_row, const double* top_row,
+                                                             double* halo_below, double* halo_above, int nx, unsigned seq, int* err) {
+  const int side_out = blockIdx.x;                         // 0: to the upper neighbour, 1: to the lower neighbour
+  const int dst = side_out == 0 ? pv.upper : pv.lower;
+  const int par = seq & 1;
+  if (dst >= 0) {
+    const double* src = side_out == 0 ? top_row : bottom_row;
+    peer_u64* row = reinterpret_cast<peer_u64*>(pv.mbox[dst] + PeerLayout::ex_row(par, side_out, pv.row_cap));
+    for (int i = threadIdx.x; i < nx; i += kBlock) peer_store(row + i, (peer_u64)__double_as_longlong(src[i]));
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(reinterpret_cast<peer_u64*>(pv.mbox[dst] + PeerLayout::ex_flag(par, side_out)), (peer_u64)seq, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const int side_in = blockIdx.x;                          // 0: the row below my slab (from the lower neighbour), 1: the row above
+  const int from = side_in == 0 ? pv.lower : pv.upper;
+  if (from < 0) return;
+  __shared__ int ok_s;
+  if (threadIdx.x == 0) {
+    const peer_u64* flag = reinterpret_cast<const peer_u64*>(pv.mbox[pv.rank] + PeerLayout::ex_flag(par, side_in));
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != (peer_u64)seq) {
+      if (++spins > kPeerSpinLimit) { ok = 0; *err = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    ok_s = ok;
+  }
+  __syncthreads();
+  if (!ok_s) return;
+  const peer_u64* row = reinterpret_cast<const peer_u64*>(pv.mbox[pv.rank] + PeerLayout::ex_row(par, side_in, pv.row_cap));
+  double* halo = side_in == 0 ? halo_below : halo_above;
+  for (int i = threadIdx.x; i < nx; i += kBlock) halo[i] = __longlong_as_double((long long)peer_load(row + i));
+}
+
 // ------------------------------------------------------------------------------------------------ communication
 template <typename T>
 struct Comm {
   int world;              // slabs in the ring
   bool periodic_y;
-  PisoComm* rccl;         // NULL = loopback over the local ranks
+  PisoComm* rccl;         // NULL = loopback over the local ranks; else the communicator (RCCL or peer transport)
   size_t g_stride;        // loopback: distance between consecutive ranks' g buffers
+  bool peer() const { return rccl && rccl->transport == TRANSPORT_PEER; }
 
   // sum `count` values at offset `off` of every rank's g buffer
   int allreduce(std::vector<SlabRank<T>>& R, int off, int count, hipStream_t s) {
-    if (rccl) {
+    if (peer()) {
+      if constexpr (sizeof(T) == 8) {
+        if (world == 1) return PISO_OK;
+        peer_allreduce<<<1, 64, 0, s>>>(make_view(rccl, periodic_y), reinterpret_cast<double*>(R[0].g) + off, count, ++rccl->seq_ar, rccl->err);
+      } else {
+        set_error_msg("peer transport: fp64 only"); return PISO_ERR_INVALID_ARG;
+      }
+    } else if (rccl) {
       if (world == 1) return PISO_OK;
       PISO_NCCL_CHECK(g_rccl.AllReduce(R[0].g + off, R[0].g + off, count, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum,
                                        rccl->comm, s));
@@ -135,7 +248,18 @@ struct Comm {
   int exchange(std::vector<SlabRank<T>>& R, int which, hipStream_t s) {
     const int nx = R[0].a.nx;
     auto base0 = [&](SlabRank<T>& k) { return which == 0 ? k.a.r : k.a.x; };   // row 0
-    if (rccl) {
+    if (peer()) {
+      if constexpr (sizeof(T) == 8) {
+        SlabRank<T>& me = R[0];
+        double* row0 = reinterpret_cast<double*>(base0(me));
+        const int ny = me.a.ny;
+        if (nx > (int)rccl->row_cap) { set_error_msg("peer transport: row longer than the mailbox rows"); return PISO_ERR_INVALID_ARG; }
+        peer_exchange_rows<<<2, kBlock, 0, s>>>(make_view(rccl, periodic_y), row0, row0 + (size_t)(ny - 1) * nx, row0 - nx,
+                                                row0 + (size_t)ny * nx, nx, ++rccl->seq_ex, rccl->err);
+      } else {
+        set_error_msg("peer transport: fp64 only"); return PISO_ERR_INVALID_ARG;
+      }
+    } else if (rccl) {
       SlabRank<T>& me = R[0];
       const int ny = me.a.ny, rank = rccl->rank;
       const int lo = (rank > 0) ? rank - 1 : (periodic_y ? world - 1 : -1);
@@ -173,16 +297,46 @@ static size_t slab_rank_bytes(int nx, int nyl) {
   b += align_up(n * sizeof(T), 256) * (1 + 4 + 1);          // cC, oT(4), z
   b += align_up(4 * n * sizeof(float), 256);                 // oF
   b += align_up(nh * sizeof(T), 256) * 4;                    // r, p0, p1, x with halos
+  b += align_up(n * sizeof(T), 256) * 2;                     // z' perimeter buffers of the persistent kernel
   b += 3 * align_up(3 * kMaxPartials * sizeof(T), 256);
   b += 4 * 256 + align_up(16 * sizeof(T), 256);
+  b += align_up(kSlabPersistWsWords * sizeof(unsigned), 256);
   return b + 4096;
 }
 
-static thread_local CgState* tl_slab_pinned = nullptr;
+struct SlabPinned { CgState st; int err; int pad[3]; double errsum; };
+static thread_local SlabPinned* tl_slab_pinned = nullptr;
 
+template <typename T, typename CT, bool RECON, bool SYMV>
+static void launch_slab_segment(int R, int grid, const CgArgs<T>& a, const PersistCtl& pc, int kb, int ke, int sv, int pend,
+                                const SlabCtl& sl, hipStream_t stream) {
+  if constexpr (sizeof(T) == 8) {
+    switch (R) {
+      case 2: cg_persist1<T, CT, 2, 2, RECON, SYMV, true><<<grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pend, sl); break;
+      case 4: cg_persist1<T, CT, 4, 2, RECON, SYMV, true><<<grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pend, sl); break;
+      default: cg_persist1<T, CT, 16, 1, RECON, SYMV, true><<<grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pend, sl); break;
+    }
+  }
+}
+template <typename T, typename CT, bool RECON, bool SYMV>
+static const void* slab_segment_kernel(int R) {
+  if constexpr (sizeof(T) == 8) {
+    switch (R) {
+      case 2: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 2, RECON, SYMV, true>);
+      case 4: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 4, 2, RECON, SYMV, true>);
+      default: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 16, 1, RECON, SYMV, true>);
+    }
+  }
+  return nullptr;
+}
+
+// returns PISO_OK, an error, or kSlabRetry: a persistent segment failed on some rank -> the caller re-initialises the solve and
+// calls again with allow_persist = false
+constexpr int kSlabRetry = -1000;
 template <typename T, typename CT, int V, bool RECON>
 static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accuracy, int max_iterations, int reset,
-                        int* iterations_out, hipStream_t stream) {
+                        int* iterations_out, hipStream_t stream, bool symmetric, bool allow_persist, double global_cells,
+                        unsigned* persist_ws) {
   const int nloc = (int)R.size();
   std::vector<int> g1(nloc), g2(nloc), gflat(nloc);
   for (int q = 0; q < nloc; ++q) {
@@ -200,7 +354,41 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
     a.nA = g1[q]; a.nB = g2[q];
     a.gA = R[q].g; a.gB = R[q].g + 4;
   }
-  if (!tl_slab_pinned) PISO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&tl_slab_pinned), sizeof(CgState), hipHostMallocDefault));
+  if (!tl_slab_pinned) PISO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&tl_slab_pinned), sizeof(SlabPinned), hipHostMallocDefault));
+
+  // ---- persistent segments (peer transport, one rank per process): the NORMAL iterations of the slab run inside
+  // cg_persist1<..., SLAB>; every rank takes the same decision (same shape, same options, failures are all-reduced)
+  PersistShape shape;
+  PersistCtl pc;
+  pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr; pc.epoch0 = 0;
+  SlabCtl sl;
+  constexpr bool kCanSym = RECON && sizeof(CT) == 4;
+  if (sizeof(T) == 8 && V == 16 / (int)sizeof(T) && allow_persist && comm.peer() && nloc == 1 && opt(OPT_CG_PERSIST) != 0 &&
+      R[0].a.nx <= (int)comm.rccl->row_cap) {
+    int dev = 0, cus = 0, per_cu = 0;
+    PISO_HIP_CHECK(hipGetDevice(&dev));
+    PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    shape = persist_shape(R[0].a.nx, R[0].a.ny, V, cus, opt(OPT_CG_PERSIST_R));
+    if (shape.R == 8) shape.R = 0;                          // (two regions of 8 rows: cg_persist1 spills registers there)
+    if (shape.R && (size_t)R[0].a.nx * R[0].a.ny < 16384 && opt(OPT_CG_PERSIST) != 1) shape.R = 0;
+    if (shape.R) {
+      const void* kfn = slab_segment_kernel<T, CT, RECON, false>(shape.R);
+      if constexpr (kCanSym) { if (symmetric) kfn = slab_segment_kernel<T, CT, RECON, true>(shape.R); }
+      PISO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPersistThreads, 0));
+      if ((long long)per_cu * cus < shape.grid || shape.grid > kPersistMaxGrid) shape.R = 0;
+    }
+    if (shape.R) {
+      pc.rec = reinterpret_cast<unsigned long long*>(persist_ws);
+      pc.err = reinterpret_cast<int*>(persist_ws + kSlabPersistWsWords - 16);
+      pc.nreg = shape.nreg; pc.ntx = shape.ntx;
+      PISO_HIP_CHECK(hipMemsetAsync(persist_ws, 0, kSlabPersistWsWords * sizeof(unsigned), stream));
+      sl.pv = make_view(comm.rccl, comm.periodic_y);
+      sl.ncells = global_cells;
+    }
+  }
+  int seg_len = (int)(20000.0 / ((double)R[0].a.nx * R[0].a.ny * 8.5e-6 + 4.0));   // ~20 ms of work per segment
+  seg_len = seg_len < 50 ? 50 : (seg_len > 2000 ? 2000 : seg_len);
+  if (opt(OPT_CG_SEGMENT) > 0) seg_len = opt(OPT_CG_SEGMENT);
 
   auto k1 = [&](int k, int mode, int sv, int chk, int pend) -> int {
     for (int q = 0; q < nloc; ++q) cg_k1<T, CT, V, RECON><<<g1[q], kBlock, 0, stream>>>(R[q].a, k, mode, sv, chk, pend);
@@ -221,6 +409,49 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
   for (int k = 0; k < max_iterations && !finished; ++k) {
     const bool is_reset = ((k + 1) % reset == 0);
     int rc = PISO_OK;
+    if (shape.R && k > 0 && !is_reset) {
+      // NORMAL iterations [k, ke) in one launch: up to the next reset iteration / the end / one segment length
+      int ke = max_iterations;
+      { const int next_reset = ((k + 1 + reset - 1) / reset) * reset - 1; if (next_reset < ke) ke = next_reset; }
+      if (ke > k + seg_len) ke = k + seg_len;
+      if (ke > k) {
+        PisoComm* c = comm.rccl;
+        // tags: a 16-bit launch counter (the same on every rank) above a 16-bit exchange counter.  When the counter wraps, the
+        // records of 65536 launches ago could pass for new ones: everybody waits for everybody, then clears its own.
+        if ((c->launches & 0xffffu) == 0 && c->launches > 0) {
+          rc = comm.allreduce(R, 12, 1, stream);
+          if (rc == PISO_OK) PISO_HIP_CHECK(hipMemsetAsync(c->mbox[c->rank] + PeerLayout::x_rec(0, 0), 0, 2 * kMaxRanks * PeerLayout::kRecBytes, stream));
+          if (rc == PISO_OK) rc = comm.allreduce(R, 12, 1, stream);
+          if (rc != PISO_OK) return rc;
+        }
+        pc.epoch0 = (c->launches++ & 0xffffu) << 16;
+        PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 128, stream));
+        bool launched = false;
+        if constexpr (kCanSym) {
+          if (symmetric) { launch_slab_segment<T, CT, RECON, true>(shape.R, shape.grid, R[0].a, pc, k, ke, sv, pending ? 1 : 0, sl, stream); launched = true; }
+        }
+        if (!launched) launch_slab_segment<T, CT, RECON, false>(shape.R, shape.grid, R[0].a, pc, k, ke, sv, pending ? 1 : 0, sl, stream);
+        PISO_LAUNCH_CHECK();
+        // did the segment fail anywhere?  (g[12] = my error flag, summed over the ranks)
+        slab_err_to_sum<T><<<1, 64, 0, stream>>>(pc.err, c->err, R[0].g + 12);
+        rc = comm.allreduce(R, 12, 1, stream);
+        if (rc != PISO_OK) return rc;
+        if constexpr (sizeof(T) == 8) PISO_HIP_CHECK(hipMemcpyAsync(&tl_slab_pinned->errsum, R[0].g + 12, sizeof(double), hipMemcpyDeviceToHost, stream));
+        PISO_HIP_CHECK(hipMemcpyAsync(&tl_slab_pinned->st, &R[0].a.state[0], sizeof(CgState), hipMemcpyDeviceToHost, stream));
+        PISO_HIP_CHECK(hipStreamSynchronize(stream));
+        if (tl_slab_pinned->errsum != 0) {
+          ++c->persist_fallbacks;
+          PISO_HIP_CHECK(hipMemsetAsync(c->err, 0, sizeof(int), stream));
+          return kSlabRetry;
+        }
+        c->persist_iterations += ke - k;
+        if (tl_slab_pinned->st.done) { finished = true; stop_it = tl_slab_pinned->st.iterations; }
+        k_last = ke - 1;
+        pending = false;                                   // the segment applies every x += alpha p itself
+        k = ke - 1;
+        continue;
+      }
+    }
     if (is_reset) {
       if (pending) { for (int q = 0; q < nloc; ++q) cg_flush_x<T><<<gflat[q], kBlock, 0, stream>>>(R[q].a, k - 1, sv); pending = false; }
       rc = comm.exchange(R, 1, stream);                  // halo rows of x for L x
@@ -241,9 +472,9 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
     pending = true;
     k_last = k;
     if ((k + 1) % batch == 0 || k + 1 == max_iterations) {
-      PISO_HIP_CHECK(hipMemcpyAsync(tl_slab_pinned, &R[0].a.state[sv & 1], sizeof(CgState), hipMemcpyDeviceToHost, stream));
+      PISO_HIP_CHECK(hipMemcpyAsync(&tl_slab_pinned->st, &R[0].a.state[sv & 1], sizeof(CgState), hipMemcpyDeviceToHost, stream));
       PISO_HIP_CHECK(hipStreamSynchronize(stream));
-      if (tl_slab_pinned->done) { finished = true; stop_it = tl_slab_pinned->iterations; }
+      if (tl_slab_pinned->st.done) { finished = true; stop_it = tl_slab_pinned->st.iterations; }
     }
   }
   if (pending && k_last >= 0)
@@ -251,7 +482,13 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
   for (int q = 0; q < nloc; ++q)
     slab_copy_rows<T><<<gflat[q], kBlock, 0, stream>>>(R[q].a.x, R[q].x_out, (size_t)R[q].a.nx * R[q].a.ny);
   PISO_LAUNCH_CHECK();
+  if (comm.peer()) PISO_HIP_CHECK(hipMemcpyAsync(&tl_slab_pinned->err, comm.rccl->err, sizeof(int), hipMemcpyDeviceToHost, stream));
   PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  if (comm.peer() && tl_slab_pinned->err) {
+    PISO_HIP_CHECK(hipMemsetAsync(comm.rccl->err, 0, sizeof(int), stream));
+    set_error_msg("slab CG: a wait on a peer's mailbox gave up (peer process gone or not running?)");
+    return PISO_ERR_HIP;
+  }
   if (iterations_out) *iterations_out = finished ? stop_it : max_iterations;
   return PISO_OK;
 }
@@ -273,11 +510,12 @@ static int slab_solve(std::vector<SlabRank<T>>& R, Comm<T>& comm, int nx, int ny
     Arena ar(ws + gbytes + (size_t)q * ws_per_rank, ws_per_rank);
     k.g = gall + (size_t)q * 16;
     k.cC = ar.take<T>(n); k.oT = ar.take<T>(4 * n); k.oF = ar.take<float>(4 * n);
-    k.flags = ar.take<int>(2);
+    k.flags = ar.take<int>(4);
     k.rbase = ar.take<T>(nh); k.pbase[0] = ar.take<T>(nh); k.pbase[1] = ar.take<T>(nh); k.xbase = ar.take<T>(nh);
     CgArgs<T>& a = k.a;
     a.z = ar.take<T>(n);
-    a.zp[0] = a.zp[1] = nullptr;              // (the slab solver runs the two-kernel iteration)
+    a.zp[0] = ar.take<T>(n); a.zp[1] = ar.take<T>(n);   // z' perimeters of the persistent kernel (agent-scope accesses only)
+    k.persist_ws = ar.take<unsigned>(kSlabPersistWsWords);
     a.partsA = ar.take<T>(3 * kMaxPartials); a.partsB = ar.take<T>(3 * kMaxPartials); a.partsS = ar.take<T>(kMaxPartials);
     a.scal = ar.take<T>(SC_COUNT);
     a.state = ar.take<CgState>(2);
@@ -286,43 +524,61 @@ static int slab_solve(std::vector<SlabRank<T>>& R, Comm<T>& comm, int nx, int ny
     a.r = k.rbase + nx; a.p[0] = k.pbase[0] + nx; a.p[1] = k.pbase[1] + nx; a.x = k.xbase + nx;
     a.nx = nx; a.ny = nyl; a.per_x = per_x; a.per_y = 2;
     a.gA = nullptr; a.gB = nullptr; a.nt = 0;
-    PISO_HIP_CHECK(hipMemsetAsync(k.flags, 0, 2 * sizeof(int), stream));
+    PISO_HIP_CHECK(hipMemsetAsync(k.flags, 0, 4 * sizeof(int), stream));
     PISO_HIP_CHECK(hipMemsetAsync(k.rbase, 0, nh * sizeof(T), stream));
     PISO_HIP_CHECK(hipMemsetAsync(k.pbase[0], 0, nh * sizeof(T), stream));
     PISO_HIP_CHECK(hipMemsetAsync(k.pbase[1], 0, nh * sizeof(T), stream));
     PISO_HIP_CHECK(hipMemsetAsync(k.xbase, 0, nh * sizeof(T), stream));
     cg_zero_partials<T><<<(3 * kMaxPartials + 255) / 256, 256, 0, stream>>>(a.partsA, a.partsB, a.partsS);
     const int gs = grid_for((long long)n, kBlock * 4);
-    cg_setup_coeffs<T><<<gs, kBlock, 0, stream>>>(k.L, k.cC, k.oT, k.oF, a.partsS, k.flags, n);
+    // symmetry is checked inside the slab (per_y = 2: the N entries of its last row pair with S entries on the neighbour - the
+    // persistent kernel reads them from the N array, so nothing is assumed about that pair)
+    cg_setup_coeffs<T><<<gs, kBlock, 0, stream>>>(k.L, k.cC, k.oT, k.oF, a.partsS, k.flags, n, nx, nyl, per_x, 2);
     slab_collapse<T><<<1, kBlock, 0, stream>>>(a.partsS, gs, 1, k.g + 8);
     slab_flags_to_sums<T><<<1, 64, 0, stream>>>(k.flags, k.g + 8);
   }
   PISO_LAUNCH_CHECK();
-  { const int rc = comm.allreduce(R, 8, 3, stream); if (rc != PISO_OK) return rc; }
-  T hg[3];
-  PISO_HIP_CHECK(hipMemcpyAsync(hg, R[0].g + 8, 3 * sizeof(T), hipMemcpyDeviceToHost, stream));
+  { const int rc = comm.allreduce(R, 8, 4, stream); if (rc != PISO_OK) return rc; }
+  T hg[4];
+  PISO_HIP_CHECK(hipMemcpyAsync(hg, R[0].g + 8, 4 * sizeof(T), hipMemcpyDeviceToHost, stream));
   PISO_HIP_CHECK(hipStreamSynchronize(stream));
   const bool f32ok = sizeof(T) == 8 && hg[1] == 0 && !opt_on(OPT_CG_NO_COMPACT);
   const bool recon = f32ok && hg[2] == 0 && !opt_on(OPT_CG_NO_RECON);
-  for (int q = 0; q < nloc; ++q) {
-    SlabRank<T>& k = R[q];
-    const int gflat = grid_for((long long)n, kBlock * 4);
-    cg_init<T><<<gflat, kBlock, 0, stream>>>(k.a, rank_deficient, k.g + 8, global_cells);
-    if (f32ok) { k.a.oS = k.oF; k.a.oW = k.oF + n; k.a.oE = k.oF + 2 * n; k.a.oN = k.oF + 3 * n; }
-    else { k.a.oS = k.oT; k.a.oW = k.oT + n; k.a.oE = k.oT + 2 * n; k.a.oN = k.oT + 3 * n; }
-  }
-  { const int rc = comm.exchange(R, 0, stream); if (rc != PISO_OK) return rc; }     // halo rows of r0 = b
+  const bool symmetric = hg[3] == 0 && !opt_on(OPT_CG_NO_SYM);
   constexpr int VMID = 16 / sizeof(T);
   const bool vec = (nx % VMID == 0);
-#define PISO_SLAB_RUN(CT, V, RC) return slab_iterate<T, CT, V, RC>(R, comm, accuracy, max_iterations, reset, iterations_out, stream)
-  if (f32ok) {
-    if (recon) { if (vec) PISO_SLAB_RUN(float, VMID, true); PISO_SLAB_RUN(float, 1, true); }
-    if (vec) PISO_SLAB_RUN(float, VMID, false);
-    PISO_SLAB_RUN(float, 1, false);
-  }
-  if (vec) PISO_SLAB_RUN(T, VMID, false);
-  PISO_SLAB_RUN(T, 1, false);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    // (second attempt: a persistent segment failed on some rank - every rank restarts the solve on the two-kernel iteration)
+    for (int q = 0; q < nloc; ++q) {
+      SlabRank<T>& k = R[q];
+      const int gflat = grid_for((long long)n, kBlock * 4);
+      if (attempt > 0) {
+        PISO_HIP_CHECK(hipMemsetAsync(k.rbase, 0, nh * sizeof(T), stream));
+        PISO_HIP_CHECK(hipMemsetAsync(k.pbase[0], 0, nh * sizeof(T), stream));
+        PISO_HIP_CHECK(hipMemsetAsync(k.pbase[1], 0, nh * sizeof(T), stream));
+        PISO_HIP_CHECK(hipMemsetAsync(k.xbase, 0, nh * sizeof(T), stream));
+        cg_zero_partials<T><<<(3 * kMaxPartials + 255) / 256, 256, 0, stream>>>(k.a.partsA, k.a.partsB, k.a.partsB);
+        k.a.gA = nullptr; k.a.gB = nullptr;
+      }
+      cg_init<T><<<gflat, kBlock, 0, stream>>>(k.a, rank_deficient, k.g + 8, global_cells);
+      if (f32ok) { k.a.oS = k.oF; k.a.oW = k.oF + n; k.a.oE = k.oF + 2 * n; k.a.oN = k.oF + 3 * n; }
+      else { k.a.oS = k.oT; k.a.oW = k.oT + n; k.a.oE = k.oT + 2 * n; k.a.oN = k.oT + 3 * n; }
+    }
+    { const int rc = comm.exchange(R, 0, stream); if (rc != PISO_OK) return rc; }     // halo rows of r0 = b
+    int rc = PISO_OK;
+#define PISO_SLAB_RUN(CT, V, RC) \
+    rc = slab_iterate<T, CT, V, RC>(R, comm, accuracy, max_iterations, reset, iterations_out, stream, symmetric, attempt == 0, global_cells, R[0].persist_ws)
+    if (f32ok && recon && vec) PISO_SLAB_RUN(float, VMID, true);
+    else if (f32ok && recon) PISO_SLAB_RUN(float, 1, true);
+    else if (f32ok && vec) PISO_SLAB_RUN(float, VMID, false);
+    else if (f32ok) PISO_SLAB_RUN(float, 1, false);
+    else if (vec) PISO_SLAB_RUN(T, VMID, false);
+    else PISO_SLAB_RUN(T, 1, false);
 #undef PISO_SLAB_RUN
+    if (rc != kSlabRetry) return rc;
+  }
+  set_error_msg("slab CG: persistent segment failed twice");
+  return PISO_ERR_HIP;
 }
 
 }  // namespace piso
@@ -344,7 +600,7 @@ int piso_comm_create(const void* id128, int rank, int world, void** comm_out) {
   ncclUniqueId id;
   memcpy(&id, id128, sizeof(id));
   PisoComm* c = new PisoComm;
-  c->rank = rank; c->world = world;
+  c->rank = rank; c->world = world; c->transport = TRANSPORT_RCCL;
   ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, id, rank);
   if (r != ncclSuccess) { set_error_msg(g_rccl.GetErrorString(r)); delete c; return PISO_ERR_HIP; }
   *comm_out = c;
@@ -354,8 +610,68 @@ int piso_comm_create(const void* id128, int rank, int world, void** comm_out) {
 int piso_comm_destroy(void* comm) {
   if (!comm) return PISO_OK;
   PisoComm* c = static_cast<PisoComm*>(comm);
-  if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  if (c->transport == TRANSPORT_RCCL) {
+    if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  } else {
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < c->world; ++r)
+      if (r != c->rank && c->mbox[r]) (void)hipIpcCloseMemHandle(c->mbox[r]);
+    if (c->mbox[c->rank]) (void)hipFree(c->mbox[c->rank]);
+    if (c->err) (void)hipFree(c->err);
+  }
   delete c;
+  return PISO_OK;
+}
+
+// ---- peer transport: create my mailbox (step 1), exchange the 64-byte handles by any means, connect (step 2)
+int piso_comm_peer_create(int rank, int world, int row_capacity, void** comm_out, void* ipc_handle64_out) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  if (!comm_out || !ipc_handle64_out || world < 1 || world > kMaxRanks || rank < 0 || rank >= world || row_capacity < 1) {
+    set_error_msg("piso_comm_peer_create: invalid argument (at most 8 ranks: the GPUs of one node)");
+    return PISO_ERR_INVALID_ARG;
+  }
+  PisoComm* c = new PisoComm;
+  c->rank = rank; c->world = world; c->transport = TRANSPORT_PEER;
+  c->row_cap = align_up((size_t)row_capacity, 32);
+  c->mbox_bytes = PeerLayout::bytes(c->row_cap);
+  void* mb = nullptr;
+  // uncached + fine-grained: a peer's write over xGMI is visible to my system-scope loads without any cache maintenance
+  hipError_t e = hipExtMallocWithFlags(&mb, c->mbox_bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) { set_error("hipExtMallocWithFlags(mailbox)", e); delete c; return PISO_ERR_HIP; }
+  c->mbox[rank] = static_cast<char*>(mb);
+  e = hipMemset(mb, 0, c->mbox_bytes);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->err), sizeof(int));
+  if (e == hipSuccess) e = hipMemset(c->err, 0, sizeof(int));
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipIpcGetMemHandle(static_cast<hipIpcMemHandle_t*>(ipc_handle64_out), mb);
+  if (e != hipSuccess) { set_error("piso_comm_peer_create", e); (void)hipFree(mb); if (c->err) (void)hipFree(c->err); delete c; return PISO_ERR_HIP; }
+  c->connected = (world == 1);
+  *comm_out = c;
+  return PISO_OK;
+}
+
+int piso_comm_peer_connect(void* comm, const void* ipc_handles64_all_ranks) {
+  PisoComm* c = static_cast<PisoComm*>(comm);
+  if (!c || c->transport != TRANSPORT_PEER || !ipc_handles64_all_ranks) { set_error_msg("piso_comm_peer_connect: invalid argument"); return PISO_ERR_INVALID_ARG; }
+  const char* h = static_cast<const char*>(ipc_handles64_all_ranks);
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank || c->mbox[r]) continue;
+    hipIpcMemHandle_t handle;
+    memcpy(&handle, h + (size_t)r * 64, 64);
+    void* p = nullptr;
+    PISO_HIP_CHECK(hipIpcOpenMemHandle(&p, handle, hipIpcMemLazyEnablePeerAccess));
+    c->mbox[r] = static_cast<char*>(p);
+  }
+  c->connected = true;
+  return PISO_OK;
+}
+
+// what the communicator did so far: [0] transport (1 RCCL, 2 peer mailboxes), [1] CG iterations executed inside persistent slab
+// segments, [2] solves restarted on the two-kernel iteration after a segment failed, [3] persistent launches
+int piso_comm_stats(void* comm, long long* out4) {
+  PisoComm* c = static_cast<PisoComm*>(comm);
+  if (!c || !out4) { set_error_msg("piso_comm_stats: invalid argument"); return PISO_ERR_INVALID_ARG; }
+  out4[0] = c->transport; out4[1] = c->persist_iterations; out4[2] = c->persist_fallbacks; out4[3] = c->launches;
   return PISO_OK;
 }
 
@@ -373,6 +689,7 @@ int piso_cg_solve_slab_f64(void* comm, int nx, int ny_local, int periodic_x, int
   }
   if (workspace_bytes < piso_cg_slab_workspace_bytes(nx, ny_local, 1)) { set_error_msg("piso_cg_solve_slab_f64: workspace too small"); return PISO_ERR_INVALID_ARG; }
   PisoComm* pc = static_cast<PisoComm*>(comm);
+  if (pc->transport == TRANSPORT_PEER && !pc->connected) { set_error_msg("piso_cg_solve_slab_f64: peer communicator not connected"); return PISO_ERR_INVALID_ARG; }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   std::vector<SlabRank<double>> R(1);
   R[0].L = laplace_local; R[0].x_out = x_out_local; R[0].rank = pc->rank;
@@ -386,6 +703,9 @@ int piso_cg_solve_slab_f64(void* comm, int nx, int ny_local, int periodic_x, int
   if (x_out_global) {                                       // every rank receives the whole field (replicated PISO step)
     if (pc->world == 1) {
       PISO_HIP_CHECK(hipMemcpyAsync(x_out_global, x_out_local, (size_t)nx * ny_local * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    } else if (pc->transport == TRANSPORT_PEER) {
+      set_error_msg("piso_cg_solve_slab_f64: x_out_global is an RCCL all-gather; with the peer transport pass NULL and gather the slabs yourself");
+      return PISO_ERR_INVALID_ARG;
     } else {
       PISO_NCCL_CHECK(g_rccl.AllGather(x_out_local, x_out_global, (size_t)nx * ny_local, ncclDouble, pc->comm, stream));
     }

@@ -91,6 +91,12 @@ lib.piso_comm_create.argtypes = [_vp, _i, _i, C.POINTER(_vp)]
 lib.piso_comm_create.restype = _i
 lib.piso_comm_destroy.argtypes = [_vp]
 lib.piso_comm_destroy.restype = _i
+lib.piso_comm_peer_create.argtypes = [_i, _i, _i, C.POINTER(_vp), _vp]
+lib.piso_comm_peer_create.restype = _i
+lib.piso_comm_peer_connect.argtypes = [_vp, _vp]
+lib.piso_comm_peer_connect.restype = _i
+lib.piso_comm_stats.argtypes = [_vp, C.POINTER(C.c_longlong)]
+lib.piso_comm_stats.restype = _i
 lib.piso_cg_slab_workspace_bytes.argtypes = [_i, _i, _i]
 lib.piso_cg_slab_workspace_bytes.restype = _sz
 lib.piso_cg_solve_slab_f64.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _ip, _vp, _sz, _vp]

@@ -1,9 +1,14 @@
 """Slab-decomposed pressure CG across the GPUs of one node -- host side.
 
-One process per GPU (torch.distributed, backend "nccl" = RCCL).  The library owns its own RCCL communicator: rank 0 creates
-the 128-byte unique id, it is broadcast with torch.distributed, every rank calls piso_comm_create.  In this round the rest of
-the PISO step is replicated on every rank (it is ~1 % of the step at 2048^2); the CG -- 98 % of the time -- is decomposed:
-each rank solves the rows [rank * ny/world, (rank + 1) * ny/world) and all ranks receive the full pressure (all-gather).
+One process per GPU (torch.distributed).  The grid is cut into contiguous y-slabs; each rank solves the rows
+[rank * ny/world, (rank + 1) * ny/world).  Two transports carry what crosses the slab edges (include/piso_hip.h):
+
+* "peer" (default): every rank owns a peer-mapped mailbox inside the library (hipIpc handle, xGMI peer access); reductions
+  and halo rows are written by kernels straight into the consumer's mailbox, and the NORMAL CG iterations run inside the
+  persistent kernel (state on chip, one in-kernel exchange per iteration).  torch.distributed only carries the 64-byte
+  handles once (any backend: "nccl" on a multi-GPU node, "gloo" when several processes share one GPU in the tests).
+* "rccl": the library's own RCCL communicator (unique id broadcast through torch.distributed), two-kernel iteration with
+  ncclAllReduce / ncclSend / ncclRecv between the kernels.
 """
 import ctypes as C
 
@@ -20,6 +25,12 @@ def slab_rows(rank, world, ny):
     return rank * nyl, (rank + 1) * nyl
 
 
+def _comm_device(device):
+    """torch.distributed moves tensors of the backend's kind: device tensors for nccl (= RCCL), host tensors for gloo."""
+    import torch.distributed as dist
+    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def exchange_unique_id(rank, world, device, make_id=None):
     """Rank 0 creates the 128-byte RCCL unique id, everybody receives it through torch.distributed (any backend)."""
     import torch.distributed as dist
@@ -32,10 +43,22 @@ def exchange_unique_id(rank, world, device, make_id=None):
         else:
             uid = make_id()
     if world > 1:
-        uid_dev = uid.to(device)
+        uid_dev = uid.to(_comm_device(device))
         dist.broadcast(uid_dev, src=0)
         uid = uid_dev.cpu()
     return uid
+
+
+def all_gather_bytes(payload, rank, world, device):
+    """Every rank contributes len(payload) bytes and receives all of them in rank order (mailbox handles)."""
+    mine = torch.tensor(list(payload), dtype=torch.uint8)
+    if world == 1:
+        return bytes(payload)
+    import torch.distributed as dist
+    dev = _comm_device(device)
+    parts = [torch.zeros(len(payload), dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine.to(dev))
+    return b"".join(bytes(t.cpu().tolist()) for t in parts)
 
 
 def max_over_ranks(value, device):
@@ -43,47 +66,93 @@ def max_over_ranks(value, device):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 class SlabCommunicator(object):
-    def __init__(self, rank=None, world=None, device=None):
+    """transport "peer": mailboxes mapped into every rank (row_capacity = longest grid row it has to carry);
+    transport "rccl": the library's RCCL communicator."""
+
+    def __init__(self, rank=None, world=None, device=None, transport="peer", row_capacity=8192):
         import torch.distributed as dist
         if rank is None:
             rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.transport = rank, world, transport
         device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        uid = exchange_unique_id(rank, world, device)
-        raw = (C.c_ubyte * 128)(*[int(v) for v in uid.tolist()])
+        self.device = device
         handle = C.c_void_p()
-        N.check(N.lib.piso_comm_create(raw, rank, world, C.byref(handle)), "piso_comm_create")
-        self.handle = handle
+        if transport == "peer":
+            mine = (C.c_ubyte * 64)()
+            with torch.cuda.device(device):
+                N.check(N.lib.piso_comm_peer_create(rank, world, int(row_capacity), C.byref(handle), mine), "piso_comm_peer_create")
+                self.handle = handle
+                everybody = all_gather_bytes(bytes(mine), rank, world, device)
+                raw = (C.c_ubyte * (64 * world)).from_buffer_copy(everybody)
+                N.check(N.lib.piso_comm_peer_connect(handle, raw), "piso_comm_peer_connect")
+            if world > 1:
+                dist.barrier()                      # nobody writes into a mailbox that is not mapped everywhere yet
+        elif transport == "rccl":
+            uid = exchange_unique_id(rank, world, device)
+            raw = (C.c_ubyte * 128)(*[int(v) for v in uid.tolist()])
+            N.check(N.lib.piso_comm_create(raw, rank, world, C.byref(handle)), "piso_comm_create")
+            self.handle = handle
+        else:
+            raise ValueError("transport must be 'peer' or 'rccl'")
+
+    def stats(self):
+        out = (C.c_longlong * 4)()
+        N.check(N.lib.piso_comm_stats(self.handle, out), "piso_comm_stats")
+        return {"transport": {1: "rccl", 2: "peer"}[int(out[0])], "persistent_iterations": int(out[1]),
+                "persistent_fallbacks": int(out[2]), "persistent_launches": int(out[3])}
 
     def close(self):
         if self.handle:
+            if self.world > 1 and self.transport == "peer":
+                import torch.distributed as dist
+                torch.cuda.synchronize()
+                dist.barrier()                      # nobody unmaps a mailbox a peer's kernel may still write to
             N.lib.piso_comm_destroy(self.handle)
             self.handle = None
 
 
-def cg_solve_slab(comm, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient, residual_reset):
-    """Distributed counterpart of solvers.cg_solve_native: L [ny*nx*5] and div [ny*nx] are the FULL (replicated) arrays;
-    this rank solves its slab and every rank returns the full solution."""
+def cg_solve_slab(comm, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient, residual_reset, gather=True):
+    """Distributed counterpart of solvers.cg_solve_native: L [ny*nx*5] and div [ny*nx] are the FULL (replicated) arrays; this
+    rank solves its slab.  gather=True: every rank returns the full solution; gather=False: only its own rows."""
     assert L.dtype == torch.float64 and ny % comm.world == 0, "slab CG: fp64, ny divisible by the number of ranks"
     j0, j1 = slab_rows(comm.rank, comm.world, ny)
     nyl = j1 - j0
     off = j0 * nx
     L_loc = L[off * 5:(off + nyl * nx) * 5].contiguous()
     d_loc = div.reshape(-1).to(torch.float64)[off:off + nyl * nx].contiguous()
+    return cg_solve_slab_local(comm, nx, nyl, per_x, per_y, L_loc, d_loc, accuracy, max_iterations, rank_deficient, residual_reset, gather)
+
+
+def cg_solve_slab_local(comm, nx, nyl, per_x, per_y, L_loc, d_loc, accuracy, max_iterations, rank_deficient, residual_reset,
+                        gather=False):
+    """The same with this rank's slab only: L_loc [nyl*nx*5], d_loc [nyl*nx] (nothing is replicated)."""
     x_loc = torch.empty_like(d_loc)
-    x_all = torch.empty(ny * nx, dtype=torch.float64, device=d_loc.device)
+    rccl_gather = gather and comm.transport == "rccl"
+    x_all = torch.empty(nyl * comm.world * nx, dtype=torch.float64, device=d_loc.device) if gather else None
     ws = N.workspace(N.lib.piso_cg_slab_workspace_bytes(nx, nyl, 1), d_loc.device, "cg_slab")
     it = C.c_int(0)
     st = N.lib.piso_cg_solve_slab_f64(comm.handle, nx, nyl, int(per_x), int(per_y), N.ptr(L_loc), N.ptr(d_loc), N.ptr(x_loc),
-                                      N.ptr(x_all), C.c_float(accuracy), int(max_iterations), int(bool(rank_deficient)),
-                                      int(residual_reset), C.byref(it), N.ptr(ws), C.c_size_t(ws.numel()), N.stream_ptr())
+                                      N.ptr(x_all) if rccl_gather else None, C.c_float(accuracy), int(max_iterations),
+                                      int(bool(rank_deficient)), int(residual_reset), C.byref(it), N.ptr(ws), C.c_size_t(ws.numel()),
+                                      N.stream_ptr())
     N.check(st, "piso_cg_solve_slab_f64")
+    if not gather:
+        return x_loc, it.value
+    if not rccl_gather:
+        if comm.world == 1:
+            x_all.copy_(x_loc)
+        else:
+            import torch.distributed as dist
+            dev = _comm_device(d_loc.device)
+            parts = [torch.empty(nyl * nx, dtype=torch.float64, device=dev) for _ in range(comm.world)]
+            dist.all_gather(parts, x_loc.to(dev))
+            x_all = torch.cat(parts).to(d_loc.device)
     return x_all, it.value
 
 

@@ -204,15 +204,33 @@ int piso_conv2d_wgrad(const float* in, const float* grad_out, float* dw, int H, 
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Slab-decomposed pressure CG (no counterpart in the reference, which is single-GPU).
- * The grid is cut along y into `world` slabs of ny_local rows, one rank per GPU.  Per iteration: K1, a 3-double all-reduce,
- * K2, a 3-double all-reduce and a one-row halo exchange of the residual -- all stream-ordered RCCL calls, no host sync.
- * The communicator wraps an RCCL communicator (librccl is dlopen'ed on first use); the 128-byte unique id is created on one
- * rank and distributed by the caller (e.g. torch.distributed broadcast).
+ * The grid is cut along y into `world` slabs of ny_local rows, one rank (process) per GPU.  Two transports:
+ *
+ *  PEER (piso_comm_peer_create / _connect; the GPUs of one node, world <= 8): every rank owns a peer-mapped MAILBOX (uncached
+ *  device memory exported with hipIpcGetMemHandle and mapped by all ranks).  Step 1 creates the mailbox and returns its 64-byte
+ *  handle; the caller distributes the handles of all ranks by any means (torch.distributed all_gather, MPI, a pipe); step 2 maps
+ *  them.  Reductions and halo rows are written by kernels straight into the consumers' mailboxes (tagged words / release-acquire
+ *  at system scope), never through the host.  The NORMAL iterations run inside the persistent kernel: the slab's r, p, x stay on
+ *  chip, the z' rows at the slab edges and the per-GPU totals cross xGMI from inside the kernel, one extra hop per iteration;
+ *  resets, the first iteration and slab shapes the kernel cannot tile (row length not a multiple of 128, ...) run the two-kernel
+ *  iteration with mailbox collectives between the kernels.  A wait on a peer that gives up (peer gone) fails the call, it never
+ *  hangs; a failed persistent segment makes ALL ranks restart the solve on the two-kernel iteration (piso_comm_stats counts it).
+ *  row_capacity = longest grid row (cells) the communicator will carry.  x_out_global must be NULL (gather the slabs yourself).
+ *
+ *  RCCL (piso_comm_unique_id / piso_comm_create): per iteration K1, a 3-double all-reduce, K2, a 3-double all-reduce and a
+ *  one-row halo exchange of the residual -- stream-ordered RCCL calls, no host sync, two-kernel iteration only.  librccl is
+ *  dlopen'ed on first use; the 128-byte unique id is created on one rank and distributed by the caller.
+ *
  *   laplace_local [ny_local*nx][5], divergence_local / x_out_local [ny_local*nx]: this rank's rows;
- *   x_out_global  [world*ny_local*nx] or NULL: if given, every rank receives the full solution (all-gather).
- * piso_cg_solve_slab_emulated_f64 runs `slabs` virtual ranks on ONE device in lock-step with an in-process loopback
- * instead of RCCL: same kernels, same halo / partial-sum logic; it exists to test the multi-rank index logic on one GPU.
+ *   x_out_global  [world*ny_local*nx] or NULL (RCCL transport): every rank receives the full solution (all-gather).
+ * piso_cg_solve_slab_emulated_f64 runs `slabs` virtual ranks on ONE device in lock-step with an in-process loopback: same
+ * kernels, same halo / partial-sum logic; it exists to test the multi-rank index logic of the two-kernel iteration on one GPU.
+ * piso_comm_stats: out4 = {transport (1 RCCL, 2 peer), CG iterations executed inside persistent slab segments, solves restarted
+ * on the two-kernel iteration, persistent launches}.
  * ------------------------------------------------------------------------------------------------------------- */
+int piso_comm_peer_create(int rank, int world, int row_capacity, void** comm_out, void* ipc_handle64_out);
+int piso_comm_peer_connect(void* comm, const void* ipc_handles64_all_ranks);
+int piso_comm_stats(void* comm, long long* out4);
 int piso_comm_unique_id(void* id128);
 int piso_comm_create(const void* id128, int rank, int world, void** comm_out);
 int piso_comm_destroy(void* comm);

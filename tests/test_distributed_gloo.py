@@ -19,7 +19,9 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from diffpiso.distributed import exchange_unique_id, max_over_ranks, slab_rows
+        from diffpiso.distributed import all_gather_bytes, exchange_unique_id, max_over_ranks, slab_rows
+        handles = all_gather_bytes(bytes([17 * (rank + 1)] * 64), rank, world, torch.device("cpu"))   # mailbox handles (peer transport)
+        assert handles == bytes([17] * 64) + bytes([34] * 64), handles
         uid = exchange_unique_id(rank, world, torch.device("cpu"),
                                  make_id=lambda: torch.arange(128, dtype=torch.uint8) * 3 + 1)
         rows = slab_rows(rank, world, 64)

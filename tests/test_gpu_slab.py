@@ -57,7 +57,7 @@ def test_rccl_path_with_one_rank():
     from diffpiso.solvers import cg_solve_native
     ny, nx = 64, 48
     s, L, b = _laplace_case("periodic", ny, nx, seed=3)
-    comm = SlabCommunicator(rank=0, world=1)
+    comm = SlabCommunicator(rank=0, world=1, transport="rccl")
     try:
         Ld, bd = dev(L), dev(b)
         x1, it1 = cg_solve_native(nx, ny, True, True, Ld, bd, 1e-9, 3000, False, 1000)
@@ -92,3 +92,35 @@ def test_emulated_slabs_1024(slabs, walls):
     assert ita < 20000 and itb < 20000 and abs(ita - itb) <= max(10, 0.1 * ita), (ita, itb)
     # both stop at max|r| < 1e-7: the iterates agree to (tolerance / smallest eigenvalue)
     assert float((xa - xb).abs().max() / xa.abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("n,walls", [(1024, False), (1024, True), (2048, False), (2048, True)])
+def test_peer_transport_one_rank_persistent_slab_kernel(n, walls, piso_option):
+    """The slab variant of the persistent kernel with ONE rank: with periodic y its lower and upper neighbour are itself, so the
+    edge rows of z' travel through its own mailbox and the second exchange level sums one record - every slab-specific code path
+    of the kernel runs, and the iterates must agree with the single-GPU solver to round-off (the two-kernel iterations around the
+    segments group their partial sums differently).  Walls: no neighbours, the ring copies beyond the edges stay zero."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from diag_persist1 import case
+    from diffpiso.distributed import SlabCommunicator, cg_solve_slab
+    from diffpiso.solvers import cg_solve_native
+    L, b = case(n, n, walls=walls)
+    per = not walls
+    comm = SlabCommunicator(rank=0, world=1, transport="peer", row_capacity=n)
+    try:
+        piso_option("cg_segment", 40)
+        for nit in (1, 2, 7, 45, 150):
+            xa, _ = cg_solve_native(n, n, per, per, L, b, 1e-30, nit, False, 1000)
+            xb, itb = cg_solve_slab(comm, n, n, per, per, L, b, 1e-30, nit, False, 1000)
+            assert itb == nit
+            assert float((xa - xb).abs().max() / xa.abs().max()) <= 2e-10, nit
+        tol = 1e-7 if n <= 1024 else 1e-6
+        xa, ita = cg_solve_native(n, n, per, per, L, b, tol, 20000, False, 1000)
+        xb, itb = cg_solve_slab(comm, n, n, per, per, L, b, tol, 20000, False, 1000)
+        assert (ita == itb == 20000) or (ita < 20000 and itb < 20000 and abs(ita - itb) <= max(10, 0.1 * ita)), (ita, itb)
+        assert float((xa - xb).abs().max() / xa.abs().max()) <= 1e-3
+        st = comm.stats()
+        assert st["persistent_iterations"] > 150 and st["persistent_fallbacks"] == 0, st
+    finally:
+        comm.close()
