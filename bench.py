@@ -10,7 +10,11 @@ CFL 0.5, p0 = 0) and resident in HBM before the clock starts.  Solver settings a
 tolerance 1e-6, max_iterations 10000, CG residual_reset 1000, pressure solve fp64, advection solve fp32.
 
 Multi-GPU: "replicas" (default) -- every rank runs the same independent 2048^2 problem, no data-path collective; value =
-N * K / max-over-ranks time, scaling "weak".  `--decomp slab` cuts the pressure CG of ONE grid into y-slabs (RCCL).
+N * K / max-over-ranks time, scaling "weak".  After the timed region every N > 1 run exercises the slab-decomposed pressure CG
+on the real node (peer-mapped mailboxes over xGMI, persistent slab kernel, RCCL transport) and reports it INSIDE the JSON line
+(`slab_cg_self_check`: strong- and weak-scaled us per iteration, agreement with single-GPU solves); a failed or hung check
+makes the run exit non-zero.  `--decomp slab` runs the whole bench on ONE grid with the CG cut into y-slabs and the rest of
+the step replicated (strong scaling: DESIGN.md 6 explains why that cannot beat the on-chip single-GPU kernel at 2048^2).
 
 One JSON line on stdout (rank 0) with, besides the contract's keys:
   roofline      the dominant kernel (persistent pressure CG), HIP-event timed inside the timed region.  `achieved` counts the
@@ -254,36 +258,109 @@ def measured_traffic(n, kernel):
         return None, "no PMC record (%s)" % type(ex).__name__
 
 
-def slab_self_check(n, device, rank, world, iters=300):
-    """N > 1 only, AFTER the timed region: the slab-decomposed CG (RCCL all-reduce + halo exchange) on one
-    2048^2 pressure system cut into `world` slabs, against the single-GPU solve of the same system on every rank."""
+def slab_self_check(n, device, rank, world, iters=300, share_gpu=False):
+    """N > 1 only, AFTER the timed region, not part of the metric: the slab-decomposed pressure CG on the real
+    node, result inside the JSON line.  Three legs, every one compared with a single-GPU solve computed on the same rank:
+      strong   one n x n system cut into `world` y-slabs: two-kernel iteration with mailbox collectives, then the persistent slab
+               kernel (edge rows and per-GPU totals cross xGMI from inside the kernel);
+      weak     every rank owns an n x n slab of an n x (n * world) grid (the regime the persistent kernel is built for: the state
+               of a 2048^2 slab fills one GPU's registers and LDS) -- us per iteration against the single-GPU n x n figure is the
+               parallel efficiency of the kernel that is 95 % of a step;
+      rccl     the same strong system through the library's RCCL communicator (two-kernel iteration)."""
     import torch
-    from diffpiso.distributed import SlabCommunicator, cg_solve_slab
+    import diffpiso._native as N
+    from diffpiso.distributed import SlabCommunicator, cg_solve_slab, cg_solve_slab_local, slab_rows
     from diffpiso.solvers import cg_solve_native, laplace_matrix_native
-    g = torch.Generator(device="cpu")
-    g.manual_seed(1234)
-    a0 = (0.5 + torch.rand(n * (n + 1) + (n + 1) * n, generator=g)).to(device)
-    ones = torch.ones((n + 2) * (n + 2), device=device)
-    L = laplace_matrix_native(n, n, ones, ones, a0, torch.float64)
-    b = torch.randn(n * n, generator=g, dtype=torch.float64).to(device)
-    b -= b.mean()
-    comm = SlabCommunicator(rank=rank, world=world, device=device)
-    out = {}
+
+    def system(nx, ny, seed):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        a0 = 0.5 + torch.rand(nx * (ny + 1) + (nx + 1) * ny, generator=g)
+        av = a0[:nx * (ny + 1)].view(ny + 1, nx)
+        au = a0[nx * (ny + 1):].view(ny, nx + 1)
+        av[ny] = av[0]
+        au[:, nx] = au[:, 0]                                  # periodic duplicates of the face fields: a symmetric matrix
+        ones = torch.ones((ny + 2) * (nx + 2), device=device)
+        return laplace_matrix_native(nx, ny, ones, ones, a0.to(device), torch.float64)
+
+    def rhs(nx, ny, seed):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed)
+        b = torch.randn(nx * ny, generator=g, dtype=torch.float64)
+        return b - b.mean()
+
+    check_iters = 100     # agreement is judged here: CG amplifies round-off (different summation grouping) exponentially with the
+                          # iteration count -- 1e-13 after 100 iterations, 1e-5 after 300 on the same systems, on ANY two orderings
+
+    def timed(fn):
+        x, _ = fn(check_iters)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(iters)
+        torch.cuda.synchronize()
+        return x, 1e6 * (time.perf_counter() - t0) / iters
+
+    out = {"ranks": world, "iterations_timed": iters, "iterations_compared": 100, "grid": [n, n], "transport": "peer mailboxes (hipIpc handles, xGMI peer access)"}
+    comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=n)
+    saved = {k: N.get_option(k) for k in ("cg_persist", "cg_persist_r")}
     try:
-        # un-shifted operator: with the rank-1 shift CG trajectories are not reproducible between summation orders
-        for name, fn in (("single", lambda: cg_solve_native(n, n, True, True, L, b, 1e-30, iters, False, 1000)),
-                         ("slab", lambda: cg_solve_slab(comm, n, n, True, True, L, b, 1e-30, iters, False, 1000))):
-            fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            x, it = fn()
-            torch.cuda.synchronize()
-            out[name] = (x, (time.perf_counter() - t0) / iters)
-        diff = float((out["slab"][0] - out["single"][0]).abs().max() / out["single"][0].abs().max())
-        return {"ok": bool(diff < 1e-8), "max_rel_diff_vs_single_gpu": diff, "iterations": iters,
-                "us_per_iteration_single_gpu": 1e6 * out["single"][1], "us_per_iteration_slab": 1e6 * out["slab"][1],
-                "ranks": world}
+        if share_gpu:                       # test mode, all ranks on one GPU: their persistent kernels must fit side by side
+            N.set_option("cg_persist_r", 16)
+        # ---- strong: un-shifted operator (with the rank-1 shift CG trajectories are not reproducible between summation orders)
+        L, b = system(n, n, 1234), rhs(n, n, 99).to(device)
+        j0, j1 = slab_rows(rank, world, n)
+        own = slice(j0 * n, j1 * n)
+        N.set_option("cg_persist", 0 if share_gpu else saved["cg_persist"])
+        xs, t_single = timed(lambda k: cg_solve_native(n, n, True, True, L, b, 1e-30, k, False, 1 << 30))
+        N.set_option("cg_persist", 0)
+        x2, t_two = timed(lambda k: cg_solve_slab(comm, n, n, True, True, L, b, 1e-30, k, False, 1 << 30, gather=False))
+        N.set_option("cg_persist", saved["cg_persist"])
+        before = comm.stats()
+        xp, t_pers = timed(lambda k: cg_solve_slab(comm, n, n, True, True, L, b, 1e-30, k, False, 1 << 30, gather=False))
+        after = comm.stats()
+        scale = float(xs.abs().max())
+        d_two = float((x2 - xs[own]).abs().max()) / scale
+        d_pers = float((xp - xs[own]).abs().max()) / scale
+        out["strong"] = {"us_per_iteration_single_gpu": t_single, "us_per_iteration_slab_two_kernel": t_two,
+                         "us_per_iteration_slab_persistent": t_pers, "max_rel_diff_two_kernel": d_two, "max_rel_diff_persistent": d_pers,
+                         "persistent_iterations": after["persistent_iterations"] - before["persistent_iterations"],
+                         "persistent_fallbacks": after["persistent_fallbacks"]}
+        ok = d_two < 1e-8 and d_pers < 1e-8
+        del x2, xp
+        # ---- weak: n x n per rank; the tiles share one coefficient field, the right-hand sides differ
+        L_tile = L
+        b_all = [rhs(n, n, 1000 + r) for r in range(world)]
+        b_mean = sum(float(v.sum()) for v in b_all) / (world * n * n)
+        b_loc = (b_all[rank] - b_mean).to(device)
+        xw, t_weak = timed(lambda k: cg_solve_slab_local(comm, n, n, True, True, L_tile, b_loc, 1e-30, k, False, 1 << 30))
+        weak = {"cells_per_gpu": n * n, "us_per_iteration_slab_persistent": t_weak,
+                "parallel_efficiency_vs_single_gpu_iteration": t_single / t_weak if not share_gpu else None}
+        if world * n * n <= 8 * 2048 * 2048:   # the tall grid on ONE GPU (two-kernel iteration; its state does not fit on chip)
+            L_tall = L_tile.reshape(n * n, 5).repeat(world, 1).reshape(-1).contiguous()
+            b_tall = (torch.cat(b_all) - b_mean).to(device)
+            N.set_option("cg_persist", 0)
+            xt, _ = cg_solve_native(n, n * world, True, True, L_tall, b_tall, 1e-30, check_iters, False, 1 << 30)
+            N.set_option("cg_persist", saved["cg_persist"])
+            weak["max_rel_diff_vs_single_gpu_tall_grid"] = float((xw - xt[rank * n * n:(rank + 1) * n * n]).abs().max()) / float(xt.abs().max())
+            ok = ok and weak["max_rel_diff_vs_single_gpu_tall_grid"] < 1e-8
+            del L_tall, b_tall, xt
+        out["weak"] = weak
+        out["persistent_fallbacks"] = comm.stats()["persistent_fallbacks"]
+        # ---- the RCCL transport on the same strong system (needs one GPU per rank)
+        if not share_gpu:
+            rc = SlabCommunicator(rank=rank, world=world, device=device, transport="rccl")
+            try:
+                xr, t_rccl = timed(lambda k: cg_solve_slab(rc, n, n, True, True, L, b, 1e-30, k, False, 1 << 30, gather=False))
+                d_rccl = float((xr - xs[own]).abs().max()) / scale
+                out["rccl"] = {"us_per_iteration_slab_two_kernel": t_rccl, "max_rel_diff": d_rccl}
+                ok = ok and d_rccl < 1e-8
+            finally:
+                rc.close()
+        out["ok"] = bool(ok)
+        return out
     finally:
+        for k, v in saved.items():
+            N.set_option(k, v)
         comm.close()
 
 
@@ -300,7 +377,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the bicgstab / other_configs legs (profiling runs)")
     ap.add_argument("--decomp", choices=["replicas", "slab"], default=os.environ.get("PISO_BENCH_DECOMP", "replicas"),
                     help="N > 1: 'replicas' = one independent grid per GPU (weak); 'slab' = ONE grid, pressure CG cut into "
-                         "y-slabs over the GPUs with RCCL all-reduce + halo exchange, rest of the step replicated (strong)")
+                         "y-slabs over the GPUs (peer-mapped mailboxes, persistent slab kernel), rest of the step replicated (strong)")
     args = ap.parse_args()
 
     import torch
@@ -310,11 +387,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the PISO path has no CPU fallback (libpiso_hip.so is the product)")
+    # PISO_BENCH_SHARE_GPU=1 (test mode for a one-GPU box): every rank uses cuda:0 and torch.distributed runs on gloo -- RCCL
+    # refuses two ranks on one device; the library's peer transport does not care.  Timings of that mode mean nothing.
+    share_gpu = world > 1 and os.environ.get("PISO_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend="gloo" if share_gpu else "nccl")
 
     import diffpiso._native as N
     n = args.grid
@@ -322,7 +404,7 @@ def main():
     slab = world > 1 and args.decomp == "slab"
     if slab:
         from diffpiso.distributed import SlabCommunicator
-        P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device)
+        P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=n)
 
     def barrier():
         torch.cuda.synchronize()
@@ -330,6 +412,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if share_gpu:
+        N.set_option("cg_persist", 0)      # (two replicas' persistent kernels do not fit one GPU side by side)
     for _ in range(args.warmup):
         run_unrolled(P, 1)
     for s_ in (P["ps"].stats, P["lin"].stats):
@@ -457,22 +541,31 @@ def main():
 
         def give_up():
             if rank == 0 and out is not None:
-                out["slab_cg_self_check"] = {"ok": False, "error": "timed out after 180 s"}
+                out["slab_cg_self_check"] = {"ok": False, "error": "timed out after 240 s"}
                 print(json.dumps(out), flush=True)
             sys.stderr.write("slab_cg_self_check timed out\n")
             sys.stderr.flush()
             os._exit(3)
-        timer = threading.Timer(180.0, give_up)
+        timer = threading.Timer(240.0, give_up)
         timer.daemon = True
         timer.start()
         try:
-            chk = slab_self_check(n, device, rank, world)
+            if share_gpu:
+                N.set_option("cg_persist", -1)
+            chk = slab_self_check(n, device, rank, world, share_gpu=share_gpu)
         except Exception as e:
             chk = {"ok": False, "error": repr(e)}
+        try:       # rank 0 reports for everybody
+            okt = torch.tensor([1.0 if chk.get("ok") else 0.0], device="cpu" if share_gpu else device)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            chk["ok_all_ranks"] = bool(okt.item() > 0)
+        except Exception as e:
+            chk["ok_all_ranks"] = False
+            chk["all_ranks_error"] = repr(e)
         timer.cancel()
         if rank == 0:
             out["slab_cg_self_check"] = chk
-        if not chk.get("ok"):
+        if not (chk.get("ok") and chk.get("ok_all_ranks")):
             rc = 3
     if rank == 0:
         print(json.dumps(out), flush=True)

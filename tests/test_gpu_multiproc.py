@@ -55,3 +55,28 @@ def test_slab_cg_over_processes(world, nx, ny, walls):
         assert r["stats"]["persistent_iterations"] > 150 and r["stats"]["persistent_fallbacks"] == 0, r["stats"]
     # every rank took the same decisions
     assert len({tuple(r["persistent"]["converged_its"]) for r in res}) == 1
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path end to end (torch.distributed.run, max-over-ranks timing, the slab self-check inside the JSON line)
+    with two ranks sharing the box's one GPU (PISO_BENCH_SHARE_GPU=1: gloo instead of RCCL for torch.distributed, the library's
+    peer transport for the solver).  The timings of this mode mean nothing; the agreement figures do."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PISO_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "1024",
+           "--max-iterations", "300"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and lines, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    chk = d["slab_cg_self_check"]
+    print(chk)
+    assert chk["ok"] and chk["ok_all_ranks"], chk
+    assert chk["strong"]["max_rel_diff_persistent"] < 1e-9 and chk["strong"]["max_rel_diff_two_kernel"] < 1e-9
+    assert chk["weak"]["max_rel_diff_vs_single_gpu_tall_grid"] < 1e-9
+    assert chk["strong"]["persistent_iterations"] > 0 and chk["persistent_fallbacks"] == 0
