@@ -20,6 +20,7 @@
 // The iteration itself (order of updates, absolute ||r||_2 test after each half step, zero + one restart on failure,
 // NaN -> warning) is the reference's.
 #include "piso_common.h"
+#include "slab_comm.h"
 
 namespace piso {
 
@@ -74,6 +75,17 @@ struct BiArgs {
   int* flags;                     // [0]: unsupported pattern, [1]: NaN seen
   float tol;
   int nparts;                     // blocks per component that write partial records (<= kBiParts; the rest stays zero)
+  // slab decomposition (one GPU: everything): the rows [rb, re) and the bands [bb, be) of each component this rank works on.
+  // All arrays stay globally indexed; rows outside the range are never written (the SpMV inputs receive their neighbours' edge
+  // rows before every product), so slabs cut at band edges reproduce the single-GPU preconditioner exactly.
+  int rb[2], re[2], bb[2], be[2];
+};
+// cross-rank part of a scalar kernel (peer transport): the two component blocks add their four partial sums over the ranks
+struct BiPeer {
+  PeerView pv;
+  unsigned seq;
+  int* err;
+  int on;
 };
 
 __device__ __forceinline__ bool is_nan(float v) { return v != v; }
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
   const T* val = val_all + k0;
   const int* col = col_all + k0;
   bool nan_seen = false, bad = false;
-  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
     const int i = row % W, j = row / W;
     const int fo = frame_ordinal(i, j, W, H);
     T s = 0, w = 0, cc = 0, e = 0, nn = 0;
@@ -227,9 +239,10 @@ __global__ __launch_bounds__(kBlock) void bi_factor(BiArgs<T> a) {
   __shared__ Moebius<T> smem[4];
   const int c = blockIdx.y;
   const Geo& g = a.g;
-  if (blockIdx.x >= g.nb[c]) return;
+  const int band = a.bb[c] + blockIdx.x;
+  if (band >= a.be[c]) return;
   const int W = g.W[c], H = g.H[c], r0 = g.r0[c];
-  const int j0 = blockIdx.x * g.R, j1 = min(j0 + g.R, H);
+  const int j0 = band * g.R, j1 = min(j0 + g.R, H);
   const int i0 = threadIdx.x * E;
   T d_prev_row[E];          // pivots of the previous row at my columns
   T cN_prev_row[E];
@@ -287,9 +300,10 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
   const int c = blockIdx.y;
   const Geo& g = a.g;
   if (a.sc[c].done) return;
-  if (blockIdx.x >= g.nb[c]) return;
+  const int band = a.bb[c] + blockIdx.x;
+  if (band >= a.be[c]) return;
   const int W = g.W[c], H = g.H[c], r0 = g.r0[c];
-  const int j0 = blockIdx.x * g.R, j1 = min(j0 + g.R, H);
+  const int j0 = band * g.R, j1 = min(j0 + g.R, H);
   const T* __restrict__ ca = FWD ? a.LW : a.UE;
   const T* __restrict__ cb = FWD ? a.LS : a.UN;
   // element order along the scan: forward i ascending, backward i descending
@@ -394,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void bi_residual_init(BiArgs<T> a) {
   if (a.sc[c].done) return;
   const int n = a.g.n[c], r0 = a.g.r0[c];
   T acc[1] = {0};
-  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
     const int k = r0 + row;
     const T r = a.rhs[k] - stencil_row(a, c, row, a.x);
     a.r[k] = r; a.rh[k] = r; a.p[k] = 0; a.v[k] = 0;
@@ -410,7 +424,7 @@ __global__ __launch_bounds__(kBlock) void bi_update_p(BiArgs<T> a) {
   const CompScalars<T> s = a.sc[c];
   if (s.done) return;
   const int n = a.g.n[c], r0 = a.g.r0[c];
-  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
     const int k = r0 + row;
     a.p[k] = (a.p[k] - s.omega * a.v[k]) * s.beta + a.r[k];
   }
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void bi_spmv(BiArgs<T> a, const T* __restri
   if (a.sc[c].done) return;
   const int n = a.g.n[c], r0 = a.g.r0[c];
   T acc[2] = {0, 0};
-  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
     const int k = r0 + row;
     const T o = stencil_row(a, c, row, in);
     out[k] = o;
@@ -446,7 +460,7 @@ __global__ __launch_bounds__(kBlock) void bi_update_xr(BiArgs<T> a) {
   const T* __restrict__ dir = WHICH == 0 ? a.ph : a.sh;
   const T* __restrict__ w = WHICH == 0 ? a.v : a.t;
   T acc[2] = {0, 0};
-  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
     const int k = r0 + row;
     a.x[k] = a.x[k] + coef * dir[k];
     const T r = a.r[k] - coef * w[k];
@@ -462,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void bi_zero_x(BiArgs<T> a, int comp_mask) 
   const int c = blockIdx.y;
   if (!((comp_mask >> c) & 1)) return;
   const int n = a.g.n[c], r0 = a.g.r0[c];
-  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) a.x[r0 + row] = 0;
+  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) a.x[r0 + row] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -478,17 +492,27 @@ template <>
 __device__ __forceinline__ double sqrt_t<double>(double v) { return sqrt(v); }
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void bi_scalar(BiArgs<T> a, int stage) {
+__global__ __launch_bounds__(kBlock) void bi_scalar(BiArgs<T> a, int stage, BiPeer bp) {
   __shared__ T smem[16];
   const int c = blockIdx.x;
   CompScalars<T> s = a.sc[c];
-  if (s.done) return;
+  if (s.done) return;             // (the same decision on every rank: `done` follows from all-reduced sums)
   T q[4] = {0, 0, 0, 0};
   for (int b = threadIdx.x; b < a.nparts; b += kBlock) {       // (four independent loads in flight per pass)
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] += a.parts[(c * 4 + k) * kBiParts + b];
   }
   block_sum<T, 4>(q, smem);
+  if (bp.on && threadIdx.x < 64) {
+    // the distributed dot products: component c's four sums travel in words [8 c, 8 c + 8) of the all-reduce records
+    const int lane = threadIdx.x;
+    const int vq = (lane >> 1) & 3;
+    bool good = true;
+    const double acc = peer_wave_sum(bp.pv, (double)(vq == 0 ? q[0] : (vq == 1 ? q[1] : (vq == 2 ? q[2] : q[3]))), 8, 8 * c, bp.seq, &good);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = (T)__shfl(acc, 2 * k, 64);
+    if (!good && lane == 0) *bp.err = 1;
+  }
   if (threadIdx.x != 0) return;
   const T tol = (T)a.tol;
   switch (stage) {
@@ -533,6 +557,16 @@ __global__ void bi_init_scalars(BiArgs<T> a) {
   }
   for (int i = threadIdx.x; i < 2 * 4 * kBiParts; i += blockDim.x) a.parts[i] = 0;
   if (threadIdx.x == 0) { a.flags[0] = 0; a.flags[1] = 0; }
+}
+
+// slab mode: "unsupported pattern" / "NaN seen" of ANY rank's rows count for every rank
+template <typename T>
+__global__ void bi_flags_allreduce(BiArgs<T> a, BiPeer bp) {
+  const int lane = threadIdx.x;
+  bool good = true;
+  const double acc = peer_wave_sum(bp.pv, lane < 4 ? (double)a.flags[lane >> 1] : 0.0, 4, 0, bp.seq, &good);
+  if (lane < 4 && (lane & 1) == 0) a.flags[lane >> 1] = acc > 0 ? 1 : 0;
+  if (!good && lane == 0) *bp.err = 1;
 }
 
 template <typename T>
@@ -590,10 +624,12 @@ static void launch_sweeps(const BiArgs<T>& a, dim3 gb, const T* in, T* out, hipS
   bi_sweep<T, E, false><<<gb, kBlock, 0, s>>>(a, a.y, out);
 }
 
+// pc = NULL: one GPU.  Else (peer transport): this rank works on the face rows of its y-slab of cell rows; val / rowptr / col /
+// rhs / x0 are the FULL arrays on every rank (the caller's assembly is replicated), x_out is valid on the owned rows only.
 template <typename T>
 static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rhs, const T* x0, T* x_out, int nx,
                     int ny, float tol, int max_it, int transpose, int band_rows, uint8_t* warning,
-                    int* iterations_out, void* ws, size_t ws_bytes, piso_stream_t stream_) {
+                    int* iterations_out, void* ws, size_t ws_bytes, piso_stream_t stream_, PisoComm* pc = nullptr) {
   if (nx < 4 || ny < 4 || !val || !rowptr || !col || !rhs || !x0 || !x_out || !ws || max_it < 0) {
     set_error_msg("piso_multi_bicgstab_ilu: invalid argument (need nx, ny >= 4 and non-NULL arrays)");
     return PISO_ERR_INVALID_ARG;
@@ -620,13 +656,53 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   a.rhs = rhs; a.x = x_out; a.tol = tol;
   if (!ar.ok()) { set_error_msg("piso_multi_bicgstab_ilu: workspace too small"); return PISO_ERR_INVALID_ARG; }
 
-  const int nmax = g.n[0] > g.n[1] ? g.n[0] : g.n[1];
+  for (int c = 0; c < 2; ++c) { a.rb[c] = 0; a.re[c] = g.n[c]; a.bb[c] = 0; a.be[c] = g.nb[c]; }
+  BiPeer bp;
+  bp.on = 0; bp.seq = 0; bp.err = nullptr;
+  HaloMsg to_upper = {}, to_lower = {}, from_lower = {}, from_upper = {};
+  const bool slab = pc && pc->world > 1;
+  if (pc) {
+    if (pc->transport != TRANSPORT_PEER || !pc->connected) { set_error_msg("piso_multi_bicgstab_ilu_slab: needs a connected peer communicator"); return PISO_ERR_INVALID_ARG; }
+    const int world = pc->world, rank = pc->rank;
+    if (ny % world != 0 || (ny / world) % g.R != 0 || ny / world < 2) {
+      set_error_msg("piso_multi_bicgstab_ilu_slab: the slabs (ny / ranks cell rows) must be whole preconditioner bands");
+      return PISO_ERR_INVALID_ARG;
+    }
+    if ((size_t)(3 * nx + 1) > pc->row_cap) { set_error_msg("piso_multi_bicgstab_ilu_slab: communicator row_capacity < 3 nx + 1"); return PISO_ERR_INVALID_ARG; }
+    const int nyl = ny / world, jb = rank * nyl, jt = jb + nyl - 1;
+    const bool last = rank == world - 1;
+    a.rb[0] = jb * g.W[0]; a.re[0] = (jb + nyl) * g.W[0];
+    a.rb[1] = jb * g.W[1]; a.re[1] = (jb + nyl + (last ? 1 : 0)) * g.W[1];      // (the duplicate face row v[ny] lives on the last slab)
+    a.bb[0] = a.bb[1] = jb / g.R;
+    a.be[0] = (jb + nyl) / g.R;
+    a.be[1] = last ? g.nb[1] : (jb + nyl) / g.R;
+    bp.pv = make_view(pc, true);       // always a ring: without periodic y the wrap rows travel but no matrix entry reads them
+    bp.err = pc->err; bp.on = slab ? 1 : 0;
+    // Edge rows of an SpMV input; they land at the same global offsets on the receiver.  Downwards go u[jb], v[jb] and v[jb + 1],
+    // upwards u[jt], v[jt] - and, across the periodic seam, the duplicate row v[ny] as well: in A the row v[ny] reads v[1] and
+    // v[0] reads v[ny - 1] (the wrap skips the duplicate face, central_difference_csr_op.cu.cc:259-264), in A^T it is v[1] that
+    // reads v[ny] and v[ny - 1] that reads v[0].
+    const int lo = bp.pv.lower, up = bp.pv.upper;
+    const int jt_lo = lo * nyl + nyl - 1, jb_up = up * nyl;
+    to_lower = {2, {jb * g.W[0], g.n[0] + jb * g.W[1], 0}, {g.W[0], 2 * g.W[1], 0}};
+    to_upper = {2, {jt * g.W[0], g.n[0] + jt * g.W[1], 0}, {g.W[0], (last ? 2 : 1) * g.W[1], 0}};
+    from_lower = {2, {jt_lo * g.W[0], g.n[0] + jt_lo * g.W[1], 0}, {g.W[0], (lo == world - 1 ? 2 : 1) * g.W[1], 0}};
+    from_upper = {2, {jb_up * g.W[0], g.n[0] + jb_up * g.W[1], 0}, {g.W[0], 2 * g.W[1], 0}};
+  }
+  auto next_seq = [&]() -> BiPeer { BiPeer b = bp; if (slab) b.seq = ++pc->seq_ar; return b; };
+  auto halo = [&](T* vec) {
+    if (slab) peer_exchange_segments<T><<<2, 256, 0, stream>>>(bp.pv, vec, to_upper, to_lower, from_lower, from_upper, ++pc->seq_ex, pc->err);
+  };
+
+  const int own0 = a.re[0] - a.rb[0], own1 = a.re[1] - a.rb[1];
+  const int nmax = own0 > own1 ? own0 : own1;
   int gv = (nmax + kBlock * 4 - 1) / (kBlock * 4);
   if (gv > kBiParts) gv = kBiParts;
   if (gv < 1) gv = 1;
   const dim3 grid_v(gv, 2);
   a.nparts = gv;
-  const int nbmax = g.nb[0] > g.nb[1] ? g.nb[0] : g.nb[1];
+  const int nb0 = a.be[0] - a.bb[0], nb1 = a.be[1] - a.bb[1];
+  const int nbmax = nb0 > nb1 ? nb0 : nb1;
   const dim3 grid_b(nbmax, 2);
   const int Wmax = nx + 1;
   const int need = (Wmax + kBlock - 1) / kBlock;
@@ -634,6 +710,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
 
   bi_init_scalars<T><<<1, 256, 0, stream>>>(a);
   bi_convert<T><<<grid_v, kBlock, 0, stream>>>(a, val, rowptr, col, x0, transpose ? 1 : 0);
+  if (slab) bi_flags_allreduce<T><<<1, 64, 0, stream>>>(a, next_seq());
   if (need <= 1) launch_factor<T, 1>(a, grid_b, stream);
   else if (need <= 2) launch_factor<T, 2>(a, grid_b, stream);
   else if (need <= 3) launch_factor<T, 3>(a, grid_b, stream);             // (W = nx + 1 with nx a power of two: 2^k / 256 + 1)
@@ -669,26 +746,29 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   bool pattern_checked = false;
   for (int restart = 0; restart < 2; ++restart) {
     // r = b - B x, rh = r, p = v = 0, ||r|| test, first rho / beta
+    halo(a.x);
     bi_residual_init<T><<<grid_v, kBlock, 0, stream>>>(a);
-    bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_INIT);
+    bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_INIT, next_seq());
     PISO_LAUNCH_CHECK();
     int it = 0;
     bool all_done = false;
     while (it < max_it && !all_done) {
       const int chunk = (max_it - it) < 2 ? (max_it - it) : 2;          // iterations between host looks
       for (int q = 0; q < chunk; ++q, ++it) {
-        if (it > 0) bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_RHO_BETA);
+        if (it > 0) bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_RHO_BETA, next_seq());
         bi_update_p<T><<<grid_v, kBlock, 0, stream>>>(a);
         precond(a.p, a.ph);
+        halo(a.ph);
         bi_spmv<T, 0><<<grid_v, kBlock, 0, stream>>>(a, a.ph, a.v);
-        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_ALPHA);
+        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_ALPHA, next_seq());
         bi_update_xr<T, 0><<<grid_v, kBlock, 0, stream>>>(a);
-        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_CHECK_S);
+        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_CHECK_S, next_seq());
         precond(a.r, a.sh);
+        halo(a.sh);
         bi_spmv<T, 1><<<grid_v, kBlock, 0, stream>>>(a, a.sh, a.t);
-        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_OMEGA);
+        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_OMEGA, next_seq());
         bi_update_xr<T, 1><<<grid_v, kBlock, 0, stream>>>(a);
-        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_CHECK_R);
+        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_CHECK_R, next_seq());
       }
       PISO_LAUNCH_CHECK();
       { const int rc = fetch(); if (rc != PISO_OK) return rc; }
@@ -717,6 +797,16 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
     }
   }
   (void)failed_mask;
+  if (slab) {
+    int herr = 0;
+    PISO_HIP_CHECK(hipMemcpyAsync(&herr, pc->err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PISO_HIP_CHECK(hipStreamSynchronize(stream));
+    if (herr) {
+      PISO_HIP_CHECK(hipMemsetAsync(pc->err, 0, sizeof(int), stream));
+      set_error_msg("piso_multi_bicgstab_ilu_slab: a wait on a peer's mailbox gave up (peer process gone or not running?)");
+      return PISO_ERR_HIP;
+    }
+  }
   PISO_HIP_CHECK(hipStreamSynchronize(stream));
   if (host.flags[1] && warning) {
     const uint8_t one = 1;
@@ -782,6 +872,24 @@ int piso_multi_bicgstab_ilu_f64(const double* csr_val, const int* csr_rowptr, co
                                 size_t workspace_bytes, piso_stream_t stream) {
   return bi_solve<double>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning,
                           iterations_out, workspace, workspace_bytes, stream);
+}
+
+int piso_multi_bicgstab_ilu_slab_f32(void* comm, const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* rhs,
+                                     const float* x0, float* x_out, int nx, int ny, float tol, int max_it, int transpose,
+                                     int band_rows, uint8_t* warning, int* iterations_out, void* workspace, size_t workspace_bytes,
+                                     piso_stream_t stream) {
+  if (!comm) { set_error_msg("piso_multi_bicgstab_ilu_slab_f32: NULL communicator"); return PISO_ERR_INVALID_ARG; }
+  return bi_solve<float>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning, iterations_out,
+                         workspace, workspace_bytes, stream, static_cast<PisoComm*>(comm));
+}
+
+int piso_multi_bicgstab_ilu_slab_f64(void* comm, const double* csr_val, const int* csr_rowptr, const int* csr_col, const double* rhs,
+                                     const double* x0, double* x_out, int nx, int ny, float tol, int max_it, int transpose,
+                                     int band_rows, uint8_t* warning, int* iterations_out, void* workspace, size_t workspace_bytes,
+                                     piso_stream_t stream) {
+  if (!comm) { set_error_msg("piso_multi_bicgstab_ilu_slab_f64: NULL communicator"); return PISO_ERR_INVALID_ARG; }
+  return bi_solve<double>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning, iterations_out,
+                          workspace, workspace_bytes, stream, static_cast<PisoComm*>(comm));
 }
 
 int piso_csr_matvec_f32(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* x, float* y,

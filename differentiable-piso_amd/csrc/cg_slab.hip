@@ -28,6 +28,7 @@
 #include "cg_persist1.h"
 #include "options.h"
 #include "peer.h"
+#include "slab_comm.h"
 
 namespace piso {
 
@@ -74,31 +75,6 @@ static int load_rccl() {
       return PISO_ERR_HIP;                                                      \
     }                                                                           \
   } while (0)
-
-enum { TRANSPORT_RCCL = 1, TRANSPORT_PEER = 2 };
-struct PisoComm {
-  ncclComm_t comm = nullptr;
-  int rank = 0, world = 1;
-  int transport = TRANSPORT_RCCL;
-  // peer transport
-  char* mbox[kMaxRanks] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  bool connected = false;
-  size_t row_cap = 0, mbox_bytes = 0;
-  unsigned seq_ar = 0, seq_ex = 0;    // sequence numbers of the host-level collectives (advance identically on every rank)
-  unsigned launches = 0;              // persistent slab launches so far: the high half of their exchange tags
-  int* err = nullptr;                 // device flag: a wait on a peer gave up
-  int persist_fallbacks = 0;          // solves restarted on the two-kernel iteration after a persistent segment failed
-  long long persist_iterations = 0;   // CG iterations executed inside persistent slab segments
-};
-
-static PeerView make_view(const PisoComm* pc, bool periodic_y) {
-  PeerView v;
-  for (int r = 0; r < kMaxRanks; ++r) v.mbox[r] = pc->mbox[r];
-  v.rank = pc->rank; v.world = pc->world; v.row_cap = pc->row_cap;
-  v.lower = (pc->rank > 0) ? pc->rank - 1 : (periodic_y ? pc->world - 1 : -1);
-  v.upper = (pc->rank < pc->world - 1) ? pc->rank + 1 : (periodic_y ? 0 : -1);
-  return v;
-}
 
 // ------------------------------------------------------------------------------------------------ per-rank context
 template <typename T>
@@ -154,26 +130,9 @@ __global__ void slab_copy_rows(const T* __restrict__ src, T* __restrict__ dst, s
 // rank order: every rank obtains bitwise the same sums.
 __global__ void peer_allreduce(PeerView pv, double* g, int count, unsigned seq, int* err) {
   const int lane = threadIdx.x;
-  const bool active = lane < 2 * count;
-  const peer_u64 word = peer_tagged(active ? g[lane >> 1] : 0.0, lane & 1, seq);
-  if (active)
-    for (int p = 0; p < pv.world; ++p)
-      peer_store(reinterpret_cast<peer_u64*>(pv.mbox[p] + PeerLayout::ar_rec(seq & 1, pv.rank)) + lane, word);
-  double acc = 0;
   bool good = true;
-  for (int r = 0; r < pv.world; ++r) {
-    peer_u64 w = 0;
-    unsigned spins = 0;
-    while (true) {
-      if (active) w = peer_load(reinterpret_cast<const peer_u64*>(pv.mbox[pv.rank] + PeerLayout::ar_rec(seq & 1, r)) + lane);
-      if (__all(!active || (unsigned)(w & 0xffffffffull) == seq)) break;
-      if (++spins > kPeerSpinLimit) { good = false; break; }
-      __builtin_amdgcn_s_sleep(2);
-    }
-    const peer_u64 wo = __shfl_down(w, 1, 64);
-    acc += peer_untag(w, wo);
-  }
-  if (active && (lane & 1) == 0) g[lane >> 1] = acc;
+  const double acc = peer_wave_sum(pv, lane < 2 * count ? g[lane >> 1] : 0.0, 2 * count, 0, seq, &good);
+  if (lane < 2 * count && (lane & 1) == 0) g[lane >> 1] = acc;
   if (!good && lane == 0) *err = 1;
 }
 

@@ -55,4 +55,84 @@ __device__ __forceinline__ double peer_untag(peer_u64 lo_word, peer_u64 hi_word)
   return __longlong_as_double((long long)((lo_word >> 32) | (hi_word & 0xffffffff00000000ull)));
 }
 
+// One wave sums up to 8 values over the ranks through the all-reduce records of the mailboxes.  Lane l < nwords carries half
+// l & 1 of value l >> 1 (`v_lane` = that value) as a tagged word into words [word0, word0 + nwords) of every rank's record
+// (parity seq & 1, source = my rank), then polls the `world` records of its own mailbox and adds them in rank order: bitwise the
+// same sums on every rank.  Returns the sum of value l >> 1 in the EVEN lanes below nwords.
+__device__ __forceinline__ double peer_wave_sum(const PeerView& pv, double v_lane, int nwords, int word0, unsigned seq, bool* good) {
+  const int lane = threadIdx.x & 63;
+  const bool active = lane < nwords;
+  const peer_u64 word = peer_tagged(v_lane, lane & 1, seq);
+  if (active)
+    for (int p = 0; p < pv.world; ++p)
+      peer_store(reinterpret_cast<peer_u64*>(pv.mbox[p] + PeerLayout::ar_rec(seq & 1, pv.rank)) + word0 + lane, word);
+  double acc = 0;
+  for (int r = 0; r < pv.world; ++r) {
+    peer_u64 w = 0;
+    unsigned spins = 0;
+    while (true) {
+      if (active) w = peer_load(reinterpret_cast<const peer_u64*>(pv.mbox[pv.rank] + PeerLayout::ar_rec(seq & 1, r)) + word0 + lane);
+      if (__all(!active || (unsigned)(w & 0xffffffffull) == seq)) break;
+      if (++spins > kPeerSpinLimit) { *good = false; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const peer_u64 wo = __shfl_down(w, 1, 64);
+    acc += peer_untag(w, wo);
+  }
+  return acc;
+}
+
+// Segments of a globally indexed vector that cross a slab edge (element offsets into the vector; at most 3 segments per message)
+struct HaloMsg {
+  int count;
+  int off[3], len[3];
+};
+// Block 0 pushes `to_upper` into the upper neighbour's mailbox (side 0: what lies below ITS slab), block 1 `to_lower` into the
+// lower neighbour's (side 1); a system-scope release store of `seq` follows the data.  Then block 0 waits for the message from
+// below and stores it at `from_lower`'s offsets of my copy of the vector, block 1 the same for the message from above.  One
+// element travels as one 8-byte word.  Every rank pushes before it waits.
+template <typename T>
+__global__ __launch_bounds__(256) void peer_exchange_segments(PeerView pv, T* vec, HaloMsg to_upper, HaloMsg to_lower, HaloMsg from_lower,
+                                                              HaloMsg from_upper, unsigned seq, int* err) {
+  const int side = blockIdx.x;                             // out: 0 to the upper neighbour, 1 to the lower; in: 0 from below, 1 from above
+  const int dst = side == 0 ? pv.upper : pv.lower;
+  const int par = seq & 1;
+  if (dst >= 0) {
+    const HaloMsg& m = side == 0 ? to_upper : to_lower;
+    peer_u64* row = reinterpret_cast<peer_u64*>(pv.mbox[dst] + PeerLayout::ex_row(par, side, pv.row_cap));
+    int base = 0;
+    for (int q = 0; q < m.count; ++q) {
+      for (int i = threadIdx.x; i < m.len[q]; i += 256) peer_store(row + base + i, (peer_u64)__double_as_longlong((double)vec[m.off[q] + i]));
+      base += m.len[q];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(reinterpret_cast<peer_u64*>(pv.mbox[dst] + PeerLayout::ex_flag(par, side)), (peer_u64)seq, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const int from = side == 0 ? pv.lower : pv.upper;
+  if (from < 0) return;
+  __shared__ int ok_s;
+  if (threadIdx.x == 0) {
+    const peer_u64* flag = reinterpret_cast<const peer_u64*>(pv.mbox[pv.rank] + PeerLayout::ex_flag(par, side));
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != (peer_u64)seq) {
+      if (++spins > kPeerSpinLimit) { ok = 0; *err = 1; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    ok_s = ok;
+  }
+  __syncthreads();
+  if (!ok_s) return;
+  const HaloMsg& m = side == 0 ? from_lower : from_upper;
+  const peer_u64* row = reinterpret_cast<const peer_u64*>(pv.mbox[pv.rank] + PeerLayout::ex_row(par, side, pv.row_cap));
+  int base = 0;
+  for (int q = 0; q < m.count; ++q) {
+    for (int i = threadIdx.x; i < m.len[q]; i += 256) vec[m.off[q] + i] = (T)__longlong_as_double((long long)peer_load(row + base + i));
+    base += m.len[q];
+  }
+}
+
 }  // namespace piso

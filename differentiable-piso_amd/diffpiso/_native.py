@@ -55,6 +55,9 @@ lib.piso_bicgstab_workspace_bytes.restype = _sz
 for _n in ("piso_multi_bicgstab_ilu_f32", "piso_multi_bicgstab_ilu_f64"):
     getattr(lib, _n).argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _ip, _vp, _sz, _vp]
     getattr(lib, _n).restype = _i
+for _n in ("piso_multi_bicgstab_ilu_slab_f32", "piso_multi_bicgstab_ilu_slab_f64"):
+    getattr(lib, _n).argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _ip, _vp, _sz, _vp]
+    getattr(lib, _n).restype = _i
 lib.piso_csr_matvec_f32.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]
 lib.piso_csr_matvec_f32.restype = _i
 

@@ -168,3 +168,49 @@ def cg_solve_slab_emulated(slabs, nx, ny, per_x, per_y, L, div, accuracy, max_it
                                                N.stream_ptr())
     N.check(st, "piso_cg_solve_slab_emulated_f64")
     return x, it.value
+
+
+def face_rows_of_rank(rank, world, nx, ny):
+    """Element ranges of the flat u-first face vector [u (ny rows of nx + 1), v (ny + 1 rows of nx)] a rank owns: the face rows
+    of its cell rows; the duplicate row v[ny] lives on the last rank."""
+    j0, j1 = slab_rows(rank, world, ny)
+    n_u = (nx + 1) * ny
+    return (j0 * (nx + 1), j1 * (nx + 1)), (n_u + j0 * nx, n_u + (j1 + (1 if rank == world - 1 else 0)) * nx)
+
+
+def gather_face_rows(comm, x, nx, ny):
+    """Every rank holds valid values on its own face rows of `x`: fill in everybody else's (all-gather through torch.distributed)."""
+    import torch.distributed as dist
+    dev = _comm_device(x.device)
+    (u0, u1), (v0, v1) = face_rows_of_rank(comm.rank, comm.world, nx, ny)
+    per_u = (nx + 1) * (ny // comm.world)
+    per_v = nx * (ny // comm.world + 1)                      # (padded to the last rank's size)
+    mine = torch.zeros(per_u + per_v, dtype=x.dtype, device=dev)
+    mine[:u1 - u0] = x[u0:u1].to(dev)
+    mine[per_u:per_u + (v1 - v0)] = x[v0:v1].to(dev)
+    parts = [torch.empty_like(mine) for _ in range(comm.world)]
+    dist.all_gather(parts, mine)
+    out = x.clone()
+    for r, part in enumerate(parts):
+        (a0, a1), (b0, b1) = face_rows_of_rank(r, comm.world, nx, ny)
+        out[a0:a1] = part[:a1 - a0].to(x.device)
+        out[b0:b1] = part[per_u:per_u + (b1 - b0)].to(x.device)
+    return out
+
+
+def multi_bicgstab_ilu_slab(comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn, gather=True):
+    """piso_multi_bicgstab_ilu_slab_{f32,f64}: all arrays are the FULL ones on every rank; the rank solves its slab."""
+    dt = values.dtype
+    assert dt in (torch.float32, torch.float64) and comm.transport == "peer"
+    values, rhs, x0 = values.contiguous(), rhs.to(dt).contiguous(), x0.to(dt).contiguous()
+    row_ptr, col_indices = row_ptr.contiguous(), col_indices.contiguous()
+    x = torch.zeros_like(rhs)
+    ws = N.workspace(N.lib.piso_bicgstab_workspace_bytes(nx, ny, 8 if dt == torch.float64 else 4), rhs.device, "bicgstab")
+    its = (C.c_int * 2)()
+    fn = N.lib.piso_multi_bicgstab_ilu_slab_f64 if dt == torch.float64 else N.lib.piso_multi_bicgstab_ilu_slab_f32
+    st = fn(comm.handle, N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(rhs), N.ptr(x0), N.ptr(x), nx, ny, C.c_float(tol),
+            int(max_it), int(bool(transpose)), int(band_rows), N.ptr(warn), its, N.ptr(ws), C.c_size_t(ws.numel()), N.stream_ptr())
+    N.check(st, "piso_multi_bicgstab_ilu_slab")
+    if gather and comm.world > 1:
+        x = gather_face_rows(comm, x, nx, ny)
+    return x, (its[0], its[1])

@@ -82,8 +82,14 @@ class LinearSolverScipy(LinearSolver):
                                    bool(transpose))
 
 
-def multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn):
-    """One call of piso_multi_bicgstab_ilu_{f32,f64}. Returns (x, iterations[2]); sets warn[0] in place on NaN input."""
+def multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn, slab_comm=None):
+    """One call of piso_multi_bicgstab_ilu_{f32,f64}. Returns (x, iterations[2]); sets warn[0] in place on NaN input.
+    slab_comm (distributed.SlabCommunicator, peer transport, more than one rank): the solve is cut into y-slabs over the ranks
+    (every rank passes the full arrays and works on its rows; dot products are all-reduced inside the scalar kernels, the edge
+    rows of the SpMV inputs travel through the mailboxes) and every rank returns the full solution."""
+    if slab_comm is not None and slab_comm.world > 1:
+        from .distributed import multi_bicgstab_ilu_slab
+        return multi_bicgstab_ilu_slab(slab_comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn)
     dt = values.dtype
     assert dt in (torch.float32, torch.float64)
     values, rhs, x0 = values.contiguous(), rhs.to(dt).contiguous(), x0.to(dt).contiguous()
@@ -109,7 +115,7 @@ class _LinearSolveFn(torch.autograd.Function):
     def forward(ctx, rhs, values, row_ptr, col_indices, x0, solver, nx, ny, transpose, warn):
         tol = _scalar(solver.accuracy)
         x, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, solver.max_iterations,
-                                           transpose, solver.band_rows, warn)
+                                           transpose, solver.band_rows, warn, solver.slab_comm)
         solver.last_iterations = its
         solver.stats["solves"] += 1
         solver.stats["iterations"] += max(its)
@@ -126,7 +132,7 @@ class _LinearSolveFn(torch.autograd.Function):
         warn_b = warn_fwd.clone()
         tol = _scalar(solver.accuracy)
         df, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, ds.to(values.dtype), x0, nx, ny, tol,
-                                            solver.max_iterations, not transpose, solver.band_rows, warn_b)
+                                            solver.max_iterations, not transpose, solver.band_rows, warn_b, solver.slab_comm)
         solver.last_adjoint_iterations = its
         solver.stats["adjoint_solves"] += 1
         solver.stats["adjoint_iterations"] += max(its)
@@ -146,6 +152,7 @@ class LinearSolverCudaMultiBicgstabILU(LinearSolver):
         self.cast_to_double = cast_to_double
         self.accuracy = accuracy
         self.band_rows = band_rows
+        self.slab_comm = None        # distributed.SlabCommunicator (peer transport): cut every solve into y-slabs over the ranks
         self.last_iterations = None
         self.last_adjoint_iterations = None
         self.stats = dict(solves=0, iterations=0, adjoint_solves=0, adjoint_iterations=0)   # cumulative (max over u, v per solve)

@@ -231,6 +231,20 @@ int piso_conv2d_wgrad(const float* in, const float* grad_out, float* dw, int H, 
 int piso_comm_peer_create(int rank, int world, int row_capacity, void** comm_out, void* ipc_handle64_out);
 int piso_comm_peer_connect(void* comm, const void* ipc_handles64_all_ranks);
 int piso_comm_stats(void* comm, long long* out4);
+/* Slab-decomposed ILU(0)-BiCGStab (peer transport): same arguments as piso_multi_bicgstab_ilu_*, all arrays FULL on every rank
+ * (the assembly is cheap and replicated); the rank works on the face rows of its ny / world cell rows, which must be whole
+ * preconditioner bands (ny / world a multiple of the band height: then the banded ILU(0) is the single-GPU one and the iterates
+ * agree to summation order).  Per iteration: the five dot products are all-reduced INSIDE the one-block scalar kernels (tagged
+ * words through the mailboxes), the inputs of the two SpMVs receive their neighbours' edge rows (u[j], v[j], v[j+1] downwards,
+ * u[j], v[j] upwards, ring).  x_out is valid on the owned rows only.  The communicator's row_capacity must be >= 3 nx + 1. */
+int piso_multi_bicgstab_ilu_slab_f32(void* comm, const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* rhs,
+                                     const float* x0, float* x_out, int nx, int ny, float tol, int max_it, int transpose,
+                                     int band_rows, uint8_t* warning, int* iterations_out, void* workspace, size_t workspace_bytes,
+                                     piso_stream_t stream);
+int piso_multi_bicgstab_ilu_slab_f64(void* comm, const double* csr_val, const int* csr_rowptr, const int* csr_col, const double* rhs,
+                                     const double* x0, double* x_out, int nx, int ny, float tol, int max_it, int transpose,
+                                     int band_rows, uint8_t* warning, int* iterations_out, void* workspace, size_t workspace_bytes,
+                                     piso_stream_t stream);
 int piso_comm_unique_id(void* id128);
 int piso_comm_create(const void* id128, int rank, int world, void** comm_out);
 int piso_comm_destroy(void* comm);

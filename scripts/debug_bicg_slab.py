@@ -1,0 +1,35 @@
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
+rank, world, port = (int(v) for v in sys.argv[1:4])
+name, nx, ny = sys.argv[4], int(sys.argv[5]), int(sys.argv[6])
+maxit = int(sys.argv[7]) if len(sys.argv) > 7 else 200
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+import numpy as np, torch, torch.distributed as dist
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+from oracle import piso_ref as R
+from tests.cases import make_case, oracle_setup
+from diffpiso.distributed import SlabCommunicator
+from diffpiso.solvers import multi_bicgstab_ilu_native
+c = make_case(name, ny, nx, seed=7); s = oracle_setup(c)
+beta = float(np.prod(c["dx_yx"])) / c["dt"]
+val, rp, col, _, _ = R.advection_matrix(s, c["vel"], beta)
+rhs = np.random.default_rng(11).standard_normal(s.n_u + s.n_v).astype(np.float32)
+x0 = R.flatten_staggered(c["vel"], True)
+comm = SlabCommunicator(rank=rank, world=world, transport="peer", row_capacity=3 * nx + 8)
+dev = lambda a, dt=None: torch.tensor(np.ascontiguousarray(a), device="cuda", dtype=dt)
+tdt = torch.float64
+tolv = float(sys.argv[8]) if len(sys.argv) > 8 else 1e-30
+args = (dev(-val, tdt), dev(rp), dev(col), dev(rhs, tdt), dev(x0, tdt), nx, ny, tolv, maxit, False, 8)
+w = torch.zeros(1, dtype=torch.uint8, device="cuda")
+x1, it1 = multi_bicgstab_ilu_native(*args, w)
+x2, it2 = multi_bicgstab_ilu_native(*args, w, slab_comm=comm)
+d = (x1 - x2).abs().cpu().numpy()
+nu = (nx + 1) * ny
+du = d[:nu].reshape(ny, nx + 1).max(axis=1); dv = d[nu:].reshape(ny + 1, nx).max(axis=1)
+if rank == 0:
+    print("its", it1, it2)
+    print("u row err:", np.array2string(du, precision=1, max_line_width=250))
+    print("v row err:", np.array2string(dv, precision=1, max_line_width=250))
+comm.close(); dist.destroy_process_group()

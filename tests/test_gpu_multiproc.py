@@ -13,14 +13,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_ranks(world, nx, ny, walls, timeout=600):
+def run_ranks(world, nx, ny, walls, timeout=600, worker="slab_worker.py", extra=None):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_worker.py"), str(r), str(world), str(port), str(nx),
-                               str(ny), str(int(walls)), "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    tail = [str(nx), str(ny), str(int(walls)), "1"] if extra is None else extra
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker), str(r), str(world), str(port)] + tail,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
              for r in range(world)]
     res = []
     for p in procs:
@@ -80,3 +81,24 @@ def test_bench_two_ranks_on_one_gpu():
     assert chk["strong"]["max_rel_diff_persistent"] < 1e-9 and chk["strong"]["max_rel_diff_two_kernel"] < 1e-9
     assert chk["weak"]["max_rel_diff_vs_single_gpu_tall_grid"] < 1e-9
     assert chk["strong"]["persistent_iterations"] > 0 and chk["persistent_fallbacks"] == 0
+
+
+@pytest.mark.parametrize("world,name,nx,ny", [(2, "periodic", 48, 64), (2, "spatial_ml", 40, 32), (4, "xper_ywall", 36, 64),
+                                              (4, "periodic", 128, 128)])
+def test_slab_bicgstab_over_processes(world, name, nx, ny):
+    """The distributed ILU(0)-BiCGStab: slabs cut at band edges carry the single-GPU preconditioner, so iteration counts are the
+    single-GPU ones and the solutions agree to summation order (float64 1e-9; float32: its +-1, 2e-5 like the oracle test)."""
+    res = run_ranks(world, nx, ny, False, worker="bicg_worker.py", extra=[name, str(nx), str(ny)])
+    for r in res:
+        assert r["ok"], r
+        print(r)
+        assert r["nan_warn"] == 1
+        for run in r["runs"]:
+            assert run["warn"] == [0, 0]
+            if "float64" in run["dtype"]:
+                assert run["its_single"] == run["its_slab"], run
+                assert run["rel_diff"] <= 1e-9, run
+            else:
+                assert max(abs(a - b) for a, b in zip(run["its_single"], run["its_slab"])) <= 1, run
+                assert run["rel_diff"] <= 2e-5, run
+    assert len({json.dumps(r["runs"]) for r in res}) == 1          # every rank saw the same iteration counts and the same solution
