@@ -13,8 +13,8 @@ Multi-GPU: "replicas" (default) -- every rank runs the same independent 2048^2 p
 N * K / max-over-ranks time, scaling "weak".  After the timed region every N > 1 run exercises the slab-decomposed pressure CG
 on the real node (peer-mapped mailboxes over xGMI, persistent slab kernel, RCCL transport) and reports it INSIDE the JSON line
 (`slab_cg_self_check`: strong- and weak-scaled us per iteration, agreement with single-GPU solves); a failed or hung check
-makes the run exit non-zero.  `--decomp slab` runs the whole bench on ONE grid with the CG cut into y-slabs and the rest of
-the step replicated (strong scaling: DESIGN.md 6 explains why that cannot beat the on-chip single-GPU kernel at 2048^2).
+makes the run exit non-zero.  `--decomp slab` runs the whole bench on ONE grid with both linear solvers (pressure CG, ILU(0)-BiCGStab)
+cut into y-slabs over the ranks and assembly / glue replicated (strong scaling: DESIGN.md 6 explains why that cannot beat the on-chip single-GPU kernel at 2048^2).
 
 One JSON line on stdout (rank 0) with, besides the contract's keys:
   roofline      the dominant kernel (persistent pressure CG), HIP-event timed inside the timed region.  `achieved` counts the
@@ -404,7 +404,8 @@ def main():
     slab = world > 1 and args.decomp == "slab"
     if slab:
         from diffpiso.distributed import SlabCommunicator
-        P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=n)
+        P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=3 * n + 8)
+        P["lin"].slab_comm = P["ps"].slab_comm       # the ILU(0)-BiCGStab is cut into the same slabs (dot products all-reduced)
 
     def barrier():
         torch.cuda.synchronize()
@@ -511,7 +512,7 @@ def main():
             "config": {"workload": "2-D decaying isotropic turbulence %d^2 periodic, PISO step fwd + reverse-mode, "
                                    "unrolled %d steps, tol %g, max_it %d, CG reset %d, pressure fp64 / advection fp32, "
                                    "%s" % (n, args.steps, args.tol, args.max_iterations, args.residual_reset,
-                                           ("slab-decomposed pressure CG over %d GPUs, rest replicated" % world) if slab else
+                                           ("pressure CG and ILU(0)-BiCGStab slab-decomposed over %d GPUs (peer mailboxes), assembly and glue replicated" % world) if slab else
                                            ("replicas only (one independent grid per GPU)" if world > 1 else "1 GPU")),
                        "grid": [n, n], "last_cg_iterations_fwd": P["ps"].last_iterations or 0,
                        "last_cg_iterations_adjoint": P["ps"].last_adjoint_iterations or 0,

@@ -102,3 +102,35 @@ def test_slab_bicgstab_over_processes(world, name, nx, ny):
                 assert max(abs(a - b) for a, b in zip(run["its_single"], run["its_slab"])) <= 1, run
                 assert run["rel_diff"] <= 2e-5, run
     assert len({json.dumps(r["runs"]) for r in res}) == 1          # every rank saw the same iteration counts and the same solution
+
+
+def _bench(env_extra, args, nproc):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and lines, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
+    return json.loads(lines[-1])
+
+
+def test_decomposed_step_two_ranks_matches_one_gpu():
+    """The whole benchmark step (forward PISO steps + reverse sweep) with BOTH linear solvers cut into two slabs over two
+    processes -- pressure CG through the persistent slab kernel, ILU(0)-BiCGStab with all-reduced dot products, forward and
+    transposed solves -- against the same run on one GPU: the loss and the CG / BiCGStab iteration counts must agree."""
+    common = ["--steps", "2", "--warmup", "0", "--grid", "256", "--no-cpu-baseline", "--no-extras", "--tol", "1e-7"]
+    one = _bench({}, ["--gpus", "1"] + common, 1)
+    two = _bench({"PISO_BENCH_SHARE_GPU": "1", "PISO_BENCH_SLAB_CHECK": "0"}, ["--gpus", "2", "--decomp", "slab"] + common, 2)
+    assert two["scaling"] == "strong" and two["n_gpus"] == 2
+    l1, l2 = one["config"]["loss"], two["config"]["loss"]
+    print(one["config"], two["config"])
+    assert abs(l1 - l2) <= 1e-5 * abs(l1), (l1, l2)
+    assert one["config"]["last_bicgstab_iterations"] == two["config"]["last_bicgstab_iterations"]
+    assert abs(one["config"]["last_cg_iterations_fwd"] - two["config"]["last_cg_iterations_fwd"]) <= 10
