@@ -250,6 +250,55 @@ __device__ __forceinline__ bool xgpu_exchange8(const PeerView& pv, T (&v)[kX1Val
   return good;       // (smx alternates by epoch parity: the barriers of the next exchange separate these reads from the next writes)
 }
 
+// x-neighbours across the lanes of a wave.  The values beyond the two ends of the strip (`ring`: the left neighbour of row j in
+// lane j, the right neighbour in lane 48 + j) enter through the `old` operand of the wave shift: one row-local DPP shift brings
+// lane j to lane 0 (row_shl:j) or lane 48 + j to lane 63 (row_shr:15-j), the wave shift keeps it there.  2 VALU instructions
+// per 32-bit half - through v_readlane + v_mov (SGPR broadcast) it was 3, and the loop is bound by VALU issue.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <bool UP>
+__device__ __forceinline__ int ring_to_end32(int ring, int j) {     // j: constant after unrolling
+  if (UP) {
+    switch (j) {
+      case 0: return ring;
+      case 1: return dpp_mov32<0x101>(ring); case 2: return dpp_mov32<0x102>(ring); case 3: return dpp_mov32<0x103>(ring);
+      case 4: return dpp_mov32<0x104>(ring); case 5: return dpp_mov32<0x105>(ring); case 6: return dpp_mov32<0x106>(ring);
+      case 7: return dpp_mov32<0x107>(ring); case 8: return dpp_mov32<0x108>(ring); case 9: return dpp_mov32<0x109>(ring);
+      case 10: return dpp_mov32<0x10a>(ring); case 11: return dpp_mov32<0x10b>(ring); case 12: return dpp_mov32<0x10c>(ring);
+      case 13: return dpp_mov32<0x10d>(ring); case 14: return dpp_mov32<0x10e>(ring); default: return dpp_mov32<0x10f>(ring);
+    }
+  } else {
+    switch (j) {
+      case 15: return ring;
+      case 14: return dpp_mov32<0x111>(ring); case 13: return dpp_mov32<0x112>(ring); case 12: return dpp_mov32<0x113>(ring);
+      case 11: return dpp_mov32<0x114>(ring); case 10: return dpp_mov32<0x115>(ring); case 9: return dpp_mov32<0x116>(ring);
+      case 8: return dpp_mov32<0x117>(ring); case 7: return dpp_mov32<0x118>(ring); case 6: return dpp_mov32<0x119>(ring);
+      case 5: return dpp_mov32<0x11a>(ring); case 4: return dpp_mov32<0x11b>(ring); case 3: return dpp_mov32<0x11c>(ring);
+      case 2: return dpp_mov32<0x11d>(ring); case 1: return dpp_mov32<0x11e>(ring); default: return dpp_mov32<0x11f>(ring);
+    }
+  }
+}
+// lane l receives `v` of lane l - 1 (UP) or l + 1 (!UP); lane 0 / lane 63 receives the ring value of row j
+template <bool UP, typename S>
+__device__ __forceinline__ S shift_ring(S v, S ring, int j) {
+  constexpr int ctrl = UP ? 0x138 /* wave_shr:1 */ : 0x130 /* wave_shl:1 */;
+  if constexpr (sizeof(S) == 8) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong((double)v), e = (unsigned long long)__double_as_longlong((double)ring);
+    const int elo = ring_to_end32<UP>((int)(unsigned)e, j), ehi = ring_to_end32<UP>((int)(unsigned)(e >> 32), j);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(elo, (int)(unsigned)b, ctrl, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(ehi, (int)(unsigned)(b >> 32), ctrl, 0xf, 0xf, false);
+    return (S)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  } else {
+    const int e = ring_to_end32<UP>(__float_as_int((float)ring), j);
+    return (S)__int_as_float(__builtin_amdgcn_update_dpp(e, __float_as_int((float)v), ctrl, 0xf, 0xf, false));
+  }
+}
+// lane layout of the ring columns: lanes [0, R) the left neighbours of rows 0 .. R-1, lanes [48, 48 + R) the right neighbours
+__device__ __forceinline__ void ring_lane(int lane, int R, int& side, int& er) {
+  side = (lane < R) ? 0 : ((lane >= 48 && lane < 48 + R) ? 1 : 2);
+  er = (side == 1) ? lane - 48 : lane;
+}
+
 constexpr int kSystem = 17;                       // buffer cache policy sc0 | sc1: system scope (peer-mapped mailboxes)
 
 template <typename T, typename CT, int R, int NQ, bool RECON, bool SYM, bool SLAB = false>
@@ -299,13 +348,13 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     if constexpr (SLAB) return (unsigned)((4 + parity * 2 + side) * sl.pv.row_cap * 8);
     else return 0u;
   };
-  const rsrc_t Rr = make_rsrc(a.r, nbytesT), Rx = make_rsrc(a.x, nbytesT);
   const rsrc_t RoS = make_rsrc(a.oS, nbytesC), RoW = make_rsrc(a.oW, nbytesC), RoE = make_rsrc(a.oE, nbytesC), RoN = make_rsrc(a.oN, nbytesC);
   const rsrc_t RcC = make_rsrc(a.cC, nbytesT);
   // p[0] / p[1]: the direction of the two-kernel path, read on entry and written on exit.  zp[0] / zp[1]: the published z'
   // perimeters, touched by agent-scope (sc1) stores and loads only - never by a plain load, whose copy of a line in the reader
   // XCD's L2 another XCD's write-through store does not invalidate.
-  const rsrc_t Rp0 = make_rsrc(a.p[0], nbytesT), Rp1 = make_rsrc(a.p[1], nbytesT);
+  // (r, x, p[]: resources built at the entry and again at the exit - a resource that stays alive across the loop costs 4 SGPRs,
+  // and spilled SGPRs come back through v_readlane: VALU slots of a loop that is bound by VALU issue)
   const rsrc_t Rz0 = make_rsrc(a.zp[0], nbytesT), Rz1 = make_rsrc(a.zp[1], nbytesT);
   auto row_wrap = [&](int j, bool& valid) __attribute__((always_inline)) -> int {   // scalar: rows outside wrap or vanish
     valid = true;
@@ -323,7 +372,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   T eR[NQ], edge[NQ];
   bool vb[NQ], va[NQ], vl[NQ], vr[NQ];                      // is there a cell below / above / left / right of region q at all?
   {
-    const rsrc_t Rp = (k_begin & 1) ? Rp1 : Rp0;
+    const rsrc_t Rr = make_rsrc(a.r, nbytesT), Rx = make_rsrc(a.x, nbytesT), Rp = make_rsrc(a.p[k_begin & 1], nbytesT);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int cq = (tx0[q] * 64 + lane) * V;
@@ -371,7 +420,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         stv<T, V>(hs + 64 * V, pna[q]);
       }
       }
-      const int side = lane / R, er = lane - side * R;
+      int side, er;
+      ring_lane(lane, R, side, er);
       int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
       vl[q] = tx0[q] > 0 || a.per_x;
       vr[q] = tx0[q] + 1 < c.ntx || a.per_x;
@@ -424,6 +474,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT], cSh[NQ];
   Vec<T, V> cD[NT];
   CT eW[NQ];
+  // byte offset of row j0[q] + jj: recomputed at every use (two scalar instructions) from a value the optimiser cannot see
+  // through - hoisted out of the unrolled row loops the 2 x 16 products live in SGPRs that spill, and a spilled SGPR comes back
+  // through v_readlane, a VALU slot of a loop that is bound by VALU issue
+  auto row_base = [&](int q, int jj, unsigned row_bytes) __attribute__((always_inline)) -> unsigned {
+    unsigned j = (unsigned)j0[q];
+    asm volatile("" : "+s"(j));
+    return (j + (unsigned)jj) * row_bytes;
+  };
   auto coef_offset = [&](int q) __attribute__((always_inline)) -> unsigned {
     unsigned o = vT[q];
     asm volatile("" : "+v"(o));
@@ -432,7 +490,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   auto issue_coef = [&](int t) __attribute__((always_inline)) {
     const int q = t / R, jj = t - q * R;
     const unsigned vCq = coef_offset(q);
-    const unsigned sT = (unsigned)(j0[q] + jj) * rowT, sC = (unsigned)(j0[q] + jj) * rowC;
+    const unsigned sT = row_base(q, jj, rowT), sC = row_base(q, jj, rowC);
     cS[t] = bld<CT, V>(RoS, vCq, sC); cW[t] = bld<CT, V>(RoW, vCq, sC);
     if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vCq, sC); cN[t] = bld<CT, V>(RoN, vCq, sC); }
     if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
@@ -443,7 +501,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   if constexpr (SYM) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int side = lane / R, er = lane - side * R;
+      int side, er;
+      ring_lane(lane, R, side, er);
       int cc = (tx0[q] + 1) * 64 * V;
       if (cc >= nx) cc = a.per_x ? 0 : -1;
       const unsigned vo = (has[q] && side == 1 && cc >= 0) ? (unsigned)(j0[q] + er) * rowC + (unsigned)(cc * sizeof(CT)) : 0xffffffffu;
@@ -463,14 +522,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     const Vec<T, V> behind = (jj > 0) ? pp[q][jj > 0 ? jj - 1 : 0] : (kParkHalos ? ldv<T, V>(hs) : pnb[q]);
     const Vec<T, V> cur = pp[q][jj];
     const Vec<T, V> ahead = (jj + 1 < R) ? pp[q][jj + 1 < R ? jj + 1 : jj] : (kParkHalos ? ldv<T, V>(hs + (kParkHalos ? 64 * V : 0)) : pna[q]);
-    const T left = shift_lane<true, T>(cur.v[V - 1], read_lane<T>(edge[q], jj));
-    const T right = shift_lane<false, T>(cur.v[0], read_lane<T>(edge[q], R + jj));
+    const T left = shift_ring<true, T>(cur.v[V - 1], edge[q], jj);
+    const T right = shift_ring<false, T>(cur.v[0], edge[q], jj);
     Vec<CT, V> kN, kE;
     if constexpr (SYM) {
       kN = (jj + 1 < R) ? cS[t + 1 < NT ? t + 1 : t] : cSh[q];
 #pragma unroll
       for (int e = 0; e + 1 < V; ++e) kE.v[e] = cW[t].v[e + 1];
-      kE.v[V - 1] = shift_lane<false, CT>(cW[t].v[0], read_lane<CT>(eW[q], R + jj));
+      kE.v[V - 1] = shift_ring<false, CT>(cW[t].v[0], eW[q], jj);
     } else {
       kN = cN[t]; kE = cE[t];
     }
@@ -478,8 +537,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     if constexpr (RECON) {
 #pragma unroll
       for (int e = 0; e < V; ++e) {
-        T d = 0;
-        d -= (T)cS[t].v[e]; d -= (T)kN.v[e]; d -= (T)cW[t].v[e]; d -= (T)kE.v[e];
+        T d = -(T)cS[t].v[e] - (T)kN.v[e];                    // = (0 - S) - N: the first difference of laplace_op.cu.cc:118-135 is exact
+        d -= (T)cW[t].v[e]; d -= (T)kE.v[e];
         kC.v[e] = d;
       }
     } else {
@@ -502,7 +561,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   unsigned zoff_lo = 0, zoff_hi = 0, zoff_b = 0, zoff_a = 0;   // SLAB: this iteration's rows in the neighbours' / my mailbox
   // perimeter of row jj of region q (what neighbouring regions read): the whole first / last row, else the two end cells
   auto publish = [&](rsrc_t Rd, int q, int jj, const Vec<T, V>& val) __attribute__((always_inline)) {
-    const unsigned sT = (unsigned)(j0[q] + jj) * rowT;
+    const unsigned sT = row_base(q, jj, rowT);
     if (jj == 0 || jj == R - 1) {
       bst<T, V, kAgent>(Rd, vT[q], sT, val);
       if constexpr (SLAB) {
@@ -522,7 +581,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   auto issue_halos = [&](rsrc_t Rz) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int side = lane / R, er = lane - side * R;
+      int side, er;
+      ring_lane(lane, R, side, er);
       int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
       if (cc < 0) cc = a.per_x ? nx - 1 : -1;
       else if (cc >= nx) cc = a.per_x ? 0 : -1;
@@ -620,9 +680,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     ++epoch;
     tick(0);
     healthy = grid_exchange8<T>(c, sD, epoch, smem, NoPrefetch(), (kPersistDiag && c.timing) ? tsub : nullptr);
-#ifndef PISO_SLAB_NO_XGPU
     if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl.pv, sD, epoch, smem + 2 * kX1Sm); }
-#endif
     tick(1);
     if (!healthy) break;
     // ---- the stopping test of iteration k, one exchange late but before anything moves (x = x_k): (:312-335)
@@ -644,6 +702,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     sumr = uniform(sumr - alpha * (sD[5] + ncells * vs));
     // ---- U(k): z' again, x += alpha p, r -= alpha (z' + vs) on my cells and on the ring
     lU[0] = 0; lU[1] = 0;
+    int cnt_wave = 0;                                        // #{|r_{k+1}| >= accuracy} of the whole wave, counted on the scalar unit
     if (has[0]) {
       issue_halos(Rz);
 #pragma unroll
@@ -660,7 +719,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           const T rn = fma(-alpha, z.v[e] + vs, rr[q][jj].v[e]);
           rr[q][jj].v[e] = rn;
           lU[0] += rn;
-          lU[1] += (absval(rn) < accuracy) ? (T)0 : (T)1;
+          // (one compare per cell; ballot + popcount + add run on the scalar unit - the loop is bound by VALU issue.  A NaN counts.)
+          cnt_wave += __builtin_popcountll(__ballot(!(absval(rn) < accuracy)));
         }
         PISO_SB_B1;
         if constexpr (D < NT) issue_coef(t + D < NT ? t + D : t + D - NT);   // wraps: rows 0 .. D-1 for D of the next iteration
@@ -675,10 +735,12 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           rhb[q].v[e] = fma(-alpha, hbZ[q].v[e] + vsb, rhb[q].v[e]);
           rha[q].v[e] = fma(-alpha, haZ[q].v[e] + vsa, rha[q].v[e]);
         }
-        const int side = lane / R;
+        int side, er_unused;
+        ring_lane(lane, R, side, er_unused);
         const T vse = (side == 0) ? (vl[q] ? vs : (T)0) : ((side == 1) ? (vr[q] ? vs : (T)0) : (T)0);
         eR[q] = fma(-alpha, eZ[q] + vse, eR[q]);
       }
+      lU[1] = (lane == 0) ? (T)cnt_wave : (T)0;              // (the exchange adds the lanes of a wave)
     }
     tick(2);
   }
@@ -700,7 +762,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
 
   // ---- back to the global-memory state of the two-kernel path (iteration k reads its direction from p[k & 1])
   {
-    const rsrc_t Rp = (k & 1) ? Rp1 : Rp0;
+    const rsrc_t Rr = make_rsrc(a.r, nbytesT), Rx = make_rsrc(a.x, nbytesT), Rp = make_rsrc(a.p[k & 1], nbytesT);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       if (has[q]) {
