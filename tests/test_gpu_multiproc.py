@@ -136,3 +136,19 @@ def test_decomposed_step_two_ranks_matches_one_gpu():
     # (the shifted, rank-deficient operator: CG iteration counts are not reproducible between summation orders - DESIGN.md 4 - and
     # the stopping test runs every 5th iteration)
     assert abs(one["config"]["last_cg_iterations_fwd"] - two["config"]["last_cg_iterations_fwd"]) <= 30
+
+
+def test_config5_4096_eight_slabs():
+    """BASELINE.json config 5 at its size and rank count: decaying turbulence 4096^2, 8-slab decomposition, mailbox halo exchange and
+    all-reduced dot products - eight processes (here: sharing the one GPU, so the CG runs its two-kernel iteration; eight
+    persistent slab kernels of 128 workgroups cannot be resident side by side on 256 CUs), one PISO step forward + reverse sweep
+    with a bounded iteration count, against the same step on one GPU."""
+    common = ["--steps", "1", "--warmup", "0", "--grid", "4096", "--no-cpu-baseline", "--no-extras", "--max-iterations", "100"]
+    one = _bench({}, ["--gpus", "1"] + common, 1)
+    eight = _bench({"PISO_BENCH_SHARE_GPU": "1", "PISO_BENCH_SLAB_CHECK": "0"}, ["--gpus", "8", "--decomp", "slab"] + common, 8)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong"
+    l1, l8 = one["config"]["loss"], eight["config"]["loss"]
+    print(one["config"], eight["config"])
+    assert abs(l1 - l8) <= 1e-5 * abs(l1), (l1, l8)
+    assert one["config"]["last_bicgstab_iterations"] == eight["config"]["last_bicgstab_iterations"]
+    assert eight["config"]["warn"] == 0.0
