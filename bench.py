@@ -432,6 +432,7 @@ def main():
     N.lib.piso_cg_profile_read(ms_sum, cnt)
     N.lib.piso_cg_profile_enable(0, 16)
     fallbacks = int(N.lib.piso_cg_persist_fallbacks())
+    verify_runs, verify_failures = N.cg_verify_stats()
     from diffpiso.distributed import max_over_ranks
     elapsed = max_over_ranks(elapsed, device)
 
@@ -502,7 +503,8 @@ def main():
                                                    "adjoint": lin_stats["adjoint_iterations"] / float(args.steps)},
                   "persistent_cg_ms_per_step": (cg_ms_total / args.steps) if cg_ms_total is not None else None,
                   "persistent_cg_share_of_step": (cg_ms_total / (1e3 * elapsed)) if cg_ms_total is not None else None,
-                  "persistent_cg_fallbacks": fallbacks}
+                  "persistent_cg_fallbacks": fallbacks,
+                  "persistent_cg_solves_verified_against_true_residual": verify_runs, "verification_failures": verify_failures}
         out = {
             "metric": "PISO steps/s (fwd+adjoint) at %d^2 staggered grid" % n,
             "value": (1 if slab else world) * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,

@@ -28,6 +28,8 @@ struct HostPoll {
 constexpr int kPersistDefaultExchanges = 1;   // grid-wide exchanges per persistent iteration when cg_exchanges is not set
 static std::atomic<unsigned> g_persist_launches{0};   // persistent launches so far: the high half of their exchange tags
 static int g_persist_fallbacks = 0;            // solves that were restarted on the two-kernel path after an exchange timed out
+static long long g_verify_runs = 0;            // solves whose final state was checked against the true residual (cg_verify_gap)
+static int g_verify_failures = 0;              // ... and failed: restarted on the two-kernel path
 static thread_local HostPoll tl_poll;
 
 static int ensure_poll() {
@@ -207,6 +209,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   hipEvent_t* seg_ev = tl_poll.seg_ev;
   if (persist_R && prof && !seg_ev[0]) { PISO_HIP_CHECK(hipEventCreate(&seg_ev[0])); PISO_HIP_CHECK(hipEventCreate(&seg_ev[1])); }
   double seg_ms = 0; long long seg_iters = 0, seg_launches = 0;
+  int segments_run = 0;
   for (int k = 0; k < total && !finished; ++k) {
     const bool is_reset = !fixed && ((k + 1) % reset == 0);
     if (persist_R && k > 0 && !is_reset) {
@@ -232,6 +235,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
         }
         if (prof) { float t = 0; PISO_HIP_CHECK(hipEventElapsedTime(&t, seg_ev[0], seg_ev[1])); seg_ms += t; seg_iters += ke - k; ++seg_launches; }
         if (tl_poll.pinned[0].done) { finished = true; stop_it = tl_poll.pinned[0].iterations; }
+        ++segments_run;
         k_last = ke - 1;
         pending = false;                                   // the segment applies every x += alpha p itself
         k = ke - 1;                                        // the loop increment moves to ke
@@ -284,6 +288,30 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     if (r > 0) finished = true;
   }
   PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  // ---- The persistent kernel lets workgroups read what others published without release / acquire fences (cg_persist.h).  That
+  // is checked here at run time instead of being trusted: r - the CG recurrence - must still equal b - A^ x for the x the solve
+  // returns (to eps * condition * |b|; a stale perimeter value would leave an O(alpha |z'|) gap that nothing removes before the
+  // next residual reset).  One stencil pass per solve; a failure restarts the solve on the two-kernel path and is counted.
+  if (segments_run > 0 && sizeof(T) == 8 && !fixed && opt(OPT_CG_VERIFY) != 0) {
+    unsigned* out2 = reinterpret_cast<unsigned*>(pc.err) + 4;
+    PISO_HIP_CHECK(hipMemsetAsync(out2, 0, 2 * sizeof(unsigned), stream));
+    const int gvf = grid_for((long long)n, kBlock * 4, 1024);
+    cg_verify_sum_x<T><<<gvf, kBlock, 0, stream>>>(a, a.partsA);
+    cg_verify_gap<T, CT><<<gvf, kBlock, 0, stream>>>(a, a.partsA, gvf, out2);
+    PISO_LAUNCH_CHECK();
+    unsigned h2[2] = {0, 0};
+    PISO_HIP_CHECK(hipMemcpyAsync(h2, out2, sizeof(h2), hipMemcpyDeviceToHost, stream));
+    PISO_HIP_CHECK(hipStreamSynchronize(stream));
+    float gap, scale;
+    memcpy(&gap, &h2[0], 4); memcpy(&scale, &h2[1], 4);
+    ++g_verify_runs;
+    if ((gap > 1e-5f * scale && gap > 1e-30f) || opt(OPT_CG_VERIFY) == 2) {     // (2: test knob - treat the check as failed)
+      ++g_verify_failures; ++g_persist_fallbacks;
+      if (pc.timing) { PISO_HIP_CHECK(hipFree(pc.timing)); pc.timing = nullptr; }
+      return cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out,
+                                     kernel_ms_out, stream, false);
+    }
+  }
   if (pc.timing) {
     std::vector<unsigned long long> h(12 * persist_grid);
     PISO_HIP_CHECK(hipMemcpy(h.data(), pc.timing, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -429,6 +457,10 @@ void piso_cg_profile_enable(int enable, int stride) {
 }
 
 int piso_cg_persist_fallbacks(void) { return g_persist_fallbacks; }
+void piso_cg_verify_stats(long long* runs_out, int* failures_out) {
+  if (runs_out) *runs_out = g_verify_runs;
+  if (failures_out) *failures_out = g_verify_failures;
+}
 int piso_cg_default_exchanges(void) { return kPersistDefaultExchanges; }
 
 void piso_cg_profile_read(double* ms_sum, long long* count) {

@@ -577,6 +577,55 @@ __global__ __launch_bounds__(kBlock) void cg_init(CgArgs<T> a, int rank_deficien
   }
 }
 
+// ---- run-time verification of a solve that used the persistent kernel (cg.hip): the CG recurrences keep r = b - A^ x in exact
+// arithmetic, and in floating point to ~ eps * condition * |b|; a perimeter value read before it was visible would break that
+// identity for good (nothing re-synchronises r with x between residual resets).  Two passes over the state the solve ended in:
+// sum(x), then the largest |b - (L x + c sum x) - r| and the largest |b|, as non-negative floats through atomicMax on their bit
+// patterns.  Plain gathers - not on any hot path (one stencil pass per solve).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_verify_sum_x(CgArgs<T> a, T* parts) {
+  __shared__ T smem[16];
+  const size_t n = (size_t)a.nx * a.ny;
+  T acc[1] = {0};
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) acc[0] += a.x[i];
+  block_sum<T, 1>(acc, smem);
+  if (threadIdx.x == 0) parts[blockIdx.x] = acc[0];
+}
+template <typename T, typename CT>
+__global__ __launch_bounds__(kBlock) void cg_verify_gap(CgArgs<T> a, const T* parts, int nparts, unsigned* out2) {
+  __shared__ T smem[16];
+  T sx[1] = {0};
+  for (int b = threadIdx.x; b < nparts; b += kBlock) sx[0] += parts[b];
+  block_sum<T, 1>(sx, smem);
+  const T vs = a.scal[SC_C] * sx[0];
+  const int nx = a.nx, ny = a.ny;
+  const CT *oS = static_cast<const CT*>(a.oS), *oW = static_cast<const CT*>(a.oW), *oE = static_cast<const CT*>(a.oE), *oN = static_cast<const CT*>(a.oN);
+  const size_t n = (size_t)nx * ny;
+  float gap = 0.f, scale = 0.f;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const int ci = (int)(i % (size_t)nx), cj = (int)(i / (size_t)nx);
+    auto at = [&](int ii, int jj) -> T {
+      if (ii < 0) { if (!a.per_x) return (T)0; ii = nx - 1; }
+      if (ii >= nx) { if (!a.per_x) return (T)0; ii = 0; }
+      if (jj < 0) { if (!a.per_y) return (T)0; jj = ny - 1; }
+      if (jj >= ny) { if (!a.per_y) return (T)0; jj = 0; }
+      return a.x[(size_t)jj * nx + ii];
+    };
+    T z = 0;
+    z = fma((T)oS[i], at(ci, cj - 1), z);
+    z = fma((T)oW[i], at(ci - 1, cj), z);
+    z = fma(a.cC[i], a.x[i], z);
+    z = fma((T)oE[i], at(ci + 1, cj), z);
+    z = fma((T)oN[i], at(ci, cj + 1), z);
+    const T d = a.b[i] - (z + vs) - a.r[i];
+    const float g = (float)absval(d), sc = (float)absval(a.b[i]);
+    if (g == g) gap = g > gap ? g : gap;                 // (NaN data: nothing to verify - the solve reports NaN as the reference does)
+    if (sc == sc) scale = sc > scale ? sc : scale;
+  }
+  gap = wave_max(gap); scale = wave_max(scale);
+  if ((threadIdx.x & 63) == 0) { atomicMax(out2, __float_as_uint(gap)); atomicMax(out2 + 1, __float_as_uint(scale)); }
+}
+
 template <typename T>
 __global__ void cg_zero_partials(T* partsA, T* partsB, T* partsS) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -32,6 +32,8 @@ lib.piso_get_option.argtypes = [C.c_char_p, _ip]
 lib.piso_get_option.restype = _i
 lib.piso_cg_persist_fallbacks.restype = _i
 lib.piso_cg_default_exchanges.restype = _i
+lib.piso_cg_verify_stats.argtypes = [C.POINTER(C.c_longlong), _ip]
+lib.piso_cg_verify_stats.restype = None
 lib.piso_csr_nnz.argtypes = [_i, _i, _i, _i, _ip, _ip]
 lib.piso_csr_nnz.restype = None
 lib.piso_assemble_csr.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _f, _vp, _f, _vp]
@@ -123,6 +125,13 @@ def get_option(name):
     if lib.piso_get_option(name.encode(), C.byref(v)) != 0:
         raise PisoNativeError("unknown libpiso_hip option %r" % name)
     return v.value
+
+
+def cg_verify_stats():
+    """(solves whose result was checked against the true residual, checks that failed) -- include/piso_hip.h."""
+    runs, fails = C.c_longlong(0), C.c_int(0)
+    lib.piso_cg_verify_stats(C.byref(runs), C.byref(fails))
+    return int(runs.value), int(fails.value)
 
 
 def check(status, what):

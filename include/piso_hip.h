@@ -178,6 +178,12 @@ void piso_cg_profile_read(double* ms_sum, long long* count);
 /* Solves (since load) that were restarted on the two-kernel path because a grid-wide exchange of the persistent kernel timed
  * out (workgroups not co-resident: CU mask, another process on the GPU).  0 on a dedicated GPU. */
 int piso_cg_persist_fallbacks(void);
+/* Every fp64 solve that ran iterations inside the persistent kernel is VERIFIED before it returns: the recurrence residual r must
+ * equal b - (L x + c sum x) for the returned x to 1e-5 max|b| (one extra stencil pass).  The persistent kernel publishes perimeter
+ * rows without release / acquire fences; a value read before it was visible would break exactly this identity.  A failed check
+ * restarts the solve on the two-kernel iteration and is counted here (and in piso_cg_persist_fallbacks).  Option "cg_verify": 0
+ * skips the check, 2 treats every check as failed (test knob). */
+void piso_cg_verify_stats(long long* runs_out, int* failures_out);
 /* Grid-wide exchanges per iteration of the persistent kernel when the option cg_exchanges is not set (1 or 2). */
 int piso_cg_default_exchanges(void);
 

@@ -201,3 +201,30 @@ def test_piso_step_projects_to_discretely_divergence_free_2048(problem):
     # periodic duplicate faces stay consistent
     assert float((tt[0, :N, N, 1] - tt[0, :N, 0, 1]).abs().max()) < 1e-4
     assert float((tt[0, N, :N, 0] - tt[0, 0, :N, 0]).abs().max()) < 1e-4
+
+
+def test_persistent_solves_are_verified_against_the_true_residual(piso_option):
+    """Every fp64 solve that used the persistent kernel ends with a check of r against b - A^ x (include/piso_hip.h,
+    piso_cg_verify_stats): it must run, it must pass on healthy hardware, and a failed check (forced through the test knob) must
+    restart the solve on the two-kernel iteration and still return the right answer."""
+    import diffpiso._native as N
+    from diffpiso.solvers import cg_solve_native
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    from diag_persist1 import case
+    n = 1024
+    L, b = case(n, n)
+    runs0, fails0 = N.cg_verify_stats()
+    fb0 = N.lib.piso_cg_persist_fallbacks()
+    x1, it1 = cg_solve_native(n, n, True, True, L, b, 1e-7, 20000, True, 1000)
+    runs1, fails1 = N.cg_verify_stats()
+    assert runs1 == runs0 + 1 and fails1 == fails0 and N.lib.piso_cg_persist_fallbacks() == fb0
+    piso_option("cg_verify", 2)
+    x2, it2 = cg_solve_native(n, n, True, True, L, b, 1e-7, 20000, True, 1000)
+    runs2, fails2 = N.cg_verify_stats()
+    assert runs2 == runs1 + 1 and fails2 == fails1 + 1 and N.lib.piso_cg_persist_fallbacks() == fb0 + 1
+    piso_option("cg_persist", 0)
+    x3, it3 = cg_solve_native(n, n, True, True, L, b, 1e-7, 20000, True, 1000)
+    assert it2 == it3 and float((x2 - x3).abs().max()) == 0.0           # the restarted solve IS the two-kernel solve
+    assert float((x1 - x3).abs().max() / x3.abs().max()) < 1e-3          # (both stop at max|r| < 1e-7)
+    assert N.cg_verify_stats()[0] == runs2                               # no persistent segment, nothing to verify
