@@ -592,11 +592,12 @@ __global__ __launch_bounds__(kBlock) void cg_verify_sum_x(CgArgs<T> a, T* parts)
   if (threadIdx.x == 0) parts[blockIdx.x] = acc[0];
 }
 template <typename T, typename CT>
-__global__ __launch_bounds__(kBlock) void cg_verify_gap(CgArgs<T> a, const T* parts, int nparts, unsigned* out2) {
+__global__ __launch_bounds__(kBlock) void cg_verify_gap(CgArgs<T> a, const T* parts, int nparts, unsigned* out2, const T* global_sum = nullptr) {
   __shared__ T smem[16];
   T sx[1] = {0};
   for (int b = threadIdx.x; b < nparts; b += kBlock) sx[0] += parts[b];
   block_sum<T, 1>(sx, smem);
+  if (global_sum) sx[0] = global_sum[0];                  // slab mode: sum(x) over all ranks
   const T vs = a.scal[SC_C] * sx[0];
   const int nx = a.nx, ny = a.ny;
   const CT *oS = static_cast<const CT*>(a.oS), *oW = static_cast<const CT*>(a.oW), *oE = static_cast<const CT*>(a.oE), *oN = static_cast<const CT*>(a.oN);
@@ -607,9 +608,11 @@ __global__ __launch_bounds__(kBlock) void cg_verify_gap(CgArgs<T> a, const T* pa
     auto at = [&](int ii, int jj) -> T {
       if (ii < 0) { if (!a.per_x) return (T)0; ii = nx - 1; }
       if (ii >= nx) { if (!a.per_x) return (T)0; ii = 0; }
-      if (jj < 0) { if (!a.per_y) return (T)0; jj = ny - 1; }
-      if (jj >= ny) { if (!a.per_y) return (T)0; jj = 0; }
-      return a.x[(size_t)jj * nx + ii];
+      if (a.per_y != 2) {                                 // (slab mode: rows -1 and ny are halo rows in memory)
+        if (jj < 0) { if (!a.per_y) return (T)0; jj = ny - 1; }
+        if (jj >= ny) { if (!a.per_y) return (T)0; jj = 0; }
+      }
+      return a.x[(ptrdiff_t)jj * nx + ii];
     };
     T z = 0;
     z = fma((T)oS[i], at(ci, cj - 1), z);

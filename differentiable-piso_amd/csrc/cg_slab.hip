@@ -110,6 +110,14 @@ template <typename T>
 __global__ void slab_err_to_sum(const int* seg_err, const int* comm_err, T* out) {
   if (threadIdx.x == 0) out[0] = (T)((*seg_err != 0 || *comm_err != 0) ? 1 : 0);
 }
+// verification of a slab solve (cg_verify_gap): did the gap exceed its bound on this rank?  (summable)
+template <typename T>
+__global__ void slab_gap_to_sum(const unsigned* out2, T* out, int force) {
+  if (threadIdx.x == 0) {
+    const float gap = __uint_as_float(out2[0]), scale = __uint_as_float(out2[1]);
+    out[0] = (T)(((gap > 1e-5f * scale && gap > 1e-30f) || force) ? 1 : 0);
+  }
+}
 constexpr size_t kSlabPersistWsWords = (size_t)2 * kPersistMaxGrid * 32 + 64;   // exchange records (2 x grid x 128 B) + error flag
 // loopback all-reduce: bufs of the G virtual ranks live `stride` apart; sum in rank order, write to all
 template <typename T>
@@ -362,7 +370,7 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
     return comm.exchange(R, 0, stream);                  // halo rows of the new residual
   };
 
-  int sv = 0, stop_it = -1, k_last = -1;
+  int sv = 0, stop_it = -1, k_last = -1, segments_run = 0;
   bool pending = false, finished = false;
   const int batch = 25;
   for (int k = 0; k < max_iterations && !finished; ++k) {
@@ -404,6 +412,7 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
           return kSlabRetry;
         }
         c->persist_iterations += ke - k;
+        ++segments_run;
         if (tl_slab_pinned->st.done) { finished = true; stop_it = tl_slab_pinned->st.iterations; }
         k_last = ke - 1;
         pending = false;                                   // the segment applies every x += alpha p itself
@@ -438,6 +447,34 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
   }
   if (pending && k_last >= 0)
     for (int q = 0; q < nloc; ++q) cg_flush_x<T><<<gflat[q], kBlock, 0, stream>>>(R[q].a, k_last, sv);
+  // ---- run-time verification of a solve that used the persistent slab kernel (as cg.hip does on one GPU; here it also covers
+  // what crossed xGMI): r must still be b - A^ x for the x this rank returns.  Needs the neighbours' edge rows of x and the
+  // global sum(x); the verdicts of all ranks are summed, so all ranks accept or all restart on the two-kernel iteration.
+  if constexpr (sizeof(T) == 8) {
+    if (segments_run > 0 && opt(OPT_CG_VERIFY) != 0) {
+      CgArgs<T>& a0 = R[0].a;
+      unsigned* out2 = reinterpret_cast<unsigned*>(pc.err) + 4;
+      PISO_HIP_CHECK(hipMemsetAsync(out2, 0, 2 * sizeof(unsigned), stream));
+      int rc = comm.exchange(R, 1, stream);
+      const int gvf = grid_for((long long)a0.nx * a0.ny, kBlock * 4, 1024);
+      cg_verify_sum_x<T><<<gvf, kBlock, 0, stream>>>(a0, a0.partsA);
+      slab_collapse<T><<<1, kBlock, 0, stream>>>(a0.partsA, gvf, 1, R[0].g + 12);
+      if (rc == PISO_OK) rc = comm.allreduce(R, 12, 1, stream);
+      cg_verify_gap<T, CT><<<gvf, kBlock, 0, stream>>>(a0, a0.partsA, 0, out2, R[0].g + 12);
+      slab_gap_to_sum<T><<<1, 64, 0, stream>>>(out2, R[0].g + 13, opt(OPT_CG_VERIFY) == 2 ? 1 : 0);
+      if (rc == PISO_OK) rc = comm.allreduce(R, 13, 1, stream);
+      if (rc != PISO_OK) return rc;
+      PISO_LAUNCH_CHECK();
+      PISO_HIP_CHECK(hipMemcpyAsync(&tl_slab_pinned->errsum, R[0].g + 13, sizeof(double), hipMemcpyDeviceToHost, stream));
+      PISO_HIP_CHECK(hipStreamSynchronize(stream));
+      ++comm.rccl->verify_runs;
+      if (tl_slab_pinned->errsum != 0) {
+        ++comm.rccl->verify_failures;
+        ++comm.rccl->persist_fallbacks;
+        return kSlabRetry;
+      }
+    }
+  }
   for (int q = 0; q < nloc; ++q)
     slab_copy_rows<T><<<gflat[q], kBlock, 0, stream>>>(R[q].a.x, R[q].x_out, (size_t)R[q].a.nx * R[q].a.ny);
   PISO_LAUNCH_CHECK();
@@ -627,10 +664,11 @@ int piso_comm_peer_connect(void* comm, const void* ipc_handles64_all_ranks) {
 
 // what the communicator did so far: [0] transport (1 RCCL, 2 peer mailboxes), [1] CG iterations executed inside persistent slab
 // segments, [2] solves restarted on the two-kernel iteration after a segment failed, [3] persistent launches
-int piso_comm_stats(void* comm, long long* out4) {
+int piso_comm_stats(void* comm, long long* out4) {      // (six values: see include/piso_hip.h)
   PisoComm* c = static_cast<PisoComm*>(comm);
   if (!c || !out4) { set_error_msg("piso_comm_stats: invalid argument"); return PISO_ERR_INVALID_ARG; }
   out4[0] = c->transport; out4[1] = c->persist_iterations; out4[2] = c->persist_fallbacks; out4[3] = c->launches;
+  out4[4] = c->verify_runs; out4[5] = c->verify_failures;
   return PISO_OK;
 }
 

@@ -20,6 +20,8 @@ struct PisoComm {
   int* err = nullptr;                 // device flag: a wait on a peer gave up
   int persist_fallbacks = 0;          // solves restarted on the two-kernel iteration after a persistent segment failed
   long long persist_iterations = 0;   // CG iterations executed inside persistent slab segments
+  long long verify_runs = 0;          // slab solves checked against the true residual after persistent segments ...
+  int verify_failures = 0;            // ... and found wanting on some rank: restarted on the two-kernel iteration
 };
 
 inline PeerView make_view(const PisoComm* pc, bool periodic_y) {

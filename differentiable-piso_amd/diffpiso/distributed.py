@@ -102,10 +102,11 @@ class SlabCommunicator(object):
             raise ValueError("transport must be 'peer' or 'rccl'")
 
     def stats(self):
-        out = (C.c_longlong * 4)()
+        out = (C.c_longlong * 6)()
         N.check(N.lib.piso_comm_stats(self.handle, out), "piso_comm_stats")
         return {"transport": {1: "rccl", 2: "peer"}[int(out[0])], "persistent_iterations": int(out[1]),
-                "persistent_fallbacks": int(out[2]), "persistent_launches": int(out[3])}
+                "persistent_fallbacks": int(out[2]), "persistent_launches": int(out[3]),
+                "solves_verified": int(out[4]), "verification_failures": int(out[5])}
 
     def close(self):
         if self.handle:

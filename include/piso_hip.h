@@ -231,12 +231,14 @@ int piso_conv2d_wgrad(const float* in, const float* grad_out, float* dw, int H, 
  *   x_out_global  [world*ny_local*nx] or NULL (RCCL transport): every rank receives the full solution (all-gather).
  * piso_cg_solve_slab_emulated_f64 runs `slabs` virtual ranks on ONE device in lock-step with an in-process loopback: same
  * kernels, same halo / partial-sum logic; it exists to test the multi-rank index logic of the two-kernel iteration on one GPU.
- * piso_comm_stats: out4 = {transport (1 RCCL, 2 peer), CG iterations executed inside persistent slab segments, solves restarted
- * on the two-kernel iteration, persistent launches}.
+ * piso_comm_stats: out6 = {transport (1 RCCL, 2 peer), CG iterations executed inside persistent slab segments, solves restarted
+ * on the two-kernel iteration, persistent launches, slab solves verified against the true residual b - A^ x after persistent
+ * segments (every one is; the check needs the neighbours' edge rows of x and covers what crossed xGMI), checks that failed on
+ * some rank (all ranks then restart together)}.
  * ------------------------------------------------------------------------------------------------------------- */
 int piso_comm_peer_create(int rank, int world, int row_capacity, void** comm_out, void* ipc_handle64_out);
 int piso_comm_peer_connect(void* comm, const void* ipc_handles64_all_ranks);
-int piso_comm_stats(void* comm, long long* out4);
+int piso_comm_stats(void* comm, long long* out6);
 /* Slab-decomposed ILU(0)-BiCGStab (peer transport): same arguments as piso_multi_bicgstab_ilu_*, all arrays FULL on every rank
  * (the assembly is cheap and replicated); the rank works on the face rows of its ny / world cell rows, which must be whole
  * preconditioner bands (ny / world a multiple of the band height: then the banded ILU(0) is the single-GPU one and the iterates

@@ -54,6 +54,7 @@ def test_slab_cg_over_processes(world, nx, ny, walls):
         # the NORMAL iterations really ran inside the persistent slab kernel, and no segment had to be repeated
         assert r["stats"]["transport"] == "peer"
         assert r["stats"]["persistent_iterations"] > 150 and r["stats"]["persistent_fallbacks"] == 0, r["stats"]
+        assert r["stats"]["solves_verified"] >= 5 and r["stats"]["verification_failures"] == 0, r["stats"]   # r == b - A^ x checked per solve
     # every rank took the same decisions
     assert len({tuple(r["persistent"]["converged_its"]) for r in res}) == 1
 

@@ -122,5 +122,16 @@ def test_peer_transport_one_rank_persistent_slab_kernel(n, walls, piso_option):
         assert float((xa - xb).abs().max() / xa.abs().max()) <= 1e-3
         st = comm.stats()
         assert st["persistent_iterations"] > 150 and st["persistent_fallbacks"] == 0, st
+        # every solve that ran persistent segments was checked against the true residual b - A^ x, and passed
+        assert st["solves_verified"] >= 5 and st["verification_failures"] == 0, st
+        # a failed check (forced through the test knob) restarts the solve on the two-kernel iteration: same answer as that path
+        piso_option("cg_verify", 2)
+        xc, itc = cg_solve_slab(comm, n, n, per, per, L, b, 1e-30, 45, False, 1000)
+        st2 = comm.stats()
+        assert st2["verification_failures"] == 1 and st2["persistent_fallbacks"] == 1, st2
+        piso_option("cg_verify", -1)
+        piso_option("cg_persist", 0)
+        xd, itd = cg_solve_slab(comm, n, n, per, per, L, b, 1e-30, 45, False, 1000)
+        assert itc == itd == 45 and float((xc - xd).abs().max()) == 0.0
     finally:
         comm.close()
