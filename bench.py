@@ -54,7 +54,9 @@ PERSIST_PUBLISHED_VECTORS = {1: 1, 2: 2}   # exchanges per iteration -> vectors 
 # floors of one persistent iteration (scripts/barrier_bench.hip, scripts/fp64_rate.hip measured on MI355X)
 EXCHANGE_US = 4.4            # one tagged-record grid exchange over 256 workgroups
 FP64_ISSUE_CYCLES = 4.75     # cycles per fp64 VALU instruction per SIMD with two waves resident
-FP64_INSTR_PER_CELL = {1: 40, 2: 38}   # two stencil passes (2 x 13: 4 cvt, 4 diagonal, 5 fma) + vector updates / sums (14 | 12)
+FP64_INSTR_PER_CELL = {1: 33.25, 2: 38}   # counted in the ISA of cg_persist1: 1064 fp64 add / fma per wave and iteration, 32 cells per lane
+VALU_INSTR_PER_CELL = {1: 75.2, 2: None}   # ... of 2407 VALU instructions in all (conversions, DPP shifts, lane reads, moves): EVERY
+                                           # VALU instruction of a 64-wide wave costs ~4.5 SIMD cycles (scripts/fp64_rate.hip)
 CLOCK_GHZ = 2.4
 
 
@@ -239,7 +241,7 @@ def cpu_baseline(P, n, tol, cg_iters_per_step, bicg_solves_per_step=2, sample_it
 
 def kernel_source_sha():
     h = hashlib.sha256()
-    for f in ("cg_persist.h", "cg_kernels.h", "cg.hip"):
+    for f in ("cg_persist.h", "cg_persist1.h", "cg_kernels.h", "cg.hip", "peer.h"):
         with open(os.path.join(ROOT, "differentiable-piso_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -345,7 +347,11 @@ def slab_self_check(n, device, rank, world, iters=300, share_gpu=False):
             ok = ok and weak["max_rel_diff_vs_single_gpu_tall_grid"] < 1e-8
             del L_tall, b_tall, xt
         out["weak"] = weak
-        out["persistent_fallbacks"] = comm.stats()["persistent_fallbacks"]
+        st = comm.stats()
+        out["persistent_fallbacks"] = st["persistent_fallbacks"]
+        out["solves_verified_against_true_residual"] = st["solves_verified"]     # every slab solve with persistent segments is
+        out["verification_failures"] = st["verification_failures"]                # checked: r == b - A^x incl. what crossed xGMI
+        ok = ok and st["verification_failures"] == 0
         # ---- the RCCL transport on the same strong system (needs one GPU per rank)
         if not share_gpu:
             rc = SlabCommunicator(rank=rank, world=world, device=device, transport="rccl")
@@ -457,6 +463,8 @@ def main():
             floors = {"fabric_bytes_at_hbm_peak": fabric_b * ncell / (HBM_PEAK_GBS * 1e9) * 1e6,
                       "fp64_valu_issue": FP64_INSTR_PER_CELL[exchanges] * ncell / 256 / 64 / 4 * FP64_ISSUE_CYCLES / (CLOCK_GHZ * 1e3),
                       "grid_exchanges": exchanges * EXCHANGE_US}
+            if VALU_INSTR_PER_CELL.get(exchanges):   # what THIS instruction stream needs (not a floor of the algorithm: reported beside them)
+                floors["valu_issue_of_the_compiled_loop"] = VALU_INSTR_PER_CELL[exchanges] * ncell / 256 / 64 / 4 * 4.5 / (CLOCK_GHZ * 1e3)
             serial_floor = floors["fp64_valu_issue"] + floors["grid_exchanges"]   # the exchange cannot overlap the arithmetic it feeds
             roofline = {"bound": "hbm",
                         "kernel": "cg_persist (one launch = %.0f CG iterations: r, p in registers, x in LDS, float coefficients "
