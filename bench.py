@@ -611,6 +611,32 @@ def other_configs(device):
     torch.cuda.synchronize()
     res["config3_512x256_fwd_adjoint_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / 4
     res["config3_last_cg_iterations_fwd_adjoint"] = [P3["ps"].last_iterations, P3["ps"].last_adjoint_iterations]
+    # config 5's grid on ONE GPU: the state of a 4096^2 solve (3 x 134 MB) does not fit the chip, so the CG runs the two-kernel
+    # iteration (cg_k1 / cg_k2) -- the case the 8-slab decomposition is for (8 slabs of 4096 x 512 fit their GPUs' registers + LDS)
+    import ctypes as C
+    import diffpiso._native as N
+    from diffpiso.solvers import laplace_matrix_native
+    n5 = 4096
+    g = torch.Generator(device="cpu")
+    g.manual_seed(5)
+    a0 = 0.5 + torch.rand(n5 * (n5 + 1) + (n5 + 1) * n5, generator=g)
+    av, au = a0[:n5 * (n5 + 1)].view(n5 + 1, n5), a0[n5 * (n5 + 1):].view(n5, n5 + 1)
+    av[n5] = av[0]
+    au[:, n5] = au[:, 0]
+    ones = torch.ones((n5 + 2) * (n5 + 2), device=device)
+    L = laplace_matrix_native(n5, n5, ones, ones, a0.to(device), torch.float64)
+    b = torch.randn(n5 * n5, generator=g, dtype=torch.float64).to(device)
+    b -= b.mean()
+    x = torch.empty_like(b)
+    ws = N.workspace(N.lib.piso_cg_workspace_bytes(n5, n5, 8), device, "cg")
+    ms = (C.c_float * 2)()
+    for _ in range(2):
+        N.check(N.lib.piso_cg_fixed_iterations_f64(n5, n5, 1, 1, N.ptr(L), N.ptr(b), N.ptr(x), 1, 50, ms, N.ptr(ws), C.c_size_t(ws.numel()),
+                                                   N.stream_ptr()), "piso_cg_fixed_iterations_f64")
+    torch.cuda.synchronize()
+    k1, k2 = 1e3 * ms[0], 1e3 * ms[1]
+    res["config5_4096x4096_one_gpu_two_kernel_cg_us_per_iteration"] = k1 + k2
+    res["config5_4096x4096_one_gpu_cg_algorithmic_GBs"] = CG_BYTES_PER_CELL_ITER * n5 * n5 / ((k1 + k2) * 1e-6) / 1e9 if k1 + k2 > 0 else None
     return res
 
 
