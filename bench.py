@@ -367,6 +367,40 @@ def slab_self_check(n, device, rank, world, iters=300, share_gpu=False):
                 ok = ok and d_rccl < 1e-8
             finally:
                 rc.close()
+        # ---- BASELINE config 5 as a whole step: decaying turbulence 4096^2 cut into `world` slabs, one PISO step forward + reverse
+        # sweep with both linear solvers decomposed (bounded iteration count), against the same step on one GPU (every rank runs it)
+        leg5 = os.environ.get("PISO_BENCH_CONFIG5_LEG", "1")          # "0": skip; "force": also with ranks that share a GPU (tests)
+        if 4096 % world == 0 and (4096 // world) % 32 == 0 and (leg5 == "force" or (leg5 != "0" and not share_gpu)):
+            P5 = build_problem(4096, device, 1e-6, 100, 1000)
+            run_unrolled(P5, 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, loss1, _ = run_unrolled(P5, 1)
+            torch.cuda.synchronize()
+            t_one = time.perf_counter() - t0
+            c5 = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=3 * 4096 + 8)
+            try:
+                P5["ps"].slab_comm = c5
+                P5["lin"].slab_comm = c5
+                run_unrolled(P5, 1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, lossN, _ = run_unrolled(P5, 1)
+                torch.cuda.synchronize()
+                t_dec = time.perf_counter() - t0
+                st5 = c5.stats()
+            finally:
+                P5["ps"].slab_comm = None
+                P5["lin"].slab_comm = None
+                c5.close()
+            rel = abs(lossN - loss1) / abs(loss1)
+            out["config5_step"] = {"grid": [4096, 4096], "slabs": world, "max_iterations": 100, "ms_per_step_one_gpu": 1e3 * t_one,
+                                   "ms_per_step_decomposed": 1e3 * t_dec, "loss_rel_diff": rel,
+                                   "persistent_slab_iterations": st5["persistent_iterations"], "verification_failures": st5["verification_failures"],
+                                   "note": "pressure CG (persistent slab kernel) and ILU(0)-BiCGStab decomposed, assembly / glue replicated, "
+                                           "solver outputs all-gathered through torch.distributed"}
+            ok = ok and rel < 1e-5 and st5["verification_failures"] == 0
+            del P5
         out["ok"] = bool(ok)
         return out
     finally:
@@ -557,12 +591,12 @@ def main():
 
         def give_up():
             if rank == 0 and out is not None:
-                out["slab_cg_self_check"] = {"ok": False, "error": "timed out after 240 s"}
+                out["slab_cg_self_check"] = {"ok": False, "error": "timed out after 420 s"}
                 print(json.dumps(out), flush=True)
             sys.stderr.write("slab_cg_self_check timed out\n")
             sys.stderr.flush()
             os._exit(3)
-        timer = threading.Timer(240.0, give_up)
+        timer = threading.Timer(420.0, give_up)
         timer.daemon = True
         timer.start()
         try:
