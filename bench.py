@@ -54,8 +54,8 @@ PERSIST_PUBLISHED_VECTORS = {1: 1, 2: 2}   # exchanges per iteration -> vectors 
 # floors of one persistent iteration (scripts/barrier_bench.hip, scripts/fp64_rate.hip measured on MI355X)
 EXCHANGE_US = 4.4            # one tagged-record grid exchange over 256 workgroups
 FP64_ISSUE_CYCLES = 4.75     # cycles per fp64 VALU instruction per SIMD with two waves resident
-FP64_INSTR_PER_CELL = {1: 33.25, 2: 38}   # counted in the ISA of cg_persist1: 1064 fp64 add / fma per wave and iteration, 32 cells per lane
-VALU_INSTR_PER_CELL = {1: 75.2, 2: None}   # ... of 2407 VALU instructions in all (conversions, DPP shifts, lane reads, moves): EVERY
+FP64_INSTR_PER_CELL = {1: 29.2, 2: 38}   # counted in the ISA of cg_persist1: 935 fp64 add / fma per wave and iteration, 32 cells per lane
+VALU_INSTR_PER_CELL = {1: 63.6, 2: None}   # ... of 2034 VALU instructions in all (conversions, DPP shifts, lane reads, moves): EVERY
                                            # VALU instruction of a 64-wide wave costs ~4.5 SIMD cycles (scripts/fp64_rate.hip)
 CLOCK_GHZ = 2.4
 

@@ -70,6 +70,7 @@ inline PersistShape persist_shape(int nx, int ny, int V, int cus, int force_r) {
 struct SlabCtl {
   PeerView pv;
   double ncells;           // cells of the GLOBAL grid
+  char *rows_own, *rows_lo, *rows_hi;   // the row areas (PeerLayout::kRows) of my mailbox and of the lower / upper neighbour's
 };
 
 // coefficient rows in flight per wave (A/B builds: -DPISO_PERSIST1_DEPTH=n + scripts/sweep_libs.sh).  Measured at 2048^2 / 1024^2:
@@ -91,6 +92,45 @@ constexpr int kX1RecWords = 16;                  // 8-byte words per record: 2 p
 // per lane, one round trip once the records are there.  Lane pairs (2 q, 2 q + 1) hold the two halves of sum q.
 constexpr int kX1Sm = 160;                        // LDS words per parity: [8 sums][8 waves] | [8 waves][8 sums] | 8 flags
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+
+// ---- wave-level reductions of the exchange on as few VALU instructions as possible (the row loops around the exchange are
+// bound by VALU issue, and every instruction of a 64-wide wave costs the same ~4.5 SIMD cycles whatever it does).
+// 64-bit moves between lanes: DPP inside a row of 16 lanes (VALU, two instructions), the LDS crossbar (ds_bpermute: no VALU
+// slot) across rows.
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_update(double old, double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v), o = (unsigned long long)__double_as_longlong(old);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)o, (int)(unsigned)b, CTRL, 0xf, BANK, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(o >> 32), (int)(unsigned)(b >> 32), CTRL, 0xf, BANK, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double lanes_xor4(double v) {    // lane l <- lane l ^ 4: row_shl:4 into banks 0, 2 / row_shr:4 into banks 1, 3
+  return dpp_update<0x114, 0xa>(dpp_update<0x104, 0x5>(v, v), v);
+}
+__device__ __forceinline__ double lanes_xor8(double v) { return dpp_move<0x128>(v); }                  // row_ror:8
+__device__ __forceinline__ double lanes_xor16(double v) { return __shfl_xor(v, 16, 64); }            // (ds_bpermute_b32 x 2)
+__device__ __forceinline__ double lanes_xor32(double v) { return __shfl_xor(v, 32, 64); }
+// Eight per-lane partial sums -> lane l holds the WAVE total of value l & 7.  Reduce-scatter butterfly over lane bits 0, 1, 2 (a
+// lane keeps half of its values and receives the partner's contribution to them: 7 + 7 + ... instructions instead of three full
+// butterflies of eight values), then plain butterflies of the ONE remaining value over bits 3 (DPP), 4 and 5 (LDS crossbar).
+// ~56 VALU instructions; eight wave_sum_uniform calls are ~190.  Every step adds a lane's value and its partner's: both lanes of
+// a pair compute a + b and b + a - the same bits.
+__device__ __forceinline__ double wave_reduce_scatter8(const double (&v)[8]) {
+  const int lane = threadIdx.x & 63;
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0, b2 = (lane & 4) != 0;
+  double a[4], b[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)                                // a[j]: value 2 j + b0, summed over lane pairs
+    a[j] = (b0 ? v[2 * j + 1] : v[2 * j]) + dpp_move<0xB1>(b0 ? v[2 * j] : v[2 * j + 1]);      // quad_perm [1,0,3,2]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)                                // b[m]: value 4 m + 2 b1 + b0, summed over quads
+    b[m] = (b1 ? a[2 * m + 1] : a[2 * m]) + dpp_move<0x4E>(b1 ? a[2 * m] : a[2 * m + 1]);      // quad_perm [2,3,0,1]
+  double c = (b2 ? b[1] : b[0]) + lanes_xor4(b2 ? b[0] : b[1]);                                 // value l & 7, summed over 8 lanes
+  c += lanes_xor8(c);
+  c += lanes_xor16(c);
+  c += lanes_xor32(c);
+  return c;
+}
 template <typename T, typename F = NoPrefetch>
 __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Values], unsigned epoch, T* smem,
                                                F after_drain = F(), unsigned long long* tsub = nullptr) {
@@ -105,11 +145,12 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
   static_assert(kPersistMaxGrid == kPersistWaves * 32 && (kPersistWaves & (kPersistWaves - 1)) == 0, "every wave polls 32 records");
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   T* sm = smem + (epoch & 1) * kX1Sm;                       // parity double buffer: two __syncthreads per exchange
+  {
+    double vd[NV];
 #pragma unroll
-  for (int q = 0; q < NV; ++q) v[q] = (T)wave_sum_uniform((double)v[q]);
-  if (lane == 0) {
-#pragma unroll
-    for (int q = 0; q < NV; ++q) sm[q * kPersistWaves + wave] = v[q];
+    for (int q = 0; q < NV; ++q) vd[q] = (double)v[q];
+    const double mine = wave_reduce_scatter8(vd);              // lane l: value l & 7, summed over this wave
+    if (lane < NV) sm[lane * kPersistWaves + wave] = (T)mine;
   }
   // EVERY vector-memory operation of this wave has completed - in particular its write-through perimeter stores - before the
   // workgroup's record says so.  (A counted wait that lets the two prefetch loads issued behind the last store stay in flight
@@ -168,11 +209,9 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
       const u64 bits = (w[i] >> 32) | ((u64)hi_other << 32);
       acc += __longlong_as_double((long long)bits);          // (odd lanes add garbage that nobody reads; absent records add 0)
     }
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const double t = ((read_lane_c(acc, 2 * q) + read_lane_c(acc, 16 + 2 * q)) + read_lane_c(acc, 32 + 2 * q)) + read_lane_c(acc, 48 + 2 * q);
-      if (lane == 0) sm[64 + wave * NV + q] = (T)t;
-    }
+    acc += lanes_xor16(acc);                                 // the four records-per-instruction groups of lanes (LDS crossbar)
+    acc += lanes_xor32(acc);
+    if (lane < 2 * NV && !(lane & 1)) sm[64 + wave * NV + (lane >> 1)] = (T)acc;   // this wave's 32 records, value lane / 2
     if (lane == 0) {
       sm[128 + wave] = good ? (T)0 : (T)1;
       if (!good) *c.err = 1;
@@ -180,13 +219,18 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
   }
   __syncthreads();
   tsplit(3);
+  {
+    // one read fetches all 8 x 8 wave sums (lane l: wave l / 8, value l % 8); butterflies over the wave index leave every lane
+    // with the total of value l % 8 - the same bits in every wave of every workgroup (same inputs, same order)
+    double t = (double)sm[64 + lane];
+    t += lanes_xor8(t);
+    t += lanes_xor16(t);
+    t += lanes_xor32(t);
 #pragma unroll
-  for (int q = 0; q < NV; ++q) {
-    T t = 0;
-    for (int w = 0; w < kPersistWaves; ++w) t += sm[64 + w * NV + q];
-    v[q] = uniform(t);
+    for (int q = 0; q < NV; ++q) v[q] = (T)read_lane_c(t, q);
+    const T bad = sm[128 + (lane & (kPersistWaves - 1))];
+    good = !__any(bad != (T)0);
   }
-  for (int w = 0; w < kPersistWaves; ++w) good = good && (uniform(sm[128 + w]) == (T)0);
   return good;
 }
 
@@ -236,11 +280,9 @@ __device__ __forceinline__ bool xgpu_exchange8(const PeerView& pv, T (&v)[kX1Val
       const unsigned hi_other = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(w[i] >> 32), 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
       acc += __longlong_as_double((long long)((w[i] >> 32) | ((peer_u64)hi_other << 32)));   // (odd lanes: garbage nobody reads)
     }
-#pragma unroll
-    for (int q = 0; q < kX1Values; ++q) {
-      const double t = ((read_lane_c(acc, 2 * q) + read_lane_c(acc, 16 + 2 * q)) + read_lane_c(acc, 32 + 2 * q)) + read_lane_c(acc, 48 + 2 * q);
-      if (lane == 0) smx[q] = (T)t;
-    }
+    acc += lanes_xor16(acc);                                 // ranks r, r + 1, r + 2, r + 3 (+ 4) sit in the four rows of lanes
+    acc += lanes_xor32(acc);
+    if (lane < 2 * kX1Values && !(lane & 1)) smx[lane >> 1] = (T)acc;
     if (lane == 0) smx[kX1Values] = good ? (T)0 : (T)1;
   }
   __syncthreads();
@@ -334,14 +376,13 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
 #pragma unroll
   for (int q = 0; q < NQ; ++q) { bot[q] = SLAB && has[q] && j0[q] == 0; top[q] = SLAB && has[q] && j0[q] + R == ny; }
   bool nb_lo = false, nb_hi = false;
-  rsrc_t Rmb, Rmlo, Rmhi;                                   // the rows of my mailbox and of the neighbours' mailboxes
+  // (mailbox resources are built from the kernel arguments where they are used - only the edge waves touch them, and 12 SGPRs
+  // held across the loop come back as v_readlane reloads in every wave)
   const unsigned nbytesH = nbytesT + 2 * rowT;              // r / p[] including their halo rows (resources built where they are used)
+  unsigned mbz = 0;                                         // the eight rows of a mailbox (host-level exchange + z' halos)
   if constexpr (SLAB) {
     nb_lo = sl.pv.lower >= 0; nb_hi = sl.pv.upper >= 0;
-    const unsigned mbz = (unsigned)(8 * sl.pv.row_cap * 8);  // the eight rows of a mailbox (host-level exchange + z' halos)
-    Rmb = make_rsrc(sl.pv.mbox[sl.pv.rank] + PeerLayout::kRows, mbz);
-    Rmlo = make_rsrc(sl.pv.mbox[nb_lo ? sl.pv.lower : sl.pv.rank] + PeerLayout::kRows, mbz);
-    Rmhi = make_rsrc(sl.pv.mbox[nb_hi ? sl.pv.upper : sl.pv.rank] + PeerLayout::kRows, mbz);
+    mbz = (unsigned)(8 * sl.pv.row_cap * 8);
   }
   // byte offset of z' halo row (parity, side) inside the rows of a mailbox
   auto zrow_off = [&](int parity, int side) __attribute__((always_inline)) -> unsigned {
@@ -566,8 +607,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       bst<T, V, kAgent>(Rd, vT[q], sT, val);
       if constexpr (SLAB) {
         // my first row is the row ABOVE the lower neighbour's slab (its side 1), my last row the row BELOW the upper one's (side 0)
-        if (jj == 0 && bot[q] && nb_lo) bst<T, V, kSystem>(Rmlo, vT[q], zoff_lo, val);
-        if (jj == R - 1 && top[q] && nb_hi) bst<T, V, kSystem>(Rmhi, vT[q], zoff_hi, val);
+        if (jj == 0 && bot[q] && nb_lo) bst<T, V, kSystem>(make_rsrc(sl.rows_lo, mbz), vT[q], zoff_lo, val);
+        if (jj == R - 1 && top[q] && nb_hi) bst<T, V, kSystem>(make_rsrc(sl.rows_hi, mbz), vT[q], zoff_hi, val);
       }
     } else {
       if (lane == 0) bst1<T, kAgent>(Rd, vT[q], sT, val.v[0]);
@@ -581,8 +622,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   auto issue_halos = [&](rsrc_t Rz) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      int side, er;
-      ring_lane(lane, R, side, er);
+      int side, er, lane_now = lane;
+      if constexpr (SLAB) asm volatile("" : "+v"(lane_now));
+      ring_lane(lane_now, R, side, er);
       int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
       if (cc < 0) cc = a.per_x ? nx - 1 : -1;
       else if (cc >= nx) cc = a.per_x ? 0 : -1;
@@ -595,9 +637,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
 #pragma unroll
         for (int e = 0; e < V; ++e) { hbZ[q].v[e] = 0; haZ[q].v[e] = 0; }
         if (!bot[q]) hbZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] - 1) * rowT);
-        else if (nb_lo) hbZ[q] = bld<T, V, kSystem>(Rmb, vT[q], zoff_b);
+        else if (nb_lo) hbZ[q] = bld<T, V, kSystem>(make_rsrc(sl.rows_own, mbz), vT[q], zoff_b);
         if (!top[q]) haZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] + R) * rowT);
-        else if (nb_hi) haZ[q] = bld<T, V, kSystem>(Rmb, vT[q], zoff_a);
+        else if (nb_hi) haZ[q] = bld<T, V, kSystem>(make_rsrc(sl.rows_own, mbz), vT[q], zoff_a);
       } else {
       hbZ[q] = bld<T, V, kAgent>(Rz, hb, (unsigned)jb * rowT);
       haZ[q] = bld<T, V, kAgent>(Rz, ha, (unsigned)ja * rowT);
@@ -735,8 +777,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           rhb[q].v[e] = fma(-alpha, hbZ[q].v[e] + vsb, rhb[q].v[e]);
           rha[q].v[e] = fma(-alpha, haZ[q].v[e] + vsa, rha[q].v[e]);
         }
-        int side, er_unused;
-        ring_lane(lane, R, side, er_unused);
+        int side, er_unused, lane_now = lane;
+        if constexpr (SLAB) asm volatile("" : "+v"(lane_now));   // (slab variant: recomputed here instead of a register held across the loop)
+        ring_lane(lane_now, R, side, er_unused);
         const T vse = (side == 0) ? (vl[q] ? vs : (T)0) : ((side == 1) ? (vr[q] ? vs : (T)0) : (T)0);
         eR[q] = fma(-alpha, eZ[q] + vse, eR[q]);
       }

@@ -351,6 +351,9 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
       PISO_HIP_CHECK(hipMemsetAsync(persist_ws, 0, kSlabPersistWsWords * sizeof(unsigned), stream));
       sl.pv = make_view(comm.rccl, comm.periodic_y);
       sl.ncells = global_cells;
+      sl.rows_own = sl.pv.mbox[sl.pv.rank] + PeerLayout::kRows;
+      sl.rows_lo = sl.pv.mbox[sl.pv.lower >= 0 ? sl.pv.lower : sl.pv.rank] + PeerLayout::kRows;
+      sl.rows_hi = sl.pv.mbox[sl.pv.upper >= 0 ? sl.pv.upper : sl.pv.rank] + PeerLayout::kRows;
     }
   }
   int seg_len = (int)(20000.0 / ((double)R[0].a.nx * R[0].a.ny * 8.5e-6 + 4.0));   // ~20 ms of work per segment
