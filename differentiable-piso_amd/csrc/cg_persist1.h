@@ -297,7 +297,7 @@ __device__ __forceinline__ bool xgpu_exchange8(const PeerView& pv, T (&v)[kX1Val
 // lane j to lane 0 (row_shl:j) or lane 48 + j to lane 63 (row_shr:15-j), the wave shift keeps it there.  2 VALU instructions
 // per 32-bit half - through v_readlane + v_mov (SGPR broadcast) it was 3, and the loop is bound by VALU issue.
 template <int CTRL>
-__device__ __forceinline__ int dpp_mov32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_mov32(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }   // (no `old` operand to set up)
 template <bool UP>
 __device__ __forceinline__ int ring_to_end32(int ring, int j) {     // j: constant after unrolling
   if (UP) {
@@ -611,8 +611,12 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         if (jj == R - 1 && top[q] && nb_hi) bst<T, V, kSystem>(make_rsrc(sl.rows_hi, mbz), vT[q], zoff_hi, val);
       }
     } else {
-      if (lane == 0) bst1<T, kAgent>(Rd, vT[q], sT, val.v[0]);
-      if (lane == 63) bst1<T, kAgent>(Rd, vT[q] + (unsigned)((V - 1) * sizeof(T)), sT, val.v[V - 1]);
+      // the two end cells of the row in ONE store: lane 0 its first cell, lane 63 its last (two separately predicated stores cost
+      // two exec round trips and a handful of register copies per row)
+      const bool last = lane == 63;
+      const T dat = last ? val.v[V - 1] : val.v[0];
+      const unsigned off = vT[q] + (last ? (unsigned)((V - 1) * sizeof(T)) : 0u);
+      if (lane == 0 || last) bst1<T, kAgent>(Rd, off, sT, dat);
     }
   };
   // ---- z' on the ring, as published by the neighbours (rows below / above, the two neighbouring columns): issued right after
