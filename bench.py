@@ -303,11 +303,30 @@ def slab_self_check(n, device, rank, world, iters=300, share_gpu=False):
         return x, 1e6 * (time.perf_counter() - t0) / iters
 
     out = {"ranks": world, "iterations_timed": iters, "iterations_compared": 100, "grid": [n, n], "transport": "peer mailboxes (hipIpc handles, xGMI peer access)"}
+    def rccl_leg(L, b, xs, own, scale):
+        rc = SlabCommunicator(rank=rank, world=world, device=device, transport="rccl")
+        try:
+            xr, t_rccl = timed(lambda k: cg_solve_slab(rc, n, n, True, True, L, b, 1e-30, k, False, 1 << 30, gather=False))
+            d_rccl = float((xr - xs[own]).abs().max()) / scale
+            return {"us_per_iteration_slab_two_kernel": t_rccl, "max_rel_diff": d_rccl}
+        finally:
+            rc.close()
+
     try:
         comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=n)
     except Exception as e:       # the environment cannot map device memory across processes (no result was computed: not a wrong one)
-        out["ok"] = None
         out["skipped"] = "peer transport could not be set up here: %r" % (e,)
+        out["ok"] = None
+        if not share_gpu:        # the RCCL transport does not need it
+            try:
+                L, b = system(n, n, 1234), rhs(n, n, 99).to(device)
+                j0, j1 = slab_rows(rank, world, n)
+                xs, t_single = timed(lambda k: cg_solve_native(n, n, True, True, L, b, 1e-30, k, False, 1 << 30))
+                out["rccl"] = rccl_leg(L, b, xs, slice(j0 * n, j1 * n), float(xs.abs().max()))
+                out["rccl"]["us_per_iteration_single_gpu"] = t_single
+                out["ok"] = bool(out["rccl"]["max_rel_diff"] < 1e-8)
+            except Exception as e2:
+                out["rccl"] = {"error": repr(e2)}
         return out
     saved = {k: N.get_option(k) for k in ("cg_persist", "cg_persist_r")}
     try:
@@ -359,14 +378,8 @@ def slab_self_check(n, device, rank, world, iters=300, share_gpu=False):
         ok = ok and st["verification_failures"] == 0
         # ---- the RCCL transport on the same strong system (needs one GPU per rank)
         if not share_gpu:
-            rc = SlabCommunicator(rank=rank, world=world, device=device, transport="rccl")
-            try:
-                xr, t_rccl = timed(lambda k: cg_solve_slab(rc, n, n, True, True, L, b, 1e-30, k, False, 1 << 30, gather=False))
-                d_rccl = float((xr - xs[own]).abs().max()) / scale
-                out["rccl"] = {"us_per_iteration_slab_two_kernel": t_rccl, "max_rel_diff": d_rccl}
-                ok = ok and d_rccl < 1e-8
-            finally:
-                rc.close()
+            out["rccl"] = rccl_leg(L, b, xs, own, scale)
+            ok = ok and out["rccl"]["max_rel_diff"] < 1e-8
         # ---- BASELINE config 5 as a whole step: decaying turbulence 4096^2 cut into `world` slabs, one PISO step forward + reverse
         # sweep with both linear solvers decomposed (bounded iteration count), against the same step on one GPU (every rank runs it)
         leg5 = os.environ.get("PISO_BENCH_CONFIG5_LEG", "1")          # "0": skip; "force": also with ranks that share a GPU (tests)
