@@ -22,6 +22,31 @@ def _worker(rank, world, port, q):
         from diffpiso.distributed import all_gather_bytes, exchange_unique_id, max_over_ranks, slab_rows
         handles = all_gather_bytes(bytes([17 * (rank + 1)] * 64), rank, world, torch.device("cpu"))   # mailbox handles (peer transport)
         assert handles == bytes([17] * 64) + bytes([34] * 64), handles
+        # the slab BiCGStab returns valid values on the owned face rows only: the gather that completes the vector
+        from diffpiso.distributed import face_rows_of_rank, gather_face_rows
+
+        class _C(object):
+            pass
+        c = _C()
+        c.rank, c.world = rank, world
+        nx, ny = 6, 8
+        n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
+        x = torch.zeros(n_u + n_v)
+        (u0, u1), (v0, v1) = face_rows_of_rank(rank, world, nx, ny)
+        x[u0:u1] = 10.0 * (rank + 1) + torch.arange(u1 - u0) / 1000.0
+        x[v0:v1] = 100.0 * (rank + 1) + torch.arange(v1 - v0) / 1000.0
+        full = gather_face_rows(c, x, nx, ny)
+        for r in range(world):
+            (a0, a1), (b0, b1) = face_rows_of_rank(r, world, nx, ny)
+            assert torch.equal(full[a0:a1], 10.0 * (r + 1) + torch.arange(a1 - a0) / 1000.0)
+            assert torch.equal(full[b0:b1], 100.0 * (r + 1) + torch.arange(b1 - b0) / 1000.0)
+        # the ranges of all ranks tile both components exactly once (the duplicate row v[ny] on the last rank)
+        cover = torch.zeros(n_u + n_v)
+        for r in range(world):
+            (a0, a1), (b0, b1) = face_rows_of_rank(r, world, nx, ny)
+            cover[a0:a1] += 1
+            cover[b0:b1] += 1
+        assert bool((cover == 1).all())
         uid = exchange_unique_id(rank, world, torch.device("cpu"),
                                  make_id=lambda: torch.arange(128, dtype=torch.uint8) * 3 + 1)
         rows = slab_rows(rank, world, 64)
