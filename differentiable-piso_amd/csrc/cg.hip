@@ -41,9 +41,35 @@ static int ensure_poll() {
   return PISO_OK;
 }
 
+// Padded-grid mode: a wall-bounded grid the persistent kernel cannot tile (row length not a multiple of 128 cells, rows not a
+// multiple of the region height - e.g. the lid-driven cavity's 64 x 65) is embedded in the next grid it can: zero coefficients
+// and a zero right-hand side keep the padding at zero (the kernels that add the rank-1 shift skip it, cg_kernels.h).  Only for
+// small grids, where two dependent launches per iteration cost ~14 us against ~4 us of a persistent iteration; periodic axes
+// cannot be padded (the wrap partner would move).
+constexpr size_t kPadMaxCells = (size_t)1 << 19;
+static bool padded_dims(int nx, int ny, int per_x, int per_y, int elem, int* nxp, int* nyp) {
+  *nxp = nx; *nyp = ny;
+  if (elem != 8 || nx % 2 != 0 || nx < 8 || ny < 8) return false;
+  // grids the kernel tiles as they are stay as they are: rows of whole 128-cell strips, an even number of rows (regions of 2)
+  const bool pad_x = nx % 128 != 0, pad_y = ny % 2 != 0;
+  if (!pad_x && !pad_y) return false;
+  const int px = (nx + 127) / 128 * 128;
+  int py = (ny + 3) / 4 * 4;                      // rows a multiple of 4: the number of 2-row regions comes out even (two per wave)
+  if (px != nx && per_x) return false;
+  if (py != ny && per_y) {
+    py = ny;                                      // periodic in y: only x is padded, if the region count still works out
+    if (ny % 2 != 0 || ((long long)(px / 128) * (ny / 2)) % 2 != 0) return false;
+  }
+  if ((size_t)px * py > kPadMaxCells) return false;
+  *nxp = px; *nyp = py;
+  return true;
+}
+
 template <typename T>
-static size_t cg_workspace_bytes(int nx, int ny) {
-  const size_t n = (size_t)nx * ny;
+static size_t cg_workspace_bytes(int nx_in, int ny_in) {
+  int nx = nx_in, ny = ny_in;
+  const bool padded = padded_dims(nx_in, ny_in, 0, 0, (int)sizeof(T), &nx, &ny);   // (an upper bound: periodic grids are never padded)
+  const size_t n = (size_t)nx * ny + (padded ? 2 * (size_t)nx * ny : 0);             // + padded copies of b and x
   size_t b = 0;
   b += 11 * align_up(n * sizeof(T), 256);                // diag + 4 off-diagonal arrays (T) + r, z, p0, p1 + the two z' perimeter buffers
   b += align_up(4 * n * sizeof(float), 256) + 256;        // float copy of the off-diagonals + flag
@@ -54,7 +80,16 @@ static size_t cg_workspace_bytes(int nx, int ny) {
 }
 
 template <typename T, typename CT, bool RECON, bool SYMV>
-static const void* persist_kernel(int R, int exchanges) {
+static const void* persist_kernel(int R, int exchanges, bool ragged = false) {
+  if constexpr (sizeof(T) == 8 && RECON && SYMV) {
+    if (ragged && exchanges == 1) {
+      switch (R) {
+        case 2: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 2, RECON, SYMV, false, true>);
+        case 4: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 4, 2, RECON, SYMV, false, true>);
+        default: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 16, 1, RECON, SYMV, false, true>);
+      }
+    }
+  }
   if (exchanges == 1) {
     switch (R) {
       case 2: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 2, RECON, SYMV>);
@@ -145,16 +180,22 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const PersistShape shape = persist_shape(nx, ny, V, cus, force_r);
     persist_R = shape.R; persist_NQ = shape.NQ; persist_grid = shape.grid; pc.nreg = shape.nreg; pc.ntx = shape.ntx;
-    if (persist_R && n < 16384 && force != 1) persist_R = 0;    // tiny grids: two-kernel path
+    if (persist_R && n < 16384 && force != 1 && !a.nx_true) persist_R = 0;    // tiny grids: two-kernel path (a padded grid is here BECAUSE it is small)
   }
   if (persist_R == 8) exchanges = 2;   // (two regions of 8 rows per wave: cg_persist1 spills there; rare shape)
+  const bool ragged = a.nx_true != 0;
+  if (ragged && persist_R) {
+    // the padded-grid variant exists for the common case only: fp64 state, one exchange, exact-float symmetric coefficients
+    constexpr bool kRaggedKernel = RECON && sizeof(CT) == 4 && sizeof(T) == 8;
+    if (!kRaggedKernel || !symmetric || exchanges != 1 || persist_R == 8) persist_R = 0;
+  }
   if (persist_R) {
     // the exchanges spin: EVERY workgroup must be resident at the same time.  What the occupancy calculator says one CU can
     // hold (LDS, registers) times the CUs of the device must cover the grid; what it cannot see (another process, a CU mask)
     // is caught by the spin bound -> restart on the two-kernel path (below).
     constexpr bool kCanSymO = RECON && sizeof(CT) == 4;
     const void* kfn = persist_kernel<T, CT, RECON, false>(persist_R, exchanges);
-    if constexpr (kCanSymO) { if (symmetric) kfn = persist_kernel<T, CT, RECON, true>(persist_R, exchanges); }
+    if constexpr (kCanSymO) { if (symmetric) kfn = persist_kernel<T, CT, RECON, true>(persist_R, exchanges, ragged); }
     int per_cu = 0, dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -178,6 +219,15 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     pc.epoch0 = (g_persist_launches.fetch_add(1, std::memory_order_relaxed) & 0xffffu) << 16;
     PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 128, stream));
     constexpr bool kCanSym = RECON && sizeof(CT) == 4;     // the symmetric variant exists for the compact coefficient path
+    if constexpr (kCanSym && sizeof(T) == 8) {
+      if (ragged) {                                          // padded-grid mode (symmetric, one exchange: checked above)
+        if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, true, false, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
+        else if (persist_R == 4) cg_persist1<T, CT, 4, 2, RECON, true, false, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
+        else cg_persist1<T, CT, 16, 1, RECON, true, false, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
+        PISO_LAUNCH_CHECK();
+        return PISO_OK;
+      }
+    }
 #define PISO_PERSIST_LAUNCH(SYMV)                                                                                            \
     do {                                                                                                                     \
       if (exchanges == 1) {                                                                                                  \
@@ -350,6 +400,16 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   return PISO_OK;
 }
 
+// rows of nx elements between arrays of different leading dimensions (padded-grid mode: b in, x out)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void cg_copy_rows(const T* __restrict__ src, T* __restrict__ dst, int nx, int ny, int ld_src, int ld_dst) {
+  const size_t n = (size_t)nx * ny;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const size_t j = i / (size_t)nx, c = i % (size_t)nx;
+    dst[j * (size_t)ld_dst + c] = src[j * (size_t)ld_src + c];
+  }
+}
+
 template <typename T>
 static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b, T* x_out, float accuracy,
                     int max_iterations, int rank_deficient, int reset, int fixed, int* iterations_out,
@@ -363,7 +423,11 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
     return PISO_ERR_INVALID_ARG;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const size_t n = (size_t)nx * ny;
+  const size_t n_true = (size_t)nx * ny;
+  int nxp = nx, nyp = ny;
+  const bool padded = opt(OPT_CG_PERSIST) != 0 && opt(OPT_CG_PAD) != 0 &&
+                      padded_dims(nx, ny, per_x, per_y, (int)sizeof(T), &nxp, &nyp);      // (see padded_dims)
+  const size_t n = (size_t)nxp * nyp;
   Arena ar(ws, ws_bytes);
   CgArgs<T> a;
   T* cC = ar.take<T>(n);
@@ -372,13 +436,16 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   int* flags = ar.take<int>(4);
   a.cC = cC;
   a.b = b; a.x = x_out;
+  T *b_pad = nullptr, *x_pad = nullptr;
+  if (padded) { b_pad = ar.take<T>(n); x_pad = ar.take<T>(n); a.b = b_pad; a.x = x_pad; }
   a.r = ar.take<T>(n); a.z = ar.take<T>(n); a.p[0] = ar.take<T>(n); a.p[1] = ar.take<T>(n);
   a.zp[0] = ar.take<T>(n); a.zp[1] = ar.take<T>(n);
   a.partsA = ar.take<T>(3 * kMaxPartials); a.partsB = ar.take<T>(3 * kMaxPartials); a.partsS = ar.take<T>(kMaxPartials);
   a.scal = ar.take<T>(SC_COUNT);
   a.state = ar.take<CgState>(2);
   unsigned* persist_ws = ar.take<unsigned>(kPersistWsWords);
-  a.nx = nx; a.ny = ny; a.per_x = per_x; a.per_y = per_y;
+  a.nx = nxp; a.ny = nyp; a.per_x = per_x; a.per_y = per_y;
+  a.nx_true = padded ? nx : 0; a.ny_true = padded ? ny : 0; a.ncells = padded ? (double)n_true : 0.0;
   a.ntx = a.nty = a.rows_per_wave = 0; a.nA = a.nB = 0; a.accuracy = accuracy;
   a.gA = nullptr; a.gB = nullptr;
   a.nt = 0;
@@ -387,8 +454,15 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
 
   PISO_HIP_CHECK(hipMemsetAsync(flags, 0, 4 * sizeof(int), stream));
   cg_zero_partials<T><<<(3 * kMaxPartials + 255) / 256, 256, 0, stream>>>(a.partsA, a.partsB, a.partsS);
-  const int gs = grid_for((long long)n, kBlock * 4);
-  cg_setup_coeffs<T><<<gs, kBlock, 0, stream>>>(L, cC, oT, oF, a.partsS, flags, n, nx, ny, per_x, per_y);
+  const int gs = grid_for((long long)n_true, kBlock * 4);
+  if (padded) {                                             // zero coefficients and a zero right-hand side keep the padding at zero
+    PISO_HIP_CHECK(hipMemsetAsync(cC, 0, n * sizeof(T), stream));
+    PISO_HIP_CHECK(hipMemsetAsync(oT, 0, 4 * n * sizeof(T), stream));
+    PISO_HIP_CHECK(hipMemsetAsync(oF, 0, 4 * n * sizeof(float), stream));
+    PISO_HIP_CHECK(hipMemsetAsync(b_pad, 0, n * sizeof(T), stream));
+    cg_copy_rows<T><<<gs, kBlock, 0, stream>>>(b, b_pad, nx, ny, nx, nxp);
+  }
+  cg_setup_coeffs<T><<<gs, kBlock, 0, stream>>>(L, cC, oT, oF, a.partsS, flags, n_true, nx, ny, per_x, per_y, padded ? nxp : 0, padded ? n : 0);
   PISO_LAUNCH_CHECK();
   // The off-diagonals of the PISO pressure matrix are float32 face coefficients (laplace_op.cu.cc:140-177): stored as
   // float they are exact and K1 reads 24 instead of 40 coefficient bytes per cell.  Any other input keeps them in T.
@@ -402,20 +476,29 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   if (opt_on(OPT_CG_NO_SYM)) hflags[2] = 1;
   const bool symmetric = !hflags[2];
   constexpr int VMID = 16 / sizeof(T);
-  const bool aligned = ((reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(x_out)) & 15) == 0;
-  const bool vec = aligned && (nx % VMID == 0);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(a.b) | reinterpret_cast<uintptr_t>(a.x)) & 15) == 0;
+  const bool vec = aligned && (nxp % VMID == 0);
+  int rc = PISO_OK;
 #define PISO_CG_RUN(CT, V, RECON) \
-  return cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream)
+  rc = cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream)
   if (sizeof(T) == 8 && !hflags[0]) {
     a.oS = oF; a.oW = oF + n; a.oE = oF + 2 * n; a.oN = oF + 3 * n;
-    if (!hflags[1]) { if (vec) PISO_CG_RUN(float, VMID, true); PISO_CG_RUN(float, 1, true); }
-    if (vec) PISO_CG_RUN(float, VMID, false);
-    PISO_CG_RUN(float, 1, false);
+    if (!hflags[1]) { if (vec) PISO_CG_RUN(float, VMID, true); else PISO_CG_RUN(float, 1, true); }
+    else if (vec) PISO_CG_RUN(float, VMID, false);
+    else PISO_CG_RUN(float, 1, false);
+  } else {
+    a.oS = oT; a.oW = oT + n; a.oE = oT + 2 * n; a.oN = oT + 3 * n;
+    if (vec) PISO_CG_RUN(T, VMID, false);
+    else PISO_CG_RUN(T, 1, false);
   }
-  a.oS = oT; a.oW = oT + n; a.oE = oT + 2 * n; a.oN = oT + 3 * n;
-  if (vec) PISO_CG_RUN(T, VMID, false);
-  PISO_CG_RUN(T, 1, false);
 #undef PISO_CG_RUN
+  if (rc != PISO_OK) return rc;
+  if (padded) {                                             // (cg_run has synchronised the stream: x_pad is final)
+    cg_copy_rows<T><<<gs, kBlock, 0, stream>>>(x_pad, x_out, nx, ny, nxp, nx);
+    PISO_LAUNCH_CHECK();
+    PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  return PISO_OK;
 }
 
 }  // namespace piso

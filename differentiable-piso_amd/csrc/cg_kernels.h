@@ -57,7 +57,18 @@ struct CgArgs {
   int nA, nB;                        // blocks (= partial records) of K1 / K2
   float accuracy;
   int nt;                            // tuning bits: 1 K2 stores, 2 K2 loads, 4 K1 stores, 8 K1 loads non-temporal
+  // Padded-grid mode (cg.hip): a wall-bounded nx_true x ny_true system embedded in the nx x ny grid the persistent kernel can
+  // tile.  The padding has zero coefficients and a zero right-hand side, so it stays zero by itself - except under the rank-1
+  // shift c sum(p), which the reference adds to EVERY cell: the kernels that apply it skip the padding.  0: not padded.
+  int nx_true, ny_true;
+  double ncells;                     // cells the shift constant and the sum(r) recurrence count (0: nx * ny)
 };
+// is flat cell i of the (possibly padded) grid a cell of the true system?
+template <typename T>
+__device__ __forceinline__ bool true_cell(const CgArgs<T>& a, size_t i) {
+  if (!a.nx_true) return true;
+  return (int)(i % (size_t)a.nx) < a.nx_true && (int)(i / (size_t)a.nx) < a.ny_true;
+}
 
 template <typename T, int V>
 struct Vec {
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(kBlock) void cg_k2(CgArgs<T> a, int k, int sv) {
         Vec<T, V> r0 = rq[d];
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          r0.v[e] = fma(-alpha, zq[d].v[e] + vs, r0.v[e]);
+          r0.v[e] = fma(-alpha, zq[d].v[e] + (true_cell(a, iq[d] + e) ? vs : (T)0), r0.v[e]);
           acc_rz = fma(r0.v[e], zq[d].v[e], acc_rz);
           acc_r += r0.v[e];
           acc_ex += (absval(r0.v[e]) < accuracy) ? (T)0 : (T)1;     // NaN counts as exceeding
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(kBlock) void cg_reset_residual(CgArgs<T> a, int sv)
   const T vs = a.scal[SC_C] * pa[0];
   const size_t n = (size_t)a.nx * a.ny;
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock)
-    a.r[i] = a.b[i] - (a.z[i] + vs);
+    a.r[i] = a.b[i] - (a.z[i] + (true_cell(a, i) ? vs : (T)0));
 }
 
 // L [N][5] -> SoA coefficients (off-diagonals in T and in float); partial sums of |diag| for the shift (cublasDasum,
@@ -513,10 +524,11 @@ __global__ __launch_bounds__(kBlock) void cg_reset_residual(CgArgs<T> a, int sv)
 // flags[2] is set unless the matrix is symmetric bit for bit: N of a cell equals S of the cell above, E equals W of the cell to
 // the right (periodic wrap, or 0 at a wall); nx = 0 skips the check and sets the flag; per_y = 2 (one slab of a decomposed grid)
 // checks the pairs inside the slab only.
+// ldx > 0 (padded-grid mode): the SoA outputs are laid out for a grid of ldx columns and n_out cells (zeroed by the caller).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void cg_setup_coeffs(const T* __restrict__ L, T* cC, T* oT, float* oF, T* parts,
                                                            int* flags, size_t n, int nx = 0, int ny = 0, int per_x = 0,
-                                                           int per_y = 0) {
+                                                           int per_y = 0, int ldx = 0, size_t n_out = 0) {
   __shared__ T smem[16];
   T acc = 0;
   bool bad = false, bad_recon = false, bad_sym = (nx == 0);
@@ -529,12 +541,14 @@ __global__ __launch_bounds__(kBlock) void cg_setup_coeffs(const T* __restrict__ 
       bad_sym |= !(row[3] == e_nb) || !(row[4] == n_nb);      // (per_y = 2, a slab: the last row's N pairs with a remote S - not checked)
     }
     const T o[4] = {row[0], row[1], row[3], row[4]};
-    cC[i] = row[2];
+    const size_t io = ldx ? (i / (size_t)nx) * (size_t)ldx + (i % (size_t)nx) : i;   // where cell i lives in the output layout
+    const size_t no = ldx ? n_out : n;
+    cC[io] = row[2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float f = (float)o[q];
-      oT[q * n + i] = o[q];
-      oF[q * n + i] = f;
+      oT[q * no + io] = o[q];
+      oF[q * no + io] = f;
       bad |= !((T)f == o[q]);
     }
     // can the diagonal be recomputed from the float off-diagonals exactly as calcPISOLaplaceMatrix accumulated it?
@@ -561,6 +575,7 @@ __global__ __launch_bounds__(kBlock) void cg_init(CgArgs<T> a, int rank_deficien
   size_t n = (size_t)a.nx * a.ny;
   double ncells = (double)n;
   if (global_diag_sum) { pa[0] = global_diag_sum[0]; ncells = global_cells; }   // slab mode: all-reduced sum |diag|
+  else if (a.ncells > 0) ncells = a.ncells;                                     // padded-grid mode: the cells of the true system
   for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
     a.x[i] = 0;
     a.r[i] = a.b[i];
@@ -620,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void cg_verify_gap(CgArgs<T> a, const T* pa
     z = fma(a.cC[i], a.x[i], z);
     z = fma((T)oE[i], at(ci + 1, cj), z);
     z = fma((T)oN[i], at(ci, cj + 1), z);
-    const T d = a.b[i] - (z + vs) - a.r[i];
+    const T d = a.b[i] - (z + (true_cell(a, i) ? vs : (T)0)) - a.r[i];
     const float g = (float)absval(d), sc = (float)absval(a.b[i]);
     if (g == g) gap = g > gap ? g : gap;                 // (NaN data: nothing to verify - the solve reports NaN as the reference does)
     if (sc == sc) scale = sc > scale ? sc : scale;

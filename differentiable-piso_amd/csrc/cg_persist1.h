@@ -343,9 +343,12 @@ __device__ __forceinline__ void ring_lane(int lane, int R, int& side, int& er) {
 
 constexpr int kSystem = 17;                       // buffer cache policy sc0 | sc1: system scope (peer-mapped mailboxes)
 
-template <typename T, typename CT, int R, int NQ, bool RECON, bool SYM, bool SLAB = false>
+// RAGGED = true: padded-grid mode (CgArgs::nx_true / ny_true): the rank-1 shift skips the cells of the padding - everything else
+// about them is zero by construction (zero coefficients, zero right-hand side).
+template <typename T, typename CT, int R, int NQ, bool RECON, bool SYM, bool SLAB = false, bool RAGGED = false>
 __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, PersistCtl c, int k_begin, int k_end, int sv, int pend,
                                                                std::conditional_t<SLAB, SlabCtl, NoSlab> sl = {}) {
+  static_assert(!(SLAB && RAGGED), "a slab is never padded");
   constexpr int V = 16 / sizeof(T);                        // 16-byte lane accesses
   static_assert(R * NQ <= 16 && 2 * R <= 64, "at most 16 rows per wave; the edge columns of a region fit one wave-wide load");
   static_assert(!SLAB || sizeof(T) == 8, "mailbox rows hold 8-byte elements");
@@ -478,6 +481,15 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   const T sc_c = uniform(a.scal[SC_C]);
   T ncells = (T)((double)nx * (double)ny);
   if constexpr (SLAB) ncells = (T)sl.ncells;
+  if constexpr (RAGGED) ncells = (T)a.ncells;
+  // RAGGED: are my columns / the columns next to my strip / the rows around my regions cells of the true system?
+  bool col_ok[NQ], lcol_ok[NQ], rcol_ok[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    col_ok[q] = !RAGGED || (tx0[q] * 64 + lane) * V < a.nx_true;         // (nx_true is a multiple of V: a lane's cells are all in or all out)
+    lcol_ok[q] = !RAGGED || tx0[q] * 64 * V - 1 < a.nx_true;
+    rcol_ok[q] = !RAGGED || (tx0[q] + 1) * 64 * V < a.nx_true;
+  }
   // totals of the previous K2 (or previous segment): r.z', sum r, #cells with |r| >= accuracy
   T tB[3];
   {
@@ -762,7 +774,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         stv<T, V>(xl, xv);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-          const T rn = fma(-alpha, z.v[e] + vs, rr[q][jj].v[e]);
+          T vsc = vs;
+          if constexpr (RAGGED) vsc = (col_ok[q] && j0[q] + jj < a.ny_true) ? vs : (T)0;
+          const T rn = fma(-alpha, z.v[e] + vsc, rr[q][jj].v[e]);
           rr[q][jj].v[e] = rn;
           lU[0] += rn;
           // (one compare per cell; ballot + popcount + add run on the scalar unit - the loop is bound by VALU issue.  A NaN counts.)
@@ -775,7 +789,11 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       // the ring: the same update with the neighbours' z' (beyond a wall there is no cell: the copies stay 0)
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const T vsb = vb[q] ? vs : (T)0, vsa = va[q] ? vs : (T)0;
+        T vsb = vb[q] ? vs : (T)0, vsa = va[q] ? vs : (T)0;
+        if constexpr (RAGGED) {
+          if (!(col_ok[q] && j0[q] - 1 < a.ny_true)) vsb = 0;
+          if (!(col_ok[q] && j0[q] + R < a.ny_true)) vsa = 0;
+        }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           rhb[q].v[e] = fma(-alpha, hbZ[q].v[e] + vsb, rhb[q].v[e]);
@@ -784,7 +802,11 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         int side, er_unused, lane_now = lane;
         if constexpr (SLAB) asm volatile("" : "+v"(lane_now));   // (slab variant: recomputed here instead of a register held across the loop)
         ring_lane(lane_now, R, side, er_unused);
-        const T vse = (side == 0) ? (vl[q] ? vs : (T)0) : ((side == 1) ? (vr[q] ? vs : (T)0) : (T)0);
+        T vse = (side == 0) ? (vl[q] ? vs : (T)0) : ((side == 1) ? (vr[q] ? vs : (T)0) : (T)0);
+        if constexpr (RAGGED) {
+          const bool ok = (side == 0 ? lcol_ok[q] : rcol_ok[q]) && j0[q] + er_unused < a.ny_true;
+          if (!ok) vse = 0;
+        }
         eR[q] = fma(-alpha, eZ[q] + vse, eR[q]);
       }
       lU[1] = (lane == 0) ? (T)cnt_wave : (T)0;              // (the exchange adds the lanes of a wave)

@@ -523,6 +523,7 @@ static int slab_solve(std::vector<SlabRank<T>>& R, Comm<T>& comm, int nx, int ny
     a.r = k.rbase + nx; a.p[0] = k.pbase[0] + nx; a.p[1] = k.pbase[1] + nx; a.x = k.xbase + nx;
     a.nx = nx; a.ny = nyl; a.per_x = per_x; a.per_y = 2;
     a.gA = nullptr; a.gB = nullptr; a.nt = 0;
+    a.nx_true = 0; a.ny_true = 0; a.ncells = 0.0;
     PISO_HIP_CHECK(hipMemsetAsync(k.flags, 0, 4 * sizeof(int), stream));
     PISO_HIP_CHECK(hipMemsetAsync(k.rbase, 0, nh * sizeof(T), stream));
     PISO_HIP_CHECK(hipMemsetAsync(k.pbase[0], 0, nh * sizeof(T), stream));
