@@ -259,7 +259,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   hipEvent_t* seg_ev = tl_poll.seg_ev;
   if (persist_R && prof && !seg_ev[0]) { PISO_HIP_CHECK(hipEventCreate(&seg_ev[0])); PISO_HIP_CHECK(hipEventCreate(&seg_ev[1])); }
   double seg_ms = 0; long long seg_iters = 0, seg_launches = 0;
-  int segments_run = 0;
+  int segments_run = 0, unsynced = 0;
   for (int k = 0; k < total && !finished; ++k) {
     const bool is_reset = !fixed && ((k + 1) % reset == 0);
     if (persist_R && k > 0 && !is_reset) {
@@ -271,6 +271,18 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
         if (prof) PISO_HIP_CHECK(hipEventRecord(seg_ev[0], stream));
         { const int rc = launch_segment(k, ke); if (rc != PISO_OK) return rc; }
         if (prof) PISO_HIP_CHECK(hipEventRecord(seg_ev[1], stream));
+        // Short segments (frequent residual resets: the reference's default residual_reset = 10 leaves 9 iterations between two
+        // resets) are not worth a host round trip each: the host looks again after ~250 iterations.  Everything queued behind a
+        // converged or failed segment returns at once (every kernel checks the state record first), the error flag is sticky.
+        if (!prof && ke - k <= 32 && unsynced + (ke - k) <= 256 && ke < total) {
+          unsynced += ke - k;
+          ++segments_run;
+          k_last = ke - 1;
+          pending = false;
+          k = ke - 1;
+          continue;
+        }
+        unsynced = 0;
         PISO_HIP_CHECK(hipMemcpyAsync(&tl_poll.pinned[0], &a.state[0], sizeof(CgState), hipMemcpyDeviceToHost, stream));
         int herr = 0;
         PISO_HIP_CHECK(hipMemcpyAsync(&herr, pc.err, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -338,6 +350,16 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     if (r > 0) finished = true;
   }
   PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  if (segments_run > 0 && allow_persist) {                 // (segments whose host look was deferred: did one of them give up?)
+    int herr = 0;
+    PISO_HIP_CHECK(hipMemcpy(&herr, pc.err, sizeof(int), hipMemcpyDeviceToHost));
+    if (herr) {
+      ++g_persist_fallbacks;
+      if (pc.timing) { PISO_HIP_CHECK(hipFree(pc.timing)); pc.timing = nullptr; }
+      return cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out,
+                                     kernel_ms_out, stream, false);
+    }
+  }
   // ---- The persistent kernel lets workgroups read what others published without release / acquire fences (cg_persist.h).  That
   // is checked here at run time instead of being trusted: r - the CG recurrence - must still equal b - A^ x for the x the solve
   // returns (to eps * condition * |b|; a stale perimeter value would leave an O(alpha |z'|) gap that nothing removes before the

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist(CgArgs<T> a, Persi
   };
   for (; k < k_end && healthy; ++k) {
     // ---- start of iteration k: stopping test of iteration k-1 (pressure_solve_op.cu.cc:312-335), beta (:351-352)
-    if (k > 0 && (k % 5) == 0) {
+    if (!st.done && k > 0 && (k % 5) == 0) {               // (!done: a launch queued behind a converged one changes nothing)
       const int exceeded = tB[2] > 0;
       if (st.flag && !exceeded) { st.done = 1; st.iterations = k; }
       else st.flag = 1;

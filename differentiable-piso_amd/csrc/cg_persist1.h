@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     if (kPersistDiag && c.timing) { const unsigned long long t = wall_clock64(); tacc[slot] += t - tlast; tlast = t; }
   };
   // the stopping test of iteration k_begin was left to this launch by the previous one (pressure_solve_op.cu.cc:312-335)
-  if (k > 0 && (k % 5) == 0) {
+  if (!st.done && k > 0 && (k % 5) == 0) {                  // (!done: a launch queued behind a converged one changes nothing)
     const int exceeded = tB[2] > 0;
     if (st.flag && !exceeded) { st.done = 1; st.iterations = k; }
     else st.flag = 1;
