@@ -48,7 +48,9 @@ int piso_device_count(void);
  * environment variable PISO_<NAME IN UPPER CASE>; -1 = not set (automatic).  Process-wide, not thread-safe against a
  * concurrent solve.  Names: cg_persist (0 forbid / 1 force the persistent CG kernel), cg_persist_r (2|4|8|16 rows per region),
  * cg_segment (iterations per persistent launch), cg_exchanges (1|2 grid exchanges per persistent iteration),
- * cg_persist_timing, cg_rpw, cg_maxblocks, cg_nt, cg_no_compact, cg_no_recon, cg_no_sym. */
+ * cg_persist_timing, cg_rpw, cg_maxblocks, cg_nt, cg_no_compact, cg_no_recon, cg_no_sym, cg_verify (0: skip the true-residual
+ * check of persistent solves; 2: test knob, treat it as failed), cg_pad (0: never run a small wall-bounded grid that the
+ * persistent kernel cannot tile on a zero-padded one). */
 int piso_set_option(const char* name, int value);
 int piso_get_option(const char* name, int* value_out);
 
