@@ -120,7 +120,7 @@ def test_unrolled_adjoint_matches_oracle(name, steps, cut, lin_double):
     if cut is None or (steps - 1) // cut * cut == 0:
         e = (rel(vel_t.grad.cpu().numpy(), d_vel), rel(p_t.grad[0, :, :, 0].cpu().numpy(), d_p))
         print("unrolled backward rel-L2 (d_vel, d_p):", name, steps, e)
-        assert e[0] < 2 * TOL, e
+        assert e[0] < TOL, e                         # the north star's bar: 1e-5 relative L2 on back-propagated gradients
         # dL/dp0 = G^T(adjoint of the predictor) is a difference of neighbouring faces: |d_p| is 20-400 x smaller than |d_vel|
         # and inherits the ABSOLUTE round-off of the float32 transposed solve.  The floor is measured, not assumed: how far
         # the oracle's own d_p moves between a float32 and a float64 advection solve (6.5e-5 for spatial_ml, 2e-6 periodic);
@@ -132,7 +132,7 @@ def test_unrolled_adjoint_matches_oracle(name, steps, cut, lin_double):
             _, d_p64, _ = R.run_steps_backward(s64, t64 if cut is None else t64[(steps - 1) // cut * cut:], v64[-1], np.zeros_like(p64[-1]))
             floor = rel(d_p, d_p64)
             print("float32-advection floor of d_p (oracle f32 vs f64):", floor)
-        assert e[1] < 2 * TOL + 2 * floor, (e, floor)
+        assert e[1] < TOL + 2 * floor, (e, floor)
     else:
         assert vel_t.grad is None or float(vel_t.grad.abs().max()) == 0.0
 
@@ -173,7 +173,10 @@ def test_unrolled_16_steps_adjoint_through_persistent_cg(name, shape, exchanges,
     e_b = (rel(vel_t.grad.cpu().numpy(), d_vel), rel(p_t.grad[0, :, :, 0].cpu().numpy(), d_p))
     print("16-step unroll rel-L2 fields (u, p):", e_f, " gradients (d_vel, d_p):", e_b)
     assert max(e_f) < TOL, e_f
-    assert max(e_b) < 2 * TOL, e_b
+    assert e_b[0] < TOL, e_b                      # dL/du0 through 16 steps: the north star's 1e-5
+    # dL/dp0 = G^T(adjoint faces) is a difference of neighbouring faces, 20-400 x smaller than dL/du0, and carries the absolute
+    # round-off of 16 chained float32 glue steps: 3.5e-6 (periodic), 1.7e-5 (walls in y) relative to ITSELF
+    assert e_b[1] < 2 * TOL, e_b
 
 
 def test_run_piso_steps_reference_call_returns_nine_values():
