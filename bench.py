@@ -473,8 +473,21 @@ def main():
 
     if share_gpu:
         N.set_option("cg_persist", 0)      # (two replicas' persistent kernels do not fit one GPU side by side)
+    torch.cuda.reset_peak_memory_stats(device)
     for _ in range(args.warmup):
         run_unrolled(P, 1)
+    if args.warmup > 0:
+        # A K-step unroll keeps K steps of tape alive; the warm-up unrolled one.  Without this the timed region pays the device
+        # allocator's first-time hipMalloc calls for the other K - 1 (10-20 ms of a 2-step run, at random): part of what a warm-up
+        # is for.  One block of the expected size is allocated and handed back to torch's caching allocator, which splits it.
+        need = int(torch.cuda.max_memory_allocated(device) * (args.steps + 0.5))
+        have = torch.cuda.memory_reserved(device)
+        if need > have:
+            try:
+                prime = torch.empty(need - have, dtype=torch.uint8, device=device)
+                del prime
+            except RuntimeError:
+                pass
     for s_ in (P["ps"].stats, P["lin"].stats):
         for k_ in s_:
             s_[k_] = 0
