@@ -159,3 +159,24 @@ def test_config5_4096_eight_slabs():
     assert abs(l1 - l8) <= 1e-5 * abs(l1), (l1, l8)
     assert one["config"]["last_bicgstab_iterations"] == eight["config"]["last_bicgstab_iterations"]
     assert eight["config"]["warn"] == 0.0
+
+
+def test_bench_line_contract_on_one_gpu():
+    """`python bench.py` prints ONE JSON line with the keys the driver reads, the roofline block and the CPU baseline (small grid
+    here: the shape of the line is what is tested, the numbers are the default run's business)."""
+    d = _bench({}, ["--gpus", "1", "--steps", "1", "--warmup", "1", "--grid", "256", "--no-extras"], 1)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "phases"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "steps/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert d["phases"]["verification_failures"] == 0 and d["phases"]["persistent_cg_fallbacks"] == 0
