@@ -14,7 +14,9 @@ N * K / max-over-ranks time, scaling "weak".  After the timed region every N > 1
 on the real node (peer-mapped mailboxes over xGMI, persistent slab kernel, RCCL transport) and reports it INSIDE the JSON line
 (`slab_cg_self_check`: strong- and weak-scaled us per iteration, agreement with single-GPU solves); a failed or hung check
 makes the run exit non-zero.  `--decomp slab` runs the whole bench on ONE grid with both linear solvers (pressure CG, ILU(0)-BiCGStab)
-cut into y-slabs over the ranks and assembly / glue replicated (strong scaling: DESIGN.md 6 explains why that cannot beat the on-chip single-GPU kernel at 2048^2).
+cut into y-slabs over the ranks and assembly / glue replicated (strong scaling: DESIGN.md 6 explains why that cannot beat the on-chip single-GPU kernel at 2048^2);
+`--decomp slab-weak` decomposes ONE grid x (grid * N) box the same way - every GPU owns a grid^2 slab, a step of the box counts as
+N steps (weak scaling of the sharded path).
 
 One JSON line on stdout (rank 0) with, besides the contract's keys:
   roofline      the dominant kernel (persistent pressure CG), HIP-event timed inside the timed region.  `achieved` counts the
@@ -65,49 +67,53 @@ def persist_fabric_bytes_per_cell(exchanges):
     return PERSIST_STENCIL_PASSES * 8.0 + nvec * 2 * (2.0 / 16 + 2.0 / 128) * 8.0 + 0.6
 
 
-def turbulence_velocity(n, seed=0, k0=8.0):
-    """Curl of a random stream function with E(k) ~ k^4 exp(-(k/k0)^2), sampled on faces, u_rms = 1."""
+def turbulence_velocity(n, seed=0, k0=8.0, ny=None):
+    """Curl of a random stream function with E(k) ~ k^4 exp(-(k/k0)^2), sampled on faces, u_rms = 1.
+    ny (default n): rows of a taller periodic box [0, 2 pi ny / n] x [0, 2 pi] with the same cell size and the same physical
+    spectrum (the slab-weak benchmark mode: one n x n slab per GPU)."""
+    ny = n if ny is None else ny
     rng = np.random.default_rng(seed)
     kx = np.fft.fftfreq(n, 1.0 / n)
-    ky = np.fft.fftfreq(n, 1.0 / n)
+    ky = np.fft.fftfreq(ny, 1.0 / ny) * (float(n) / ny)      # physical wavenumbers of the taller box
     KX, KY = np.meshgrid(kx, ky, indexing="xy")
     k = np.sqrt(KX ** 2 + KY ** 2)
     k[0, 0] = 1.0
     E = k ** 4 * np.exp(-(k / k0) ** 2)
     amp = np.sqrt(E) / k
-    psi_hat = amp * (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    psi_hat = amp * (rng.standard_normal((ny, n)) + 1j * rng.standard_normal((ny, n)))
     psi_hat[0, 0] = 0
     psi = np.real(np.fft.ifft2(psi_hat))            # stream function on cell corners (periodic)
     h = 2 * np.pi / n
-    u = (np.roll(psi, -1, axis=0) - psi) / h        # u = d(psi)/dy on x-faces   [n, n]
-    v = -(np.roll(psi, -1, axis=1) - psi) / h       # v = -d(psi)/dx on y-faces  [n, n]
+    u = (np.roll(psi, -1, axis=0) - psi) / h        # u = d(psi)/dy on x-faces   [ny, n]
+    v = -(np.roll(psi, -1, axis=1) - psi) / h       # v = -d(psi)/dx on y-faces  [ny, n]
     s = 1.0 / np.sqrt(0.5 * (np.mean(u ** 2) + np.mean(v ** 2)))
-    t = np.zeros((1, n + 1, n + 1, 2), np.float32)
-    t[0, :n, :n, 1] = u * s
-    t[0, :n, n, 1] = u[:, 0] * s                    # duplicate periodic face
-    t[0, :n, :n, 0] = v * s
-    t[0, n, :n, 0] = v[0, :] * s
+    t = np.zeros((1, ny + 1, n + 1, 2), np.float32)
+    t[0, :ny, :n, 1] = u * s
+    t[0, :ny, n, 1] = u[:, 0] * s                   # duplicate periodic face
+    t[0, :ny, :n, 0] = v * s
+    t[0, ny, :n, 0] = v[0, :] * s
     return t
 
 
-def build_problem(n, device, tol, max_it, reset):
-    """The metric workload: 2-D decaying turbulence n^2, doubly periodic."""
+def build_problem(n, device, tol, max_it, reset, ny=None):
+    """The metric workload: 2-D decaying turbulence n^2 (n columns x ny rows if ny is given), doubly periodic."""
     import torch
     import diffpiso as dp
+    ny = n if ny is None else ny
     L = 2 * np.pi
-    domain = dp.Domain([n, n], boundaries=dp.PERIODIC, box=dp.box[0:L, 0:L])
-    ones = np.ones((1, n + 2, n + 2, 1), np.float32)
-    st = (1, n + 1, n + 1, 2)
+    domain = dp.Domain([ny, n], boundaries=dp.PERIODIC, box=dp.box[0:L * ny / n, 0:L])
+    ones = np.ones((1, ny + 2, n + 2, 1), np.float32)
+    st = (1, ny + 1, n + 1, 2)
     lin = dp.LinearSolverCudaMultiBicgstabILU(accuracy=tol, max_iterations=max_it, cast_to_double=False)
     ps = dp.PisoPressureSolverCudaCustom(dx=[], accuracy=tol, max_iterations=max_it, residual_reset=reset, cast_to_double=True)
     sim = dp.SimulationParameters(dirichlet_mask=np.zeros(st, bool), dirichlet_values=np.zeros(st, np.float32),
                                   active_mask=ones, accessible_mask=ones, bool_periodic=(True, True), no_slip_mask=None,
                                   viscosity=1e-3, linear_solver=lin, pressure_solver=ps)
-    vel = turbulence_velocity(n)
+    vel = turbulence_velocity(n, ny=ny)
     dx = L / n
     dt = 0.5 * dx / float(np.abs(vel).max())
     sim.dirichlet_values = torch.zeros(st, device=device)
-    return dict(domain=domain, sim=sim, vel=vel, vel_t=torch.tensor(vel, device=device), p_t=torch.zeros((1, n, n, 1), device=device),
+    return dict(domain=domain, sim=sim, vel=vel, vel_t=torch.tensor(vel, device=device), p_t=torch.zeros((1, ny, n, 1), device=device),
                 dt=dt, lin=lin, ps=ps)
 
 
@@ -433,9 +439,12 @@ def main():
     ap.add_argument("--residual-reset", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the bicgstab / other_configs legs (profiling runs)")
-    ap.add_argument("--decomp", choices=["replicas", "slab"], default=os.environ.get("PISO_BENCH_DECOMP", "replicas"),
-                    help="N > 1: 'replicas' = one independent grid per GPU (weak); 'slab' = ONE grid, pressure CG cut into "
-                         "y-slabs over the GPUs (peer-mapped mailboxes, persistent slab kernel), rest of the step replicated (strong)")
+    ap.add_argument("--decomp", choices=["replicas", "slab", "slab-weak"], default=os.environ.get("PISO_BENCH_DECOMP", "replicas"),
+                    help="N > 1: 'replicas' = one independent grid per GPU (weak); 'slab' = ONE grid x grid problem, both linear "
+                         "solvers cut into y-slabs over the GPUs (peer-mapped mailboxes, persistent slab kernel), assembly / glue "
+                         "replicated (strong); 'slab-weak' = the same decomposition of ONE grid x (grid * N) problem: every GPU owns a "
+                         "grid x grid slab of a taller periodic box, a step of it counts as N steps at grid^2 (weak)")
+    ap.add_argument("--grid-ny", type=int, default=0, help="rows of the grid if different from --grid (a taller periodic box)")
     args = ap.parse_args()
 
     import torch
@@ -458,8 +467,10 @@ def main():
 
     import diffpiso._native as N
     n = args.grid
-    P = build_problem(n, device, args.tol, args.max_iterations, args.residual_reset)
-    slab = world > 1 and args.decomp == "slab"
+    slab_weak = world > 1 and args.decomp == "slab-weak"
+    ny_grid = n * world if slab_weak else (args.grid_ny if args.grid_ny > 0 else n)
+    P = build_problem(n, device, args.tol, args.max_iterations, args.residual_reset, ny=ny_grid)
+    slab = world > 1 and args.decomp in ("slab", "slab-weak")
     if slab:
         from diffpiso.distributed import SlabCommunicator
         P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=3 * n + 8)
@@ -580,22 +591,25 @@ def main():
                   "persistent_cg_solves_verified_against_true_residual": verify_runs, "verification_failures": verify_failures}
         out = {
             "metric": "PISO steps/s (fwd+adjoint) at %d^2 staggered grid" % n,
-            "value": (1 if slab else world) * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            # replicas: N independent steps per step time; slab: ONE n^2 problem on N GPUs; slab-weak: one step of the n x (n N) box
+            # is N steps' worth of n^2 cells
+            "value": (1 if (slab and not slab_weak) else world) * args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong" if slab else "weak",
+            "scaling": "strong" if (slab and not slab_weak) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "2-D decaying isotropic turbulence %d^2 periodic, PISO step fwd + reverse-mode, "
                                    "unrolled %d steps, tol %g, max_it %d, CG reset %d, pressure fp64 / advection fp32, "
                                    "%s" % (n, args.steps, args.tol, args.max_iterations, args.residual_reset,
-                                           ("pressure CG and ILU(0)-BiCGStab slab-decomposed over %d GPUs (peer mailboxes), assembly and glue replicated" % world) if slab else
+                                           (("ONE %d x %d box, a %d^2 slab per GPU: " % (n, ny_grid, n) if slab_weak else "") +
+                                            "pressure CG and ILU(0)-BiCGStab slab-decomposed over %d GPUs (peer mailboxes), assembly and glue replicated" % world) if slab else
                                            ("replicas only (one independent grid per GPU)" if world > 1 else "1 GPU")),
-                       "grid": [n, n], "last_cg_iterations_fwd": P["ps"].last_iterations or 0,
+                       "grid": [ny_grid, n], "last_cg_iterations_fwd": P["ps"].last_iterations or 0,
                        "last_cg_iterations_adjoint": P["ps"].last_adjoint_iterations or 0,
                        "last_bicgstab_iterations": list(P["lin"].last_iterations or ()),
                        "loss": loss, "warn": float(sum(float(w.detach().sum()) for w in warn))},
             "roofline": roofline, "phases": phases,
         }
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and ny_grid == n:
             try:
                 out["bicgstab"] = bicgstab_fixed_work(P, n)
             except Exception as e:
@@ -604,7 +618,7 @@ def main():
                 out["other_configs"] = other_configs(device)
             except Exception as e:
                 out["other_configs"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and ny_grid == n:
             try:
                 out["cpu_baseline"] = cpu_baseline(P, n, args.tol, int(round(cg_per_step)) or 4000)
             except Exception as e:   # the baseline must never sink the GPU number

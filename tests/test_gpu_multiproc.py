@@ -180,3 +180,17 @@ def test_bench_line_contract_on_one_gpu():
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert d["phases"]["verification_failures"] == 0 and d["phases"]["persistent_cg_fallbacks"] == 0
+
+
+def test_weak_scaled_decomposed_step_two_ranks_matches_one_gpu():
+    """`--decomp slab-weak`: ONE 256 x 512 periodic box, one 256^2 slab per rank, both linear solvers decomposed - against the
+    same box on one GPU (`--grid-ny 512`): the loss must agree (rectangular grids, slabs of a taller box)."""
+    common = ["--steps", "1", "--warmup", "0", "--grid", "256", "--no-cpu-baseline", "--no-extras", "--tol", "1e-7"]
+    one = _bench({}, ["--gpus", "1", "--grid-ny", "512"] + common, 1)
+    two = _bench({"PISO_BENCH_SHARE_GPU": "1", "PISO_BENCH_SLAB_CHECK": "0"}, ["--gpus", "2", "--decomp", "slab-weak"] + common, 2)
+    assert two["scaling"] == "weak" and two["n_gpus"] == 2 and two["config"]["grid"] == [512, 256] == one["config"]["grid"]
+    l1, l2 = one["config"]["loss"], two["config"]["loss"]
+    print(one["config"], two["config"])
+    assert abs(l1 - l2) <= 1e-5 * abs(l1), (l1, l2)
+    assert one["config"]["last_bicgstab_iterations"] == two["config"]["last_bicgstab_iterations"]
+    assert abs(two["value"] - 2 * 1e3 / two["ms_per_step"]) <= 1e-6 * two["value"]      # a step of the box counts as two steps at 256^2
