@@ -266,7 +266,7 @@ def measured_traffic(n, kernel):
         return None, "no PMC record (%s)" % type(ex).__name__
 
 
-def slab_self_check(n, device, rank, world, iters=300, share_gpu=False):
+def slab_self_check(n, device, rank, world, iters=300, share_gpu=False, settings=None, replica_steps_per_s=None):
     """N > 1 only, AFTER the timed region, not part of the metric: the slab-decomposed pressure CG on the real
     node, result inside the JSON line.  Three legs, every one compared with a single-GPU solve computed on the same rank:
       strong   one n x n system cut into `world` y-slabs: two-kernel iteration with mailbox collectives, then the persistent slab
@@ -420,6 +420,35 @@ def slab_self_check(n, device, rank, world, iters=300, share_gpu=False):
                                            "solver outputs all-gathered through torch.distributed"}
             ok = ok and rel < 1e-5 and st5["verification_failures"] == 0
             del P5
+        # ---- the metric itself with real sharding (`--decomp slab-weak` as one leg): ONE n x (n * world) periodic box, an n^2 slab
+        # per GPU, the benchmark's solver settings, one step forward + reverse sweep; a step of the box is `world` steps' worth of n^2
+        legw = os.environ.get("PISO_BENCH_WEAK_STEP_LEG", "1")
+        if settings is not None and (legw == "force" or (legw != "0" and not share_gpu)):
+            Pw = build_problem(n, device, settings["tol"], settings["max_iterations"], settings["residual_reset"], ny=n * world)
+            cw = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=3 * n + 8)
+            try:
+                Pw["ps"].slab_comm = cw
+                Pw["lin"].slab_comm = cw
+                run_unrolled(Pw, 1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, loss_w, warn_w = run_unrolled(Pw, 1)
+                torch.cuda.synchronize()
+                t_w = time.perf_counter() - t0
+                stw = cw.stats()
+            finally:
+                Pw["ps"].slab_comm = None
+                Pw["lin"].slab_comm = None
+                cw.close()
+            eq = world / t_w
+            out["weak_step"] = {"box": [n * world, n], "slab_per_gpu": [n, n], "ms_per_step_of_the_box": 1e3 * t_w,
+                                "steps_per_s_at_%d2_equivalent" % n: eq,
+                                "parallel_efficiency_vs_replicas": (eq / replica_steps_per_s) if replica_steps_per_s else None,
+                                "cg_iterations": [Pw["ps"].last_iterations, Pw["ps"].last_adjoint_iterations],
+                                "persistent_slab_iterations": stw["persistent_iterations"], "verification_failures": stw["verification_failures"],
+                                "loss_finite": bool(np.isfinite(loss_w)), "warn": float(sum(float(w.detach().sum()) for w in warn_w))}
+            ok = ok and stw["verification_failures"] == 0 and bool(np.isfinite(loss_w))
+            del Pw
         out["ok"] = bool(ok)
         return out
     finally:
@@ -642,7 +671,9 @@ def main():
         try:
             if share_gpu:
                 N.set_option("cg_persist", -1)
-            chk = slab_self_check(n, device, rank, world, share_gpu=share_gpu)
+            chk = slab_self_check(n, device, rank, world, share_gpu=share_gpu,
+                                  settings={"tol": args.tol, "max_iterations": args.max_iterations, "residual_reset": args.residual_reset},
+                                  replica_steps_per_s=world * args.steps / elapsed)
         except Exception as e:
             chk = {"ok": False, "error": repr(e)}
         try:       # rank 0 reports for everybody
