@@ -9,7 +9,8 @@
 R=$GRAFT_REPO_ROOT
 TAG=${1:-rXX}
 OUT=$R/gpurun_out/prof
-mkdir -p $OUT
+mkdir -p $OUT $R/scripts/_bin
+[ -x $R/scripts/_bin/pmc_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/scripts/pmc_calib.hip -o $R/scripts/_bin/pmc_calib > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $OUT/${TAG}_stats_run.log 2>&1
 for f in $(find /tmp/prof_stats -name "*kernel_stats.csv"); do cp $f $OUT/${TAG}_bench2048_kernel_stats.csv; done
