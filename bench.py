@@ -474,7 +474,11 @@ def main():
                          "replicated (strong); 'slab-weak' = the same decomposition of ONE grid x (grid * N) problem: every GPU owns a "
                          "grid x grid slab of a taller periodic box, a step of it counts as N steps at grid^2 (weak)")
     ap.add_argument("--grid-ny", type=int, default=0, help="rows of the grid if different from --grid (a taller periodic box)")
+    ap.add_argument("--self-check-child", action="store_true", help=argparse.SUPPRESS)      # (internal: one rank of the N > 1 self-check)
+    ap.add_argument("--replica-steps-per-s", type=float, default=0.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.self_check_child:
+        return self_check_child(args)
 
     import torch
     import torch.distributed as dist
@@ -654,36 +658,30 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     rc = 0
     if world > 1 and not slab and os.environ.get("PISO_BENCH_SLAB_CHECK", "1") != "0":
-        # not part of the metric: exercise the slab-decomposed CG over RCCL on the real multi-GPU node; the result travels
-        # INSIDE the JSON line (`slab_cg_self_check`), a failed or hung check makes the process exit non-zero
-        import threading
-
-        def give_up():
-            if rank == 0 and out is not None:
-                out["slab_cg_self_check"] = {"ok": False, "error": "timed out after 420 s"}
-                print(json.dumps(out), flush=True)
-            sys.stderr.write("slab_cg_self_check timed out\n")
-            sys.stderr.flush()
-            os._exit(3)
-        timer = threading.Timer(420.0, give_up)
-        timer.daemon = True
-        timer.start()
+        # Not part of the metric: exercise the slab-decomposed solvers on the real multi-GPU node; the result travels INSIDE the
+        # JSON line (`slab_cg_self_check`).  Every rank runs it in a CHILD process (own process group on the next port): the
+        # cross-GPU path cannot be tested before it meets real xGMI, and whatever it does there - an exception, a hang (420 s
+        # limit), a crash of the HIP runtime - must not cost the headline line this process is about to print.  A wrong or hung
+        # check still makes the run exit non-zero.
+        import subprocess
+        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 7), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # (under torchrun the agent hosts the store of the PARENT port; the children's rank 0 hosts its own)
+        cmd = [sys.executable, os.path.abspath(__file__), "--self-check-child", "--gpus", str(world), "--grid", str(n), "--tol", repr(args.tol),
+               "--max-iterations", str(args.max_iterations), "--residual-reset", str(args.residual_reset),
+               "--replica-steps-per-s", repr(world * args.steps / elapsed)]
+        torch.cuda.synchronize()
         try:
-            if share_gpu:
-                N.set_option("cg_persist", -1)
-            chk = slab_self_check(n, device, rank, world, share_gpu=share_gpu,
-                                  settings={"tol": args.tol, "max_iterations": args.max_iterations, "residual_reset": args.residual_reset},
-                                  replica_steps_per_s=world * args.steps / elapsed)
+            cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+            lines = [l for l in cp.stdout.splitlines() if l.startswith("SELFCHECK ")]
+            if lines:
+                chk = json.loads(lines[-1][len("SELFCHECK "):])
+            else:
+                chk = {"ok": False, "error": "the self-check process ended with code %d and no report" % cp.returncode,
+                       "stderr_tail": cp.stderr[-600:]}
+        except subprocess.TimeoutExpired:
+            chk = {"ok": False, "error": "timed out after 420 s"}
         except Exception as e:
             chk = {"ok": False, "error": repr(e)}
-        try:       # rank 0 reports for everybody
-            okt = torch.tensor([0.0 if chk.get("ok") is False else 1.0], device="cpu" if share_gpu else device)
-            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-            chk["ok_all_ranks"] = bool(okt.item() > 0)
-        except Exception as e:
-            chk["ok_all_ranks"] = False
-            chk["all_ranks_error"] = repr(e)
-        timer.cancel()
         if rank == 0:
             out["slab_cg_self_check"] = chk
         if chk.get("ok") is False or (chk.get("ok") and not chk.get("ok_all_ranks")):
@@ -693,6 +691,39 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     sys.exit(rc)
+
+
+def self_check_child(args):
+    """One rank of the slab self-check in its own process (started by main(), see there).  Prints `SELFCHECK {json}`."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    share_gpu = os.environ.get("PISO_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist.init_process_group(backend="gloo" if share_gpu else "nccl")
+    try:
+        chk = slab_self_check(args.grid, device, rank, world, share_gpu=share_gpu,
+                              settings={"tol": args.tol, "max_iterations": args.max_iterations, "residual_reset": args.residual_reset},
+                              replica_steps_per_s=args.replica_steps_per_s if args.replica_steps_per_s > 0 else None)
+    except Exception as e:
+        chk = {"ok": False, "error": repr(e)}
+    try:       # every rank reports for everybody
+        okt = torch.tensor([0.0 if chk.get("ok") is False else 1.0], device="cpu" if share_gpu else device)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        chk["ok_all_ranks"] = bool(okt.item() > 0)
+    except Exception as e:
+        chk["ok_all_ranks"] = False
+        chk["all_ranks_error"] = repr(e)
+    print("SELFCHECK " + json.dumps(chk), flush=True)
+    try:
+        dist.destroy_process_group()
+    except Exception:
+        pass
 
 
 def other_configs(device):
