@@ -19,10 +19,11 @@ cut into y-slabs over the ranks and assembly / glue replicated (strong scaling: 
 N steps (weak scaling of the sharded path).
 
 One JSON line on stdout (rank 0) with, besides the contract's keys:
-  roofline      the dominant kernel (persistent pressure CG), HIP-event timed inside the timed region.  `achieved` counts the
-                bytes THIS design has to move through the memory fabric per launch (DESIGN.md 3.1), so frac <= 1;
-                `algorithmic_equivalent` is SURVEY.md 8(d)'s 128 B per cell and iteration of the textbook iteration;
-                `floors_us_per_iteration` lists what bounds an iteration of this kernel (it is latency / issue bound)
+  roofline      the dominant kernel (persistent pressure CG), HIP-event timed inside the timed region.  `achieved` / `frac` are
+                the bytes the PMC counters saw per iteration (profiles/traffic.json, same kernel sources) / the measured iteration
+                time / the HBM peak; `design_byte_model` is the 18.9 B per cell model beside it; `algorithmic_equivalent` is
+                SURVEY.md 8(d)'s 128 B per cell and iteration of the textbook iteration; `binds` names what binds the kernel
+                (VALU issue + one grid exchange; `bound` stays the contract's "hbm" = the peak frac is priced against) and `floors_us_per_iteration` / `frac_of_binding_floor` price it
   bicgstab      fixed-work run of the ILU(0)-BiCGStab (both components, every launch does work), 296 B per row and iteration
   phases        forward / adjoint ms per step, CG iterations per step, CG share of the step
   other_configs ms per step of BASELINE.json's config 2 (256^2 forward) and config 3 (512x256 fwd + adjoint, 4 steps)
@@ -566,26 +567,43 @@ def main():
             seg_ms = ms_sum[2] / max(cnt[3], 1)
             it_us = 1e3 * ms_sum[2] / cnt[2]
             fabric_b = persist_fabric_bytes_per_cell(exchanges)
-            achieved = fabric_b * ncell * its / (seg_ms * 1e-3) / 1e9
+            model_gbs = fabric_b * ncell * its / (seg_ms * 1e-3) / 1e9
             alg = CG_BYTES_PER_CELL_ITER * ncell * its / (seg_ms * 1e-3) / 1e9
             pmc, pmc_src = measured_traffic(n, "cg_persist")
+            # `achieved` / `frac`: the bytes the PMC counters saw cross the memory fabric per iteration (profiles/traffic.json, taken
+            # on exactly these kernel sources) / the iteration time measured here / the HBM peak.  Without a matching PMC record
+            # the design's byte model stands in and `frac_source` says so.
+            if pmc:
+                achieved = pmc["bytes_per_iteration"] * its / (seg_ms * 1e-3) / 1e9
+                frac_source = "PMC FETCH_SIZE / WRITE_SIZE of the same kernel sources (%s): %.1f MB = %.2f B per cell per iteration" % (
+                    pmc_src, pmc["bytes_per_iteration"] / 1e6, pmc["bytes_per_iteration"] / ncell)
+            else:
+                achieved = model_gbs
+                frac_source = "design byte model (no PMC record of these kernel sources: %s)" % pmc_src
             floors = {"fabric_bytes_at_hbm_peak": fabric_b * ncell / (HBM_PEAK_GBS * 1e9) * 1e6,
                       "fp64_valu_issue": FP64_INSTR_PER_CELL[exchanges] * ncell / 256 / 64 / 4 * FP64_ISSUE_CYCLES / (CLOCK_GHZ * 1e3),
                       "grid_exchanges": exchanges * EXCHANGE_US}
             if VALU_INSTR_PER_CELL.get(exchanges):   # what THIS instruction stream needs (not a floor of the algorithm: reported beside them)
                 floors["valu_issue_of_the_compiled_loop"] = VALU_INSTR_PER_CELL[exchanges] * ncell / 256 / 64 / 4 * 4.5 / (CLOCK_GHZ * 1e3)
             serial_floor = floors["fp64_valu_issue"] + floors["grid_exchanges"]   # the exchange cannot overlap the arithmetic it feeds
-            roofline = {"bound": "hbm",
+            roofline = {"bound": "hbm",       # (the contract's enum: the roofline `frac` is priced against; what BINDS the kernel is `binds`)
+                        "binds": "valu_issue+exchange",
                         "kernel": "cg_persist (one launch = %.0f CG iterations: r, p in registers, x in LDS, float coefficients "
                                   "streamed, %d grid exchange%s per iteration, fp64)" % (its, exchanges, "" if exchanges == 1 else "s"),
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "frac_source": frac_source,
                         "traffic": (pmc["bytes_per_iteration"] * its) if pmc else None, "traffic_source": pmc_src,
-                        "bytes_counted": "%.1f B per cell and iteration: what this design must move through the memory fabric "
-                                         "(S, W float coefficient rows once per stencil pass, perimeters of the published vectors "
-                                         "out and back); the vectors themselves never leave the chip" % fabric_b,
-                        "bytes_per_launch": fabric_b * ncell * its,
+                        "bytes_per_launch": (pmc["bytes_per_iteration"] * its) if pmc else fabric_b * ncell * its,
                         "avg_launch_ms": seg_ms, "launches_sampled": int(cnt[3]), "iterations_per_launch": its,
                         "us_per_iteration": it_us,
+                        "why_not_hbm_bound": "the vectors never leave the chip and the 33.5 MB of float coefficients are re-read from the "
+                                             "256 MB Infinity Cache / L2, so the kernel is bound by VALU issue of its two stencil passes plus "
+                                             "one grid-wide exchange per iteration (floors below); frac says how much of the HBM peak the "
+                                             "fabric traffic it does generate amounts to",
+                        "design_byte_model": {"bytes_per_cell_iteration": fabric_b, "GB/s": model_gbs, "x_hbm_peak": model_gbs / HBM_PEAK_GBS,
+                                              "note": "S, W float coefficient rows once per stencil pass + perimeters of the published "
+                                                      "vector out and back; an upper bound of the fabric traffic (part of the second "
+                                                      "coefficient pass hits L2), NOT what frac is computed from"},
                         "algorithmic_equivalent": {"bytes_per_cell_iteration": CG_BYTES_PER_CELL_ITER, "GB/s": alg,
                                                    "x_hbm_peak": alg / HBM_PEAK_GBS,
                                                    "note": "SURVEY 8(d) textbook iteration (5 matrix + 11 vector fp64 words); a "

@@ -22,9 +22,15 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+LAST_MODE = None      # "compiled" / "reused": what the last build() call did (recorded by __graft_entry__.build())
+
+
 def build(force=False, verbose=False):
+    global LAST_MODE
     if not force and not needs_build():
+        LAST_MODE = "reused"
         return OUT
+    LAST_MODE = "compiled"
     objs = []
     os.makedirs(os.path.join(CSRC, "_obj"), exist_ok=True)
     procs = []

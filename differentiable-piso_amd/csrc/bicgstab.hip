@@ -623,7 +623,9 @@ struct SideStream {
   hipStream_t stream = nullptr;
   hipEvent_t ready = nullptr, halo = nullptr;
 };
-static thread_local SideStream tl_side;
+// one per device and thread: a thread that later solves on another GPU must not launch the exchange on a stream of the first
+constexpr int kMaxDevices = 16;
+static thread_local SideStream tl_side_dev[kMaxDevices];
 
 template <typename T>
 struct BiHost {
@@ -679,8 +681,10 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   if (pc) {
     if (pc->transport != TRANSPORT_PEER || !pc->connected) { set_error_msg("piso_multi_bicgstab_ilu_slab: needs a connected peer communicator"); return PISO_ERR_INVALID_ARG; }
     const int world = pc->world, rank = pc->rank;
-    if (ny % world != 0 || (ny / world) % g.R != 0 || ny / world < 2) {
-      set_error_msg("piso_multi_bicgstab_ilu_slab: the slabs (ny / ranks cell rows) must be whole preconditioner bands");
+    // (a product is split into interior rows and kEdgeRows face rows at either end of the slab: thinner slabs would make the two
+    // edge ranges overlap and count their rows twice in the dot products)
+    if (ny % world != 0 || (ny / world) % g.R != 0 || ny / world < 2 * kEdgeRows) {
+      set_error_msg("piso_multi_bicgstab_ilu_slab: the slabs (ny / ranks cell rows) must be whole preconditioner bands of at least 4 rows");
       return PISO_ERR_INVALID_ARG;
     }
     if ((size_t)(3 * nx + 1) > pc->row_cap) { set_error_msg("piso_multi_bicgstab_ilu_slab: communicator row_capacity < 3 nx + 1"); return PISO_ERR_INVALID_ARG; }
@@ -708,6 +712,9 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   auto halo = [&](T* vec) {
     if (slab) peer_exchange_segments<T><<<2, 256, 0, stream>>>(bp.pv, vec, to_upper, to_lower, from_lower, from_upper, ++pc->seq_ex, pc->err);
   };
+  int dev_now = 0;
+  if (slab) { PISO_HIP_CHECK(hipGetDevice(&dev_now)); if (dev_now < 0 || dev_now >= kMaxDevices) { set_error_msg("piso_multi_bicgstab_ilu_slab: device ordinal out of range"); return PISO_ERR_INVALID_ARG; } }
+  SideStream& tl_side = tl_side_dev[dev_now];
   if (slab && !tl_side.stream) {
     PISO_HIP_CHECK(hipStreamCreateWithFlags(&tl_side.stream, hipStreamNonBlocking));
     PISO_HIP_CHECK(hipEventCreateWithFlags(&tl_side.ready, hipEventDisableTiming));
@@ -846,6 +853,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   (void)failed_mask;
   if (slab) {
     int herr = 0;
+    peer_agree_on_error<><<<1, 64, 0, stream>>>(bp.pv, pc->err, ++pc->seq_ar);      // every rank returns the same status
     PISO_HIP_CHECK(hipMemcpyAsync(&herr, pc->err, sizeof(int), hipMemcpyDeviceToHost, stream));
     PISO_HIP_CHECK(hipStreamSynchronize(stream));
     if (herr) {

@@ -30,9 +30,17 @@ static std::atomic<unsigned> g_persist_launches{0};   // persistent launches so 
 static int g_persist_fallbacks = 0;            // solves that were restarted on the two-kernel path after an exchange timed out
 static long long g_verify_runs = 0;            // solves whose final state was checked against the true residual (cg_verify_gap)
 static int g_verify_failures = 0;              // ... and failed: restarted on the two-kernel path
-static thread_local HostPoll tl_poll;
+// one per device and thread (events belong to the device that was current when they were created); ensure_poll() selects
+constexpr int kPollDevices = 16;
+static thread_local HostPoll tl_poll_dev[kPollDevices];
+static thread_local HostPoll* tl_poll_cur = &tl_poll_dev[0];
+#define tl_poll (*tl_poll_cur)
 
 static int ensure_poll() {
+  int dev = 0;
+  PISO_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kPollDevices) { set_error_msg("piso_cg_solve: device ordinal out of range"); return PISO_ERR_INVALID_ARG; }
+  tl_poll_cur = &tl_poll_dev[dev];
   if (!tl_poll.pinned) {
     PISO_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&tl_poll.pinned), 2 * sizeof(CgState), hipHostMallocDefault));
     PISO_HIP_CHECK(hipEventCreateWithFlags(&tl_poll.ev[0], hipEventDisableTiming));

@@ -481,7 +481,11 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
   for (int q = 0; q < nloc; ++q)
     slab_copy_rows<T><<<gflat[q], kBlock, 0, stream>>>(R[q].a.x, R[q].x_out, (size_t)R[q].a.nx * R[q].a.ny);
   PISO_LAUNCH_CHECK();
-  if (comm.peer()) PISO_HIP_CHECK(hipMemcpyAsync(&tl_slab_pinned->err, comm.rccl->err, sizeof(int), hipMemcpyDeviceToHost, stream));
+  if (comm.peer()) {
+    if (comm.world > 1)       // every rank returns the same status (a wait may have given up on one rank only)
+      peer_agree_on_error<><<<1, 64, 0, stream>>>(make_view(comm.rccl, comm.periodic_y), comm.rccl->err, ++comm.rccl->seq_ar);
+    PISO_HIP_CHECK(hipMemcpyAsync(&tl_slab_pinned->err, comm.rccl->err, sizeof(int), hipMemcpyDeviceToHost, stream));
+  }
   PISO_HIP_CHECK(hipStreamSynchronize(stream));
   if (comm.peer() && tl_slab_pinned->err) {
     PISO_HIP_CHECK(hipMemsetAsync(comm.rccl->err, 0, sizeof(int), stream));
@@ -557,7 +561,7 @@ static int slab_solve(std::vector<SlabRank<T>>& R, Comm<T>& comm, int nx, int ny
         PISO_HIP_CHECK(hipMemsetAsync(k.pbase[0], 0, nh * sizeof(T), stream));
         PISO_HIP_CHECK(hipMemsetAsync(k.pbase[1], 0, nh * sizeof(T), stream));
         PISO_HIP_CHECK(hipMemsetAsync(k.xbase, 0, nh * sizeof(T), stream));
-        cg_zero_partials<T><<<(3 * kMaxPartials + 255) / 256, 256, 0, stream>>>(k.a.partsA, k.a.partsB, k.a.partsB);
+        cg_zero_partials<T><<<(3 * kMaxPartials + 255) / 256, 256, 0, stream>>>(k.a.partsA, k.a.partsB, k.a.partsS);
         k.a.gA = nullptr; k.a.gB = nullptr;
       }
       cg_init<T><<<gflat, kBlock, 0, stream>>>(k.a, rank_deficient, k.g + 8, global_cells);

@@ -82,6 +82,17 @@ __device__ __forceinline__ double peer_wave_sum(const PeerView& pv, double v_lan
   return acc;
 }
 
+// The error flag of a solve, agreed over the ranks: a wait that gave up on ONE rank (a slow peer, not a dead one) must fail the call
+// on EVERY rank - a rank that alone returned an error would leave its peers waiting in the next collective, on the device or in
+// torch.distributed.  One wave sums the flags (a dead transport makes this wait give up on every rank, which is an error too).
+template <int kUnused = 0>
+__global__ void peer_agree_on_error(PeerView pv, int* err, unsigned seq) {
+  const int lane = threadIdx.x & 63;
+  bool good = true;
+  const double acc = peer_wave_sum(pv, lane < 2 ? (double)*err : 0.0, 2, 0, seq, &good);
+  if (lane == 0 && (!good || acc != 0.0)) *err = 1;
+}
+
 // Segments of a globally indexed vector that cross a slab edge (element offsets into the vector; at most 3 segments per message)
 struct HaloMsg {
   int count;

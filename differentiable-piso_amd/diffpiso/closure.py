@@ -33,20 +33,17 @@ def _laid_out(w_hwio):
     return out.view(k, k, cin // 16, 4, 4, cop).permute(0, 1, 2, 3, 5, 4).contiguous()
 
 
-_layout_cache = {}
-
-
 def _cached_layouts(w_oihw):
     """(forward layout, input-gradient layout) of a weight tensor, recomputed only when the parameter changes (an unrolled
-    training iteration evaluates the network 2 x step_count times with the same weights)."""
-    key = (w_oihw.data_ptr(), w_oihw._version, tuple(w_oihw.shape))
-    hit = _layout_cache.get(id(w_oihw))
+    training iteration evaluates the network 2 x step_count times with the same weights).  The layouts live ON the tensor
+    object (attribute `_piso_layouts`): they die with it, and another tensor that later reuses its id() or its storage can never
+    see them; `_version` / data_ptr / shape still invalidate them after in-place updates, `.data` swaps and checkpoint loads."""
+    key = (w_oihw.data_ptr(), w_oihw._version, tuple(w_oihw.shape), str(w_oihw.device))
+    hit = getattr(w_oihw, "_piso_layouts", None)
     if hit is None or hit[0] != key:
         wd = w_oihw.detach()
         hit = (key, _laid_out(wd.permute(2, 3, 1, 0)), _laid_out(wd.flip(2, 3).permute(2, 3, 0, 1)))
-        if len(_layout_cache) > 64:
-            _layout_cache.clear()
-        _layout_cache[id(w_oihw)] = hit
+        w_oihw._piso_layouts = hit
     return hit[1], hit[2]
 
 

@@ -60,6 +60,11 @@ def save_frame(path, field_name, frame, array):
     np.savez(_frame_file(path, field_name, frame), np.asarray(array))
 
 
+def load_frame(path, field_name, frame):
+    """One frame as float32 (the reader the reference's training loop inlines, combined_training_integrated.py:268-269)."""
+    return np.load(_frame_file(path, field_name, frame))["arr_0"].astype(np.float32)
+
+
 def make_dataset(list_tuple, mapping_func=load_function, batch_size=1, shuffle=True, seed=None):
     """Stand-in for make_tf_dataset (datamanagement.py:25-32): yields batches (concatenated along axis 0) of mapped windows."""
     order = np.arange(len(list_tuple[0]))

@@ -57,7 +57,7 @@ class _Run(object):
         return (StaggeredGrid(v.staggered_tensor(), self.velocity.box, extrapolation=self.velocity.extrapolation),
                 CenteredGrid(p.data, self.pressure.box, self.pressure.extrapolation))
 
-    def forward(self, velocity, pressure, inlet_perturbation=None):
+    def forward(self, velocity, pressure, inlet_perturbation=None, step_count=None):
         """The graph-construction call of training_run (:54-56) evaluated eagerly: run_piso_steps with the reference's 14
         arguments; `inlet_perturbation` (one [1,Ny+2,1,1] array per step) stands where the reference feeds bc_placeholders."""
         td = self.td
@@ -80,6 +80,8 @@ class _Run(object):
                 lambda dv, pl: update_dirichlet_values(dv, ((False, False), (True, False)), pl))
         self.sim_physics.dirichlet_values = torch.as_tensor(self.base_dirichlet, dtype=torch.float32, device=self.device)
         td_run = dict(td)
+        if step_count is not None:                           # (the roll-out of the model comparison advances one step at a time)
+            td_run["step_count"] = step_count
         td_run.setdefault("pressure_included", True)
         td_run.setdefault("loss_influence_range", td["step_count"] + 1)
         out = run_piso_steps(velocity, pressure, self.domain, self.pp, self.sp, td_run, self.network, wrapper,
@@ -97,6 +99,33 @@ class _Run(object):
             contributions.append(float(sum(torch.as_tensor(c).sum() for c in (contrib if isinstance(contrib, list) else [contrib]))))
         total = loss if td["sum_steps"] else sum(loss)
         return total, contributions
+
+
+def _model_rollout(run, physical_parameters, sp, td, perturb_inlet):
+    """The model comparison of combined_training_integrated.py:266-296: from frame start_frame[0] of the first data set,
+    `interm_forward_steps` single steps of the solver with the current closure (the reference runs its step_count graph and
+    keeps the state after the FIRST step, velocity_all_arrays[0]), then the squared L2 distance to the data frame
+    `interm_forward_steps * dx_ratio + start_frame` (dx_ratio, as coded at :274).  Returns that distance (inf if the solver
+    produced non-finite values)."""
+    from .datamanagement import load_frame
+    starting_frame = td["start_frame"][0]
+    timesteps = td["interm_forward_steps"]
+    vel, prs = run.coarse(load_frame(td["dataset"][0], "velocity", starting_frame), load_frame(td["dataset"][0], "pressure", starting_frame))
+    target = run.coarse(load_frame(td["dataset"][0], "velocity", timesteps * sp["dx_ratio"] + starting_frame),
+                        load_frame(td["dataset"][0], "pressure", starting_frame))[0].staggered_tensor()
+    with torch.no_grad():
+        for c in range(timesteps):
+            pert = None
+            if perturb_inlet:                                                  # :281-289
+                time_c = starting_frame * sp["dt"] + sp["dt"] * sp["dt_ratio"] * c
+                if "perturbation_temporal_offset" in td:
+                    time_c += td["perturbation_temporal_offset"][0]
+                pert = [boundary_perturbation_fun(run.domain, physical_parameters["average_velocity"], run.bcx.shape,
+                                                  time_c + sp["dt"] * sp["dt_ratio"] * t, td["dataset_characteristics"][0])
+                        for t in range(1)]
+            _, _, vel, prs, _ = run.forward(vel, prs, pert, step_count=1)
+        l2 = float(((target - vel.staggered_tensor()) ** 2).sum())
+    return l2 if np.isfinite(l2) else float("inf")
 
 
 def training_run(base_dir, physical_parameters, simulation_parameters, training_dict, solver_precision=1e-10):
@@ -136,6 +165,7 @@ def training_run(base_dir, physical_parameters, simulation_parameters, training_
     if td.get("load_model_path") is not None:
         _restore(run.weights, td["load_model_path"])
     restarted, last_epoch_ckpt = False, None
+    model_l2_losses, model_descriptors, model_restores = [], [], []          # :141-142 (+ which comparisons rolled the model back)
 
     def evaluate(sample, train):
         velocity_data, pressure_data, characs = sample
@@ -173,8 +203,11 @@ def training_run(base_dir, physical_parameters, simulation_parameters, training_
                 if all(w.grad is not None and torch.isfinite(w.grad).all() for w in run.weights):
                     optimizer.step()
             else:                                                                # :199-257
-                if restarted and last_epoch_ckpt is not None:
-                    _restore(run.weights, last_epoch_ckpt)
+                if restarted and (model_descriptors or last_epoch_ckpt is not None):
+                    # second warning in a row (:200-250): back to the last intermediate checkpoint (model_descriptors[-1]); the
+                    # reference crashes here before the first one exists - the last epoch checkpoint stands in
+                    _restore(run.weights, os.path.join(base_dir, "model_epoch_%s.ckpt" % model_descriptors[-1])
+                             if model_descriptors else last_epoch_ckpt)
                 elif os.path.exists(os.path.join(base_dir, "model_last_working")):
                     print("RESTARTING FROM LAST WORKING")
                     _restore(run.weights, os.path.join(base_dir, "model_last_working"))
@@ -187,8 +220,23 @@ def training_run(base_dir, physical_parameters, simulation_parameters, training_
             loss_history[e * max(n_train, 1) + i] = loss_out
             interm = td.get("store_interm_ckpts", 0)
             if interm and i > 0 and i % max((n_train - first) // interm, 1) == 0:  # :263-264
-                last_epoch_ckpt = os.path.join(base_dir, "model_epoch_%06di%06d.ckpt" % (e, i))
+                descriptor = "%06di%06d" % (e, i)
+                last_epoch_ckpt = os.path.join(base_dir, "model_epoch_%s.ckpt" % descriptor)
                 _save(run.weights, last_epoch_ckpt)
+                if td.get("interm_forward_steps"):                               # :266-303
+                    l2 = _model_rollout(run, physical_parameters, sp, td, perturb_inlet)
+                    model_l2_losses.append(l2)
+                    model_descriptors.append(descriptor)
+                    msg = "model comparison after %d timesteps: %s  l2 %s" % (td["interm_forward_steps"], descriptor, l2)
+                    print(msg)
+                    log.write(msg + "\n")
+                    # "20 x worse than the previous checkpoint => restore the previous one" (:301-303, from the third comparison on)
+                    if len(model_l2_losses) > 2 and model_l2_losses[-1] > 20 * model_l2_losses[-2]:
+                        _restore(run.weights, os.path.join(base_dir, "model_epoch_%s.ckpt" % model_descriptors[-2]))
+                        model_restores.append((descriptor, model_descriptors[-2]))
+                        print("MODEL COMPARISON: restored model_epoch_%s.ckpt" % model_descriptors[-2])
+                    np.savez(os.path.join(base_dir, "model_comparison"), descriptors=np.array(model_descriptors),
+                             l2=np.array(model_l2_losses), restores=np.array(model_restores, dtype=str).reshape(-1, 2))
         with torch.no_grad():                                                    # validation (:306-330)
             for i, sample in enumerate(make_dataset(test_tuple, load_function, batch_size=1, shuffle=False)):
                 if i >= n_test:

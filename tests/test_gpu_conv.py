@@ -105,3 +105,31 @@ def test_config4_network_timing_mfma_vs_miopen():
     print("closure fwd+bwd at 256x896: MFMA kernels %.2f ms, torch / MIOpen %.2f ms (~%.1f TFLOP/s fp32 on the MFMA path)"
           % (1e3 * res[True], 1e3 * res[False], flops / res[True] / 1e12))
     assert res[True] > 0
+
+
+def test_weight_layout_cache_is_bound_to_the_parameter_lifetime():
+    """A checkpoint sweep: build, evaluate, free, build again.  CPython reuses id() and torch's allocator reuses same-size blocks,
+    so a cache keyed by id / data_ptr / version could hand the SECOND network the first one's laid-out weights; the layouts live on
+    the parameter object instead (closure._cached_layouts).  Every network of the sweep must agree with the torch path."""
+    import gc
+    import diffpiso as dp
+    import diffpiso.closure as closure
+    x = torch.randn(1, 24, 80, 4, generator=torch.Generator().manual_seed(0)).cuda()
+    for seed in range(4):
+        net, _, _ = dp.initialise_fullyconv_network([[0, 0], [0, 0]], padding="SAME", seed=seed)
+        net = net.cuda()
+        out = net(x)
+        closure.USE_MFMA_CONV = False
+        try:
+            want = net(x)
+        finally:
+            closure.USE_MFMA_CONV = True
+        assert rel(out, want) < 5e-6, seed
+        # an in-place update (optimiser step) and a checkpoint load (copy_) both invalidate the layouts
+        with torch.no_grad():
+            for w in net.weights:
+                w.mul_(0.5)
+        assert rel(net(x), want * 0.5 ** 7) < 5e-6
+        del net, out, want
+        gc.collect()
+        torch.cuda.empty_cache()

@@ -130,3 +130,53 @@ def test_training_run_files_recovery_and_learning(tmp_path, monkeypatch, capsys)
     assert any(n.startswith("model_epoch_000000i") for n in os.listdir(base_dir))
     w = torch.load(os.path.join(base_dir, "model_epoch_000000.ckpt"))
     assert len(w) == 7 and all(torch.isfinite(x).all() for x in w)          # the seven convolution kernels (networks.py:3-73)
+
+
+def test_training_run_model_comparison_rolls_back_a_bad_checkpoint(tmp_path, monkeypatch, capsys):
+    """combined_training_integrated.py:263-303: every intermediate checkpoint is rolled out `interm_forward_steps` steps from the
+    first data frame and compared with the data; a checkpoint 20 x worse than its predecessor is replaced by that predecessor.
+    The third comparison here meets a deliberately broken model (last layer x 1000, injected just before the roll-out): the
+    real roll-out must see it, and training must continue from the second checkpoint."""
+    import os
+    import diffpiso as dp
+    import diffpiso.training as T
+    hr, box = (32, 96), dp.box[0:8, 0:24]
+    phys = dict(average_velocity=1.0, velocity_difference=0.8, inlet_profile_sharpness=2.0, viscosity=5e-3)
+    dt = 0.1
+    data = _frames(tmp_path, 14, hr, box, phys, dt)
+    base_dir = str(tmp_path) + "/run"
+    os.makedirs(base_dir)
+    sim = dict(HRres=list(hr), dx_ratio=2, box=box, sponge_ratio=0.75, relative_sponge_max=20.0, dt=dt, dt_ratio=1,
+               setup_fun=dp.spatialMixingLayer_setup)
+    real = T._model_rollout
+    seen = {"n": 0, "l2": []}
+
+    def rollout(run, *a, **k):
+        seen["n"] += 1
+        if seen["n"] == 3:
+            with torch.no_grad():
+                run.weights[-1].mul_(1000.0)
+        l2 = real(run, *a, **k)
+        seen["l2"].append(l2)
+        return l2
+    monkeypatch.setattr(T, "_model_rollout", rollout)
+    td = dict(HR_buffer_width=[[2, 2], [2, 2]], learning_rate=1e-4, step_count=2, epochs=1, store_interm_ckpts=4, interm_forward_steps=3,
+              padding="SAME",
+              network_initialiser=lambda buffer_width, padding: dp.initialise_fullyconv_network(None, padding=padding, seed=5)[:2] + ([[1, 1], [1, 1]],),
+              network_wrapper=None, loss_functions=[dp.L2_field_loss], loss_factor=[1.0], sum_steps=True,
+              loss_influence_range=None, dataset=[data], start_frame=[0], frame_count_training=[10], frame_count_validation=[4],
+              dataset_characteristics=[(0.08, 0.05)], perturb_inlet=True, load_model_path=None, lr_decay_fun=None, seed=1)
+    hist, hist_val = dp.training_run(base_dir, phys, sim, td, solver_precision=1e-7)
+    out = capsys.readouterr().out
+    assert len(hist) == 8                                        # 10 frames, windows of 3: iterations 0 .. 7, checkpoints at 2, 4, 6
+    assert seen["n"] == 3 and np.isfinite(seen["l2"][:2]).all() and seen["l2"][0] > 0, seen
+    assert seen["l2"][2] > 20 * seen["l2"][1], seen              # the broken model IS what the third roll-out saw
+    assert "MODEL COMPARISON: restored model_epoch_000000i000004.ckpt" in out
+    cmp_ = np.load(os.path.join(base_dir, "model_comparison.npz"))
+    assert list(cmp_["descriptors"]) == ["000000i000002", "000000i000004", "000000i000006"]
+    assert cmp_["restores"].tolist() == [["000000i000006", "000000i000004"]]
+    # training went on from the restored weights: the final model is one Adam step away from checkpoint i = 4, not 1000 x larger
+    w4 = torch.load(os.path.join(base_dir, "model_epoch_000000i000004.ckpt"))
+    wf = torch.load(os.path.join(base_dir, "model_epoch_000000.ckpt"))
+    for a, b in zip(w4, wf):
+        assert float((a - b).norm()) <= 0.05 * float(a.norm()) + 1e-3, (float((a - b).norm()), float(a.norm()))
