@@ -73,10 +73,36 @@ struct SlabCtl {
   char *rows_own, *rows_lo, *rows_hi;   // the row areas (PeerLayout::kRows) of my mailbox and of the lower / upper neighbour's
 };
 
-// coefficient rows in flight per wave (A/B builds: -DPISO_PERSIST1_DEPTH=n + scripts/sweep_libs.sh).  Measured at 2048^2 / 1024^2:
-// 16-row regions 4 rows 17.8 us (15 spilled VGPRs), 3 rows 17.2 us (6), 2 rows 21.1 us; small regions 4 rows 7.05, 3 rows 8.2 us
+// coefficient rows in flight per wave (A/B builds: -DPISO_PERSIST1_DEPTH=n + scripts/build_variant.py / scripts/ab.sh).  Round 3, 16-row
+// regions at 2048^2, with the back-and-forth row order (kZigZag): 3 rows 12.5 us, 4 rows 11.8 us, 5 rows 11.5 us per iteration,
+// 6 rows spill.  (Round 2, cyclic order, before the loop was put on its VALU diet: 4 rows 17.8 us with 15 spilled VGPRs, 3 rows
+// 17.2 us, 2 rows 21.1 us; small regions 4 rows 7.05, 3 rows 8.2 us.)
 #ifndef PISO_PERSIST1_DEPTH
-#define PISO_PERSIST1_DEPTH ((NQ == 1) ? 3 : kPersistMaxDepth)
+#define PISO_PERSIST1_DEPTH 5                   // ... of the 16-row single-GPU kernel on a symmetric matrix (kDeep); every other shape: 3 / 4
+#endif
+#ifndef PISO_PERSIST1_RESIDENT
+#define PISO_PERSIST1_RESIDENT 0                // coefficient rows (of 16) that stay in registers, see kRes
+#endif
+#ifndef PISO_PERSIST1_ZIGZAG
+#define PISO_PERSIST1_ZIGZAG 1                  // the U pass walks a wave's rows downwards (see kZigZag)
+#endif
+#ifndef PISO_PERSIST1_ZIGZAG_SMALL
+#define PISO_PERSIST1_ZIGZAG_SMALL 1
+#endif
+#ifndef PISO_PERSIST1_RING_SMALL
+#define PISO_PERSIST1_RING_SMALL 1
+#endif
+#ifndef PISO_PERSIST1_ASMCNT_SLAB
+#define PISO_PERSIST1_ASMCNT_SLAB 1
+#endif
+#ifndef PISO_PERSIST1_LEAN_SLAB
+#define PISO_PERSIST1_LEAN_SLAB 0
+#endif
+#ifndef PISO_PERSIST1_ZIGZAG_SLAB
+#define PISO_PERSIST1_ZIGZAG_SLAB 0          // (the slab variant has no registers for the rows held across the turn: 17.2 vs 18.1 us)
+#endif
+#ifndef PISO_PERSIST1_PREFETCH_BEHIND_DRAIN
+#define PISO_PERSIST1_PREFETCH_BEHIND_DRAIN 0    // (measured: no gain - the first barrier of the exchange waits for the slowest wave, not for the drain)
 #endif
 #ifndef PISO_PERSIST1_POLL_SLEEP
 #define PISO_PERSIST1_POLL_SLEEP 1              // s_sleep units (64 cycles) between two polling passes
@@ -357,6 +383,17 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // the direction on the rows below / above my regions: parked in LDS (two reads per pass, one read-modify-write per iteration)
   constexpr bool kParkHalos = (NQ * R < 16) || NQ == 1;     // (two regions of 8 rows: x already fills the LDS)
   __shared__ T halo_s[kParkHalos ? kPersistWaves * NQ * 2 * 64 * V : 1];
+  // The ring columns of the direction (and, SYM, the W coefficient of the column right of the strip), by lane as `edge` / `eW`
+  // hold them: lanes [0, R) the left neighbours of rows 0 .. R-1, lanes [48, 48 + R) the right ones.  Row jj needs its two ring
+  // values in lanes 0 and 63 as the `old` operand of the wave shifts; through the DPP network that is a row-local shift per 32-bit
+  // half and side (5 VALU instructions per row and pass in a loop that is bound by VALU issue), through the LDS it is one
+  // broadcast read per row and pass that every lane receives (ring_issue) and no VALU slot at all.
+  // (the slab variant and the fp64-coefficient fallback have no registers for the values in flight: they keep the DPP shifts)
+  constexpr bool kRingLds = !SLAB && sizeof(CT) == 4 && (NQ == 1 || PISO_PERSIST1_RING_SMALL != 0);
+  // kLean: the round-3 forms of the end-cell store (range-checked, all lanes) and of the coefficient offset (kept in a VGPR)
+  constexpr bool kLean = !SLAB || PISO_PERSIST1_LEAN_SLAB != 0;
+  constexpr int kRingBytes = 64 * (int)sizeof(T) + 64 * (int)sizeof(CT);
+  __shared__ __attribute__((aligned(16))) unsigned char ring_s[kRingLds ? kPersistWaves * NQ * kRingBytes : 16];
   const int nx = a.nx, ny = a.ny;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar branches, SGPRs
@@ -410,7 +447,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // ---- the state of the two-kernel path: r and the direction p_{k-1} of my regions into registers, x into LDS
   const T alpha0 = pend ? uniform(a.scal[SC_ALPHA]) : (T)0;   // pend: x still lacks alpha p of the iteration before k_begin
   Vec<T, V> rr[NQ][R], pp[NQ][R];
-  unsigned vT[NQ];
+  unsigned vT[NQ], vEnd[NQ];                               // vEnd: vT in lanes 0 and 63, beyond any buffer (also + a row offset) elsewhere
   // copies of r (registers) and of the direction (LDS / registers, `edge`) on the ring around my regions
   Vec<T, V> rhb[NQ], rha[NQ], pnb[NQ], pna[NQ];
   T eR[NQ], edge[NQ];
@@ -421,6 +458,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     for (int q = 0; q < NQ; ++q) {
       const int cq = (tx0[q] * 64 + lane) * V;
       vT[q] = (unsigned)(cq * sizeof(T));
+      vEnd[q] = (!kLean || lane == 0 || lane == 63) ? vT[q] : 0x80000000u;
       T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
 #pragma unroll
       for (int jj = 0; jj < R; ++jj) {
@@ -520,11 +558,16 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // the same order; the loads of row t + D are issued when row t has been consumed, circularly.
   constexpr int coef_regs = ((SYM ? 2 : 4) * (int)sizeof(CT) * V + (RECON ? 0 : (int)sizeof(T) * V)) / 4;   // VGPRs of a row in flight
   constexpr int NT = NQ * R;
-  constexpr int budget = (NQ == 1 || NT < 16) ? 16 : 8;
-  constexpr int Dw = budget / coef_regs < 2 ? 2 : (budget / coef_regs > PISO_PERSIST1_DEPTH ? PISO_PERSIST1_DEPTH : budget / coef_regs);
+  // (the deep pipeline pays where the loop has registers to spare: the slab variant and the four-array / fp64-coefficient variants
+  // keep the round-2 depth, they spill otherwise)
+  constexpr bool kDeep = NQ == 1 && NT == 16 && SYM && RECON && !SLAB && sizeof(T) == 8;
+  constexpr int depth_max = kDeep ? PISO_PERSIST1_DEPTH : ((NQ == 1) ? 3 : kPersistMaxDepth);
+  constexpr int budget = kDeep ? 4 * PISO_PERSIST1_DEPTH : ((NQ == 1 || NT < 16) ? 16 : 8);
+  constexpr int Dw = budget / coef_regs < 2 ? 2 : (budget / coef_regs > depth_max ? depth_max : budget / coef_regs);
   constexpr int D = (NT >= Dw) ? Dw : NT;
   constexpr int kBaseLoads = (SYM ? 2 : 4) + (RECON ? 0 : 1);          // vector loads every row issues (some rows one or two more)
   Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT], cSh[NQ];
+  bool first_fill = false;                                 // (compile-time after unrolling: only the prologue loads the resident rows)
   Vec<T, V> cD[NT];
   CT eW[NQ];
   // byte offset of row j0[q] + jj: recomputed at every use (two scalar instructions) from a value the optimiser cannot see
@@ -537,10 +580,23 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   };
   auto coef_offset = [&](int q) __attribute__((always_inline)) -> unsigned {
     unsigned o = vT[q];
-    asm volatile("" : "+v"(o));
+    if constexpr (!kLean) asm volatile("" : "+v"(o));       // (recomputed at every use: a VGPR less where registers spill)
     return (unsigned)((unsigned long long)o * sizeof(CT) / sizeof(T));
   };
+  // The first kRes rows of a wave's rows keep their coefficients in registers for the whole launch (loaded by the prologue, never
+  // reissued).  Why: both stencil passes stream the S / W rows of the workgroup's cells, 4.19 MB per XCD and pass at 2048^2 - just
+  // above the 4 MB of an XCD's L2, so a cyclic sweep misses almost every time and the row loops run at the speed of the memory
+  // fabric (measured 33.5 MB in 3.6 us).  With kRes of 16 rows resident the streamed set is (16 - kRes) / 16 of that and fits.
+  // kZigZag: D walks the rows of a wave upwards (t = 0 .. NT-1), U walks them downwards.  The coefficient rows a pass ends with are
+  // the rows the next pass starts with: they are still in registers (Dc rows per turn are never reloaded) and the rows behind them
+  // are the most recently used lines of the XCD's L2 - a cyclic sweep over a set just above the L2's capacity misses every time,
+  // a back-and-forth sweep misses only what does not fit.  (Measured before: both row loops ran at the speed of the memory
+  // fabric, ~6 TB/s of coefficient rows, not at the speed of their arithmetic.)
+  constexpr bool kZigZag = PISO_PERSIST1_ZIGZAG != 0 && (!SLAB || PISO_PERSIST1_ZIGZAG_SLAB != 0) && (NQ == 1 || PISO_PERSIST1_ZIGZAG_SMALL != 0);
+  constexpr bool kPrefetchBehindDrain = PISO_PERSIST1_PREFETCH_BEHIND_DRAIN != 0 && !kZigZag;
+  constexpr int kRes = (NQ == 1 && NT == 16 && SYM && RECON) ? PISO_PERSIST1_RESIDENT : 0;
   auto issue_coef = [&](int t) __attribute__((always_inline)) {
+    if (t < kRes && !first_fill) return;
     const int q = t / R, jj = t - q * R;
     const unsigned vCq = coef_offset(q);
     const unsigned sT = row_base(q, jj, rowT), sC = row_base(q, jj, rowC);
@@ -551,6 +607,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // SYM: W of the first column of the strip to the right (E of my last column; lane R + jj: row jj) and S of the row above the
   // region (N of my last row).  Constants of the launch: loaded ONCE - reloading them with rows 0 / R-1 of every pass put a full
   // memory trip in front of the rows that still used them (0.55 us per iteration at 2048^2).
+  // LDS byte address of this wave's ring block, kept in a VGPR (ds instructions take their address from one) and made opaque
+  // before every use: the optimiser then cannot merge the reads of the D pass with those of the U pass (which would keep 5
+  // registers per row alive across the exchange) and leaves each read where it is issued
+  typedef __attribute__((address_space(3))) T lds_T;
+  typedef __attribute__((address_space(3))) CT lds_CT;
+  typedef __attribute__((address_space(3))) unsigned char lds_u8;
+  unsigned ring_a = (unsigned)(unsigned long)(lds_u8*)ring_s + (unsigned)(wave * NQ * kRingBytes);
+  asm volatile("" : "+v"(ring_a));
   if constexpr (SYM) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -560,6 +624,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       if (cc >= nx) cc = a.per_x ? 0 : -1;
       const unsigned vo = (has[q] && side == 1 && cc >= 0) ? (unsigned)(j0[q] + er) * rowC + (unsigned)(cc * sizeof(CT)) : 0xffffffffu;
       eW[q] = bld1<CT>(RoW, vo, 0);
+      if constexpr (kRingLds)
+        *(lds_CT*)(unsigned long)(ring_a + (unsigned)(q * kRingBytes + 64 * (int)sizeof(T)) + (unsigned)lane * (unsigned)sizeof(CT)) = eW[q];
       bool valid;
       const int jw = row_wrap(j0[q] + R, valid);
       if (SLAB && top[q]) cSh[q] = bld<CT, V>(RoN, has[q] ? coef_offset(q) : 0xffffffffu, (unsigned)(ny - 1) * rowC);   // N of my last row
@@ -567,6 +633,18 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       cSh[q] = bld<CT, V>(RoS, (has[q] && valid) ? coef_offset(q) : 0xffffffffu, (unsigned)jw * rowC);
     }
   }
+  // the ring values of row t (every lane receives them; lanes 0 / 63 are the ones that matter): issued one row ahead
+  T rgl[NT], rgr[NT];
+  CT rgw[NT];
+  auto ring_issue = [&](int t) __attribute__((always_inline)) {
+    if constexpr (!kRingLds) return;
+    const int q = t / R, jj = t - q * R;
+    asm volatile("" : "+v"(ring_a));
+    const unsigned base = ring_a + (unsigned)(q * kRingBytes);
+    rgl[t] = *(const lds_T*)(unsigned long)(base + (unsigned)(jj * (int)sizeof(T)));
+    rgr[t] = *(const lds_T*)(unsigned long)(base + (unsigned)((48 + jj) * (int)sizeof(T)));
+    if constexpr (SYM) rgw[t] = *(const lds_CT*)(unsigned long)(base + (unsigned)(64 * (int)sizeof(T) + (48 + jj) * (int)sizeof(CT)));
+  };
   // z' = L p of row t of my regions: summation order of calcZ_v4 (pressure_solve_op.cu.cc:81-90).  D and U both call this on
   // the same registers, so they see bitwise the same z'.
   auto zrow = [&](int t) __attribute__((always_inline)) -> Vec<T, V> {
@@ -575,14 +653,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     const Vec<T, V> behind = (jj > 0) ? pp[q][jj > 0 ? jj - 1 : 0] : (kParkHalos ? ldv<T, V>(hs) : pnb[q]);
     const Vec<T, V> cur = pp[q][jj];
     const Vec<T, V> ahead = (jj + 1 < R) ? pp[q][jj + 1 < R ? jj + 1 : jj] : (kParkHalos ? ldv<T, V>(hs + (kParkHalos ? 64 * V : 0)) : pna[q]);
-    const T left = shift_ring<true, T>(cur.v[V - 1], edge[q], jj);
-    const T right = shift_ring<false, T>(cur.v[0], edge[q], jj);
+    const T left = kRingLds ? shift_lane<true, T>(cur.v[V - 1], rgl[t]) : shift_ring<true, T>(cur.v[V - 1], edge[q], jj);
+    const T right = kRingLds ? shift_lane<false, T>(cur.v[0], rgr[t]) : shift_ring<false, T>(cur.v[0], edge[q], jj);
     Vec<CT, V> kN, kE;
     if constexpr (SYM) {
       kN = (jj + 1 < R) ? cS[t + 1 < NT ? t + 1 : t] : cSh[q];
 #pragma unroll
       for (int e = 0; e + 1 < V; ++e) kE.v[e] = cW[t].v[e + 1];
-      kE.v[V - 1] = shift_ring<false, CT>(cW[t].v[0], eW[q], jj);
+      kE.v[V - 1] = kRingLds ? shift_lane<false, CT>(cW[t].v[0], rgw[t]) : shift_ring<false, CT>(cW[t].v[0], eW[q], jj);
     } else {
       kN = cN[t]; kE = cE[t];
     }
@@ -623,12 +701,17 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         if (jj == R - 1 && top[q] && nb_hi) bst<T, V, kSystem>(make_rsrc(sl.rows_hi, mbz), vT[q], zoff_hi, val);
       }
     } else {
-      // the two end cells of the row in ONE store: lane 0 its first cell, lane 63 its last (two separately predicated stores cost
-      // two exec round trips and a handful of register copies per row)
-      const bool last = lane == 63;
-      const T dat = last ? val.v[V - 1] : val.v[0];
-      const unsigned off = vT[q] + (last ? (unsigned)((V - 1) * sizeof(T)) : 0u);
-      if (lane == 0 || last) bst1<T, kAgent>(Rd, off, sT, dat);
+      // the two end cells of the row: lanes 0 and 63 store their cells of the row (16 bytes each; a lane's inner cell is written
+      // too and never read), every other lane carries an offset beyond the buffer and its store is dropped by the range check -
+      // no exec mask to build, no data to select (2 compares + 2 selects per row in a loop that is bound by VALU issue)
+      if constexpr (kLean) {
+        bst<T, V, kAgent>(Rd, vEnd[q], sT, val);
+      } else {
+        const bool last = lane == 63;
+        const T dat = last ? val.v[V - 1] : val.v[0];
+        const unsigned off = vT[q] + (last ? (unsigned)((V - 1) * sizeof(T)) : 0u);
+        if (lane == 0 || last) bst1<T, kAgent>(Rd, off, sT, dat);
+      }
     }
   };
   // ---- z' on the ring, as published by the neighbours (rows below / above, the two neighbouring columns): issued right after
@@ -663,8 +746,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     }
   };
   if (has[0]) {
+    first_fill = true;
 #pragma unroll
-    for (int t = 0; t < D; ++t) issue_coef(t);
+    for (int t = 0; t < (D > kRes ? D : kRes); ++t) issue_coef(t);
+    first_fill = false;
   }
 
   unsigned epoch = c.epoch0;
@@ -700,6 +785,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           for (int e = 0; e < V; ++e) pp[q][jj].v[e] = fma(beta, pp[q][jj].v[e], rr[q][jj].v[e]);
         }
         edge[q] = fma(beta, edge[q], eR[q]);
+        if constexpr (kRingLds) *(lds_T*)(unsigned long)(ring_a + (unsigned)(q * kRingBytes) + (unsigned)lane * (unsigned)sizeof(T)) = edge[q];
         T* hs = halo_s + (kParkHalos ? (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V : 0);
         if constexpr (kParkHalos) {
           pnb[q] = ldv<T, V>(hs); pna[q] = ldv<T, V>(hs + 64 * V);
@@ -715,9 +801,11 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      ring_issue(0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int q = t / R, jj = t - q * R;
+        if (t + 1 < NT) ring_issue(t + 1);
         const Vec<T, V> z = zrow(t);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -730,14 +818,24 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         }
         publish(Rz, q, jj, z);
         PISO_SB_A1;
-        if constexpr (D < NT) issue_coef(t + D < NT ? t + D : t + D - NT);   // wraps: rows 0 .. D-1 again, for U
+        // (rows 0 .. D-1 of the U pass are issued behind the drain of the perimeter stores, see the exchange: issued here they would
+        // be in flight when the wave waits for vmcnt(0), and the wait would cover their trip as well)
+        if constexpr (D < NT) { if (t + D < NT || !(kPrefetchBehindDrain || kZigZag)) issue_coef(t + D < NT ? t + D : t + D - NT); }
         PISO_SB_A2;
       }
     }
     sD[6] = lU[0]; sD[7] = lU[1];
     ++epoch;
     tick(0);
-    healthy = grid_exchange8<T>(c, sD, epoch, smem, NoPrefetch(), (kPersistDiag && c.timing) ? tsub : nullptr);
+    auto prefetch_u = [&]() __attribute__((always_inline)) {
+      if constexpr (kPrefetchBehindDrain && D < NT) {
+        if (has[0]) {
+#pragma unroll
+          for (int t = 0; t < D; ++t) issue_coef(t);
+        }
+      }
+    };
+    healthy = grid_exchange8<T>(c, sD, epoch, smem, prefetch_u, (kPersistDiag && c.timing) ? tsub : nullptr);
     if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl.pv, sD, epoch, smem + 2 * kX1Sm); }
     tick(1);
     if (!healthy) break;
@@ -763,9 +861,12 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     int cnt_wave = 0;                                        // #{|r_{k+1}| >= accuracy} of the whole wave, counted on the scalar unit
     if (has[0]) {
       issue_halos(Rz);
+      ring_issue(kZigZag ? NT - 1 : 0);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
+      for (int tt = 0; tt < NT; ++tt) {
+        const int t = kZigZag ? NT - 1 - tt : tt;
         const int q = t / R, jj = t - q * R;
+        if (tt + 1 < NT) ring_issue(kZigZag ? t - 1 : t + 1);
         T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V + jj * 64 * V;
         Vec<T, V> xv = ldv<T, V>(xl);                        // x += alpha p (:303); the LDS latency hides under the stencil
         const Vec<T, V> z = zrow(t);
@@ -780,10 +881,23 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           rr[q][jj].v[e] = rn;
           lU[0] += rn;
           // (one compare per cell; ballot + popcount + add run on the scalar unit - the loop is bound by VALU issue.  A NaN counts.)
-          cnt_wave += __builtin_popcountll(__ballot(!(absval(rn) < accuracy)));
+          {
+            // (inline asm: left to the compiler the sixteen rows' masks are parked in VGPR lanes - v_writelane / v_readlane pairs,
+            // VALU slots - and counted after the loop)
+            const unsigned long long over = __ballot(!(absval(rn) < accuracy));
+            if constexpr (kLean || PISO_PERSIST1_ASMCNT_SLAB != 0) {
+              int ones;
+              asm volatile("s_bcnt1_i32_b64 %1, %2\n\ts_add_i32 %0, %0, %1" : "+s"(cnt_wave), "=&s"(ones) : "s"(over) : "scc");
+            } else {
+              cnt_wave += __builtin_popcountll(over);
+            }
+          }
         }
         PISO_SB_B1;
-        if constexpr (D < NT) issue_coef(t + D < NT ? t + D : t + D - NT);   // wraps: rows 0 .. D-1 for D of the next iteration
+        if constexpr (D < NT) {
+          if constexpr (kZigZag) { if (t - D >= 0) issue_coef(t - D); }       // downwards; rows D-1 .. 0 stay in registers for the next D pass
+          else issue_coef(t + D < NT ? t + D : t + D - NT);                  // wraps: rows 0 .. D-1 for D of the next iteration
+        }
         PISO_SB_B2;
       }
       // the ring: the same update with the neighbours' z' (beyond a wall there is no cell: the copies stay 0)
