@@ -40,10 +40,21 @@ def _sub(t, stride):
     return a.cpu().numpy()
 
 
-def _check(tag, got, want_sub, want_norm, stride, tol, failures=None):
-    e_sub = rel(_sub(got, stride), want_sub)
-    e_norm = abs(_nrm(got) - want_norm) / want_norm
-    print("%s: rel-L2 on the stride-%d subsample %.2e, |norm - norm_oracle| / norm %.2e  (bound %.0e)" % (tag, stride, e_sub, e_norm, tol))
+def _check(tag, got, want_sub, want_norm, stride, tol, failures=None, scale_norm=None):
+    """rel-L2 on the strided subsample and of the full-array norm.  scale_norm (optional): measure both errors against this
+    full-array scale instead of the norm of the result (a quantity that cancels to a fraction of its summands: float32
+    round-off scales with the summands)."""
+    got_sub = _sub(got, stride)
+    if scale_norm is None:
+        e_sub = rel(got_sub, want_sub)
+        e_norm = abs(_nrm(got) - want_norm) / want_norm
+    else:
+        frac = np.sqrt(float(np.size(want_sub)) / float(got.numel()))          # share of the full-array scale the subsample carries
+        e_sub = float(np.linalg.norm(got_sub.astype(np.float64) - want_sub)) / (scale_norm * frac)
+        e_norm = abs(_nrm(got) - want_norm) / scale_norm
+    print("%s: rel-L2 on the stride-%d subsample %.2e, |norm - norm_oracle| / norm %.2e  (bound %.0e%s)"
+          % (tag, stride, e_sub, e_norm, tol, "" if scale_norm is None else "; relative to the summands, %.2e relative to the result"
+             % rel(got_sub, want_sub)))
     if failures is None:
         assert e_sub < tol and e_norm < tol, (tag, e_sub, e_norm)
     elif not (e_sub < tol and e_norm < tol):
@@ -127,34 +138,36 @@ def _bench_step(fixture, tols):
     (0.5 * (vn.staggered_tensor() ** 2).sum()).backward()
     print("%s: CG iterations adjoint (last solve) %s, oracle %s" % (fixture, P["ps"].last_adjoint_iterations, meta["cg_iterations_adjoint"]))
     _check("dL/du_0", vel_t.grad, d["d_vel_sub"], float(d["d_vel_norm"]), stride, tols["du"], bad)
-    _check("dL/dp_0", p_t.grad, d["d_p_sub"], float(d["d_p_norm"]), stride, tols["dp"], bad)
+    # dL/dp_0 = G^T(-lambda) with dL/du_0 = beta lambda (piso_tf.py:58-60 differentiated): every cell adds four face values
+    # lambda dxdy / dx that cancel to ~1 % (lambda is nearly solenoidal).  Float32 round-off scales with the summands, so the
+    # error is measured against their root-sum-square = sqrt(2) dx |lambda| = sqrt(2) dt / dx |dL/du_0| (every face enters two cells).
+    dx = 2 * np.pi / n
+    summands = np.sqrt(2.0) * float(d["dt"]) / dx * float(d["d_vel_norm"])
+    _check("dL/dp_0", p_t.grad, d["d_p_sub"], float(d["d_p_norm"]), stride, tols["dp"], bad, scale_norm=max(summands, float(d["d_p_norm"])))
     assert not bad, bad
 
 
-# Converged fixtures: what two correct CG solvers that stop at max|r| < 1e-8 may differ by.  u_1 and dL/du_0 are held to the north
-# star's 1e-5.  The pressure itself is only determined to (tolerance / smallest eigenvalue): the two solvers stop at different
-# iterations (the oracle's second corrector after 1005, the GPU's after 1005 .. 1655 depending on the summation order of the dot
-# products) and differ in the smoothest modes, whose gradient - all that reaches u - is negligible: measured 3e-4 .. 3e-3 on p_1,
-# 1e-4 on dL/dp_0 (which cancels to ~1 % of its summands), while u_1 agrees to 3e-6 and dL/du_0 to 7e-7.
-_TIGHT = dict(u=1e-5, p=1e-2, du=1e-5, dp=1e-3)
+# Converged fixtures (round 3: pressure solves to max|r| < 1e-12, advection 1e-9): velocity, PRESSURE and both back-propagated
+# gradients are held to the north star's 1e-5 (dL/dp_0 against the size of its summands, see _bench_step).  At the round-2
+# tolerance of 1e-8 two correct solvers still differed by 3e-3 .. 1e-2 in the pressure's smoothest modes (tolerance / smallest
+# eigenvalue); at 1e-12 that term is ~1e-6 and float32 round-off of the glue is what remains.
+_TIGHT = dict(u=1e-5, p=1e-5, du=1e-5, dp=1e-5)
 
 
 def test_benchmark_workload_1024_converged_solves_forward_and_reverse():
-    """The benchmark's workload at 1024^2 with CONVERGED solves (pressure 1e-8, advection 1e-8 in float32 as in the reference):
+    """The benchmark's workload at 1024^2 with CONVERGED solves (pressure 1e-12, advection 1e-9 in float32 as in the reference):
     forward step and reverse sweep against the oracle."""
     _bench_step("bench1024_tight_step.npz", _TIGHT)
 
 
 def test_benchmark_workload_2048_converged_solves_forward_and_reverse():
-    """The same at the benchmark's own size, 2048^2 (the oracle needed 23 minutes on 8 threads for this fixture: 3005 + 1300
-    forward and 16245 + 22645 adjoint CG iterations).  The smallest eigenvalue is 4x smaller than at 1024^2, so the same residual
-    tolerance leaves 2-4x more room: measured u_1 8.8e-6, p_1 9.7e-3, dL/du_0 1.1e-6, dL/dp_0 2.5e-4."""
-    _bench_step("bench2048_tight_step.npz", dict(u=2e-5, p=3e-2, du=1e-5, dp=1e-3))
+    """The same at the benchmark's own size, 2048^2 (the oracle needs ~1.5 h on 8 threads for this fixture)."""
+    _bench_step("bench2048_tight_step.npz", _TIGHT)
 
 
 def test_benchmark_workload_2048_bench_settings_forward_and_reverse():
     """bench.py's own settings (tol 1e-6 absolute, max_it 10000, reset 1000).  Two correct solvers that stop at an absolute
     residual of 1e-6 agree to ~ 1e-6 / (smallest eigenvalue ~ 5e-4) on the pressure, i.e. ~1e-4 relative on u (measured
     1.2e-4; dL/du_0 1.2e-5 measured), and the adjoint pressure solves stop at the iteration cap, unconverged by the reference's own criterion: the
-    bounds below are what the settings allow, the 1e-5 bar is checked on the converged fixture above."""
+    bounds below are what the settings allow, the 1e-5 bar is checked on the converged fixtures above."""
     _bench_step("bench2048_step.npz", dict(u=5e-4, p=5e-2, du=1e-4, dp=5e-3))

@@ -64,7 +64,10 @@ def test_backward_step_matches_oracle(name, lin_double):
     if name == "cavity":
         kw["p_tol"] = 1e-6      # stay above the float32 inconsistency floor of the shifted system (tests/test_oracle_step.py)
         if not lin_double:
-            pytest.skip("float32 transposed solve of the cavity is borderline at this tolerance: zero-on-failure on either side")
+            # float32 transposed solve: an absolute residual of 1e-8 is at the float32 floor of this system (either side may hit the
+            # reference's zero-on-failure rule there); 1e-6 is a tolerance BOTH sides converge at, and the oracle's answer does not
+            # move between the two (d_vel against a float64 solve: 8.4e-8 at 1e-8, 8.6e-8 at 1e-6)
+            kw["lin_tol"] = 1e-6
     s = oracle_setup(c, **kw)
     P = product_setup(c, **kw)
     rng = np.random.default_rng(2)
