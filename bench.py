@@ -9,14 +9,17 @@ Inputs are synthetic (random solenoidal velocity with E(k) ~ k^4 e
 CFL 0.5, p0 = 0) and resident in HBM before the clock starts.  Solver settings are the reference's training settings:
 tolerance 1e-6, max_iterations 10000, CG residual_reset 1000, pressure solve fp64, advection solve fp32.
 
-Multi-GPU: "replicas" (default) -- every rank runs the same independent 2048^2 problem, no data-path collective; value =
-N * K / max-over-ranks time, scaling "weak".  After the timed region every N > 1 run exercises the slab-decomposed pressure CG
+Multi-GPU (default `--decomp auto`): the headline is the SHARDED step -- ONE 2048 x (2048 N) periodic box cut into y-slabs, a
+2048^2 slab per GPU, every kernel of the step on the rank's rows (assembly, glue, Laplacian; halo rows through peer-mapped
+mailboxes) and both linear solvers slab-decomposed; a step of the box counts as N steps at 2048^2 (scaling "weak"), timed with
+the contract's barriers in a child process per rank.  Beside it: "replicas" -- every rank runs the same independent 2048^2
+problem, no data-path collective (value = N * K / max-over-ranks time) -- and `parallel_efficiency_vs_replicas`; if the sharded
+run fails on a node it has never met, the replicas figure is the line and the exit code is 3.  After the timed regions every
+N > 1 run also exercises the slab-decomposed pressure CG
 on the real node (peer-mapped mailboxes over xGMI, persistent slab kernel, RCCL transport) and reports it INSIDE the JSON line
 (`slab_cg_self_check`: strong- and weak-scaled us per iteration, agreement with single-GPU solves); a failed or hung check
-makes the run exit non-zero.  `--decomp slab` runs the whole bench on ONE grid with both linear solvers (pressure CG, ILU(0)-BiCGStab)
-cut into y-slabs over the ranks and assembly / glue replicated (strong scaling: DESIGN.md 6 explains why that cannot beat the on-chip single-GPU kernel at 2048^2);
-`--decomp slab-weak` decomposes ONE grid x (grid * N) box the same way - every GPU owns a grid^2 slab, a step of the box counts as
-N steps (weak scaling of the sharded path).
+makes the run exit non-zero.  `--decomp slab` shards ONE grid x grid problem the same way (strong scaling: DESIGN.md 6 explains why
+that cannot beat the on-chip single-GPU kernel at 2048^2); `--decomp slab-weak` / `replicas` run one mode only, in this process.
 
 One JSON line on stdout (rank 0) with, besides the contract's keys:
   roofline      the dominant kernel (persistent pressure CG), HIP-event timed inside the timed region.  `achieved` / `frac` are
@@ -161,7 +164,11 @@ def run_unrolled(P, steps, backward=True, clock=None):
         out = dp.run_piso_steps(velocity, pressure, P["domain"], None, {"dt": P["dt"], "dt_ratio": 1},
                                 {"step_count": steps, "loss_influence_range": steps + 1}, None, None, P["sim"], None, None, None)
         vn, warn = out[3], out[6]
-        loss = 0.5 * (vn.staggered_tensor() ** 2).sum()
+        sh = P.get("sharding")
+        if sh is None:
+            loss = 0.5 * (vn.staggered_tensor() ** 2).sum()
+        else:       # slab-decomposed step: L = 1/2 |u_K|^2 is the sum over the ranks of the part on their own face rows
+            loss = 0.5 * ((vn.staggered_tensor() * sh.owned_mask_staggered(vel_t.device)) ** 2).sum()
     if clock is not None:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -423,7 +430,7 @@ def slab_self_check(n, device, rank, world, iters=300, share_gpu=False, settings
             del P5
         # ---- the metric itself with real sharding (`--decomp slab-weak` as one leg): ONE n x (n * world) periodic box, an n^2 slab
         # per GPU, the benchmark's solver settings, one step forward + reverse sweep; a step of the box is `world` steps' worth of n^2
-        legw = os.environ.get("PISO_BENCH_WEAK_STEP_LEG", "1")
+        legw = os.environ.get("PISO_BENCH_WEAK_STEP_LEG", "0")       # (off: the sharded headline run of `--decomp auto` measures this now)
         if settings is not None and (legw == "force" or (legw != "0" and not share_gpu)):
             Pw = build_problem(n, device, settings["tol"], settings["max_iterations"], settings["residual_reset"], ny=n * world)
             cw = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=3 * n + 8)
@@ -469,13 +476,17 @@ def main():
     ap.add_argument("--residual-reset", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the bicgstab / other_configs legs (profiling runs)")
-    ap.add_argument("--decomp", choices=["replicas", "slab", "slab-weak"], default=os.environ.get("PISO_BENCH_DECOMP", "replicas"),
-                    help="N > 1: 'replicas' = one independent grid per GPU (weak); 'slab' = ONE grid x grid problem, both linear "
-                         "solvers cut into y-slabs over the GPUs (peer-mapped mailboxes, persistent slab kernel), assembly / glue "
-                         "replicated (strong); 'slab-weak' = the same decomposition of ONE grid x (grid * N) problem: every GPU owns a "
-                         "grid x grid slab of a taller periodic box, a step of it counts as N steps at grid^2 (weak)")
+    ap.add_argument("--decomp", choices=["auto", "replicas", "slab", "slab-weak"], default=os.environ.get("PISO_BENCH_DECOMP", "auto"),
+                    help="N > 1: 'slab-weak' = ONE grid x (grid * N) periodic box cut into y-slabs, a grid x grid slab per GPU: the "
+                         "WHOLE step is sharded (assembly, glue, Laplacian on the rank's rows with halo rows through peer-mapped "
+                         "mailboxes; both linear solvers slab-decomposed, persistent slab CG kernel), a step of the box counts as N "
+                         "steps at grid^2 (weak); 'slab' = the same for ONE grid x grid problem (strong); 'replicas' = one independent "
+                         "grid per GPU, no data-path collective; 'auto' (default) = replicas timed first, then the slab-weak run in a "
+                         "child process per rank whose result becomes the headline (replicas beside it) - if the sharded run fails on "
+                         "a node it has never met, the replicas line survives and the exit code says so")
     ap.add_argument("--grid-ny", type=int, default=0, help="rows of the grid if different from --grid (a taller periodic box)")
     ap.add_argument("--self-check-child", action="store_true", help=argparse.SUPPRESS)      # (internal: one rank of the N > 1 self-check)
+    ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)         # (internal: one rank of the 'auto' mode's slab-weak run)
     ap.add_argument("--replica-steps-per-s", type=float, default=0.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.self_check_child:
@@ -501,14 +512,19 @@ def main():
 
     import diffpiso._native as N
     n = args.grid
-    slab_weak = world > 1 and args.decomp == "slab-weak"
+    auto = args.decomp == "auto"
+    decomp = "replicas" if auto else args.decomp
+    slab_weak = world > 1 and decomp == "slab-weak"
     ny_grid = n * world if slab_weak else (args.grid_ny if args.grid_ny > 0 else n)
     P = build_problem(n, device, args.tol, args.max_iterations, args.residual_reset, ny=ny_grid)
-    slab = world > 1 and args.decomp in ("slab", "slab-weak")
+    slab = world > 1 and decomp in ("slab", "slab-weak")
     if slab:
         from diffpiso.distributed import SlabCommunicator
-        P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=3 * n + 8)
+        from diffpiso.sharding import StepSharding
+        # mailbox rows: the longest halo message is two face rows of u and three of v, five matrix values each
+        P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=26 * n + 64)
         P["lin"].slab_comm = P["ps"].slab_comm       # the ILU(0)-BiCGStab is cut into the same slabs (dot products all-reduced)
+        P["sharding"] = P["sim"].sharding = StepSharding(P["ps"].slab_comm, n, ny_grid)   # ... and so is everything else of the step
 
     def barrier():
         torch.cuda.synchronize()
@@ -551,6 +567,19 @@ def main():
     verify_runs, verify_failures = N.cg_verify_stats()
     from diffpiso.distributed import max_over_ranks
     elapsed = max_over_ranks(elapsed, device)
+    sharded_info = None
+    grad_norm = float(torch.linalg.vector_norm(grad.double()))
+    if slab:
+        P["sharding"].check()                        # no wait on a peer gave up (agreed over the ranks)
+        tot = torch.tensor([loss, 1.0, float((grad.double() ** 2).sum())], dtype=torch.float64, device="cpu" if share_gpu else device)
+        dist.all_reduce(tot)                         # loss and |dL/du_0|^2 are sums of the ranks' parts; how many ranks took part
+        loss, grad_norm = float(tot[0]), float(tot[2]) ** 0.5
+        st_ = P["ps"].slab_comm.stats()
+        sharded_info = {"ranks_seen": int(round(float(tot[1]))), "rows_per_rank": ny_grid // world, "halo_exchanges": P["sharding"].exchanges,
+                        "persistent_slab_iterations": st_["persistent_iterations"], "persistent_fallbacks": st_["persistent_fallbacks"],
+                        "slab_solves_verified_against_true_residual": st_["solves_verified"], "verification_failures": st_["verification_failures"],
+                        "what_is_sharded": "assembly, padding, stencil glue (forward + reverse mode), Laplacian, CSR product, ILU(0)-BiCGStab, "
+                                           "pressure CG: every kernel of the step works on the rank's rows; nothing is all-gathered"}
 
     out = None
     if rank == 0:
@@ -652,14 +681,16 @@ def main():
                                    "unrolled %d steps, tol %g, max_it %d, CG reset %d, pressure fp64 / advection fp32, "
                                    "%s" % (n, args.steps, args.tol, args.max_iterations, args.residual_reset,
                                            (("ONE %d x %d box, a %d^2 slab per GPU: " % (n, ny_grid, n) if slab_weak else "") +
-                                            "pressure CG and ILU(0)-BiCGStab slab-decomposed over %d GPUs (peer mailboxes), assembly and glue replicated" % world) if slab else
+                                            "the whole step slab-decomposed over %d GPUs (peer-mapped mailboxes: halo rows, all-reduced dot products, persistent slab CG)" % world) if slab else
                                            ("replicas only (one independent grid per GPU)" if world > 1 else "1 GPU")),
                        "grid": [ny_grid, n], "last_cg_iterations_fwd": P["ps"].last_iterations or 0,
                        "last_cg_iterations_adjoint": P["ps"].last_adjoint_iterations or 0,
                        "last_bicgstab_iterations": list(P["lin"].last_iterations or ()),
-                       "loss": loss, "warn": float(sum(float(w.detach().sum()) for w in warn))},
+                       "loss": loss, "grad_norm": grad_norm, "warn": float(sum(float(w.detach().sum()) for w in warn))},
             "roofline": roofline, "phases": phases,
         }
+        if sharded_info is not None:
+            out["sharded"] = sharded_info
         if world == 1 and not args.no_extras and ny_grid == n:
             try:
                 out["bicgstab"] = bicgstab_fixed_work(P, n)
@@ -675,6 +706,50 @@ def main():
             except Exception as e:   # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     rc = 0
+    if world > 1 and auto:
+        # The headline of an N > 1 run is the SHARDED step (`--decomp slab-weak`: ONE grid x (grid N) box, a grid^2 slab per GPU, a
+        # step of the box = N steps' worth of grid^2 cells); the replicas run above stays beside it.  The sharded run happens in a
+        # child process per rank (own process group on another port), with the contract's barrier / max-over-ranks timing inside:
+        # its cross-GPU path has never met real xGMI before the driver's node, and an exception, a hang (600 s limit) or a crash
+        # of the HIP runtime there must not cost the line this process is about to print.
+        import subprocess
+        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 11), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+        cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--decomp", "slab-weak", "--gpus", str(world), "--grid", str(n),
+               "--steps", str(args.steps), "--warmup", str(args.warmup), "--tol", repr(args.tol), "--max-iterations", str(args.max_iterations),
+               "--residual-reset", str(args.residual_reset), "--no-cpu-baseline", "--no-extras"]
+        torch.cuda.synchronize()
+        child, err = None, None
+        try:
+            cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            if cp.returncode != 0:
+                err = {"error": "the sharded run ended with code %d" % cp.returncode, "stderr_tail": cp.stderr[-800:]}
+            elif rank == 0:
+                lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                child = json.loads(lines[-1]) if lines else None
+                if child is None:
+                    err = {"error": "the sharded run printed no line", "stderr_tail": cp.stderr[-800:]}
+        except subprocess.TimeoutExpired:
+            err = {"error": "the sharded run timed out after 600 s"}
+        except Exception as e:
+            err = {"error": repr(e)}
+        okt = torch.tensor([0.0 if err is not None else 1.0], device="cpu" if share_gpu else device)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        all_ok = bool(okt.item() > 0)
+        if rank == 0:
+            replicas = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak",
+                        "note": "one independent %d^2 problem per GPU, no data-path collective (the run timed first)" % n}
+            if all_ok and child is not None:
+                for k in ("value", "ms_per_step", "scaling", "config", "roofline", "phases", "sharded"):
+                    if k in child:
+                        out[k] = child[k]
+                out["replicas"] = replicas
+                out["parallel_efficiency_vs_replicas"] = out["value"] / replicas["value"]
+            else:
+                out["sharded_run"] = err or {"error": "another rank's sharded run failed"}
+                out["replicas_only"] = True
+        if not all_ok:
+            rc = 3
     if world > 1 and not slab and os.environ.get("PISO_BENCH_SLAB_CHECK", "1") != "0":
         # Not part of the metric: exercise the slab-decomposed solvers on the real multi-GPU node; the result travels INSIDE the
         # JSON line (`slab_cg_self_check`).  Every rank runs it in a CHILD process (own process group on the next port): the

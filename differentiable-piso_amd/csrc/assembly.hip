@@ -20,6 +20,7 @@ struct AsmArgs {
   int visc_is_field, nx, ny, per_x, per_y;
   float area[2], spacing[2], beta;
   int n_u, n_v, nnz_u;
+  FaceWin fw;                 // the rows this launch assembles (slab-decomposed step: this rank's face rows)
 };
 
 // closed-form CSR end offset of `row` (calcCsrRowPtrGpu, :472-505, 2-D branch)
@@ -32,8 +33,8 @@ __device__ __forceinline__ int row_end(int row, int i, int j, int W, int H, int 
 }
 
 __global__ __launch_bounds__(kBlock) void assemble_kernel(AsmArgs a) {
-  const int total = a.n_u + a.n_v;
-  for (int g = blockIdx.x * kBlock + threadIdx.x; g < total; g += gridDim.x * kBlock) {
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < a.fw.count(); w += gridDim.x * kBlock) {
+    const int g = a.fw.map(w);
     const int comp = g >= a.n_u;                     // 0: u faces (nx+1, ny); 1: v faces (nx, ny+1)
     const int row = comp ? g - a.n_u : g;
     const int W = a.nx + (comp == 0), H = a.ny + (comp == 1);
@@ -58,7 +59,9 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(AsmArgs a) {
     const int end = row_end(row, i, j, W, H, a.per_x, a.per_y);
     const int start = end - (1 + exists[0] + exists[1] + exists[2] + exists[3]);
     rp[row + 1] = end;
-    if (row == 0) rp[0] = 0;
+    rp[row] = start;                                 // (the same value the row before writes: a windowed launch has no row before its first)
+    // (a windowed launch may own neither first row: the two segment starts and the end of the u segment are closed forms)
+    if (w == 0) { a.rowptr[0] = 0; a.rowptr[a.n_u] = a.nnz_u; a.rowptr[a.n_u + 1] = 0; }
     // slot of an entry = start + number of existing entries with a smaller column (rows are stored column-sorted,
     // which is what the slot arithmetic at :176-210 produces)
     int slot[5];
@@ -166,7 +169,8 @@ int piso_assemble_csr(const float* vel_pad, float* csr_val, int* csr_col, int* c
   a.n_u = (nx + 1) * ny; a.n_v = nx * (ny + 1);
   int nnz_v;
   piso_csr_nnz(nx, ny, a.per_x, a.per_y, &a.nnz_u, &nnz_v);
-  const int g = grid_for((long long)a.n_u + a.n_v, kBlock, 8192);
+  a.fw = face_window(nx, ny);
+  const int g = grid_for((long long)a.fw.count(), kBlock, 8192);
   assemble_kernel<<<g, kBlock, 0, static_cast<hipStream_t>(stream)>>>(a);
   PISO_LAUNCH_CHECK();
   return PISO_OK;

@@ -875,14 +875,15 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
 // y = A x or A^T x on the concatenated CSR (second-corrector H product and its adjoint)
 __global__ __launch_bounds__(kBlock) void csr_matvec_kernel(const float* __restrict__ val_all, const int* __restrict__ rp_all,
                                                             const int* __restrict__ col_all, const float* __restrict__ x,
-                                                            float* __restrict__ y, Geo g, int transpose) {
+                                                            float* __restrict__ y, Geo g, int transpose, int lo0, int hi0, int lo1, int hi1) {
   const int c = blockIdx.y;
   const int n = g.n[c], r0 = g.r0[c], W = g.W[c];
+  const int row_lo = c ? lo1 : lo0, row_hi = c ? hi1 : hi0;     // (slab-decomposed step: this rank's face rows)
   const int* rp = rp_all + (c ? g.n[0] + 1 : 0);
   const int k0 = c ? rp_all[g.n[0]] : 0;
   const float* val = val_all + k0;
   const int* col = col_all + k0;
-  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+  for (int row = row_lo + blockIdx.x * kBlock + threadIdx.x; row < row_hi; row += gridDim.x * kBlock) {
     float acc = 0.f;
     if (!transpose) {
       for (int q = rp[row]; q < rp[row + 1]; ++q) acc = fmaf(val[q], x[r0 + col[q]], acc);
@@ -954,11 +955,14 @@ int piso_csr_matvec_f32(const float* csr_val, const int* csr_rowptr, const int* 
     return PISO_ERR_INVALID_ARG;
   }
   const Geo g = make_geo(nx, ny, 8);
-  const int nmax = g.n[0] > g.n[1] ? g.n[0] : g.n[1];
+  const FaceWin fw = face_window(nx, ny);                  // component-local row ranges (whole components on one GPU)
+  const int lo0 = fw.u_lo, hi0 = fw.u_lo + fw.cu, lo1 = fw.v_lo - g.n[0], hi1 = lo1 + fw.cv;
+  const int nmax = fw.cu > fw.cv ? fw.cu : fw.cv;
   int gv = (nmax + kBlock * 2 - 1) / (kBlock * 2);
   if (gv > 4096) gv = 4096;
+  if (gv < 1) gv = 1;
   csr_matvec_kernel<<<dim3(gv, 2), kBlock, 0, static_cast<hipStream_t>(stream)>>>(csr_val, csr_rowptr, csr_col, x, y, g,
-                                                                                  transpose ? 1 : 0);
+                                                                                  transpose ? 1 : 0, lo0, hi0, lo1, hi1);
   PISO_LAUNCH_CHECK();
   return PISO_OK;
 }

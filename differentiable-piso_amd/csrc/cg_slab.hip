@@ -680,6 +680,54 @@ int piso_comm_stats(void* comm, long long* out4) {      // (six values: see incl
   return PISO_OK;
 }
 
+// Halo rows of ANY globally indexed vector of the slab-decomposed step (faces, cells, CSR values): four messages of up to three
+// element segments each, in the order {to the upper neighbour, to the lower neighbour, from the lower, from the upper};
+// msgs28 = 4 x {count, off[3], len[3]} (element offsets into `vec`).  Ring neighbours always (without a periodic y axis the wrap
+// rows travel and nobody reads them).  One launch; the elements cross xGMI as 8-byte words written into the consumer's mailbox.
+int piso_comm_exchange(void* comm, void* vec, int dtype, const int* msgs28, piso_stream_t stream_) {
+  PisoComm* pc = static_cast<PisoComm*>(comm);
+  if (!pc || !vec || !msgs28) { set_error_msg("piso_comm_exchange: invalid argument"); return PISO_ERR_INVALID_ARG; }
+  if (pc->world == 1) return PISO_OK;
+  if (pc->transport != TRANSPORT_PEER || !pc->connected) { set_error_msg("piso_comm_exchange: needs a connected peer communicator"); return PISO_ERR_INVALID_ARG; }
+  HaloMsg m[4];
+  for (int q = 0; q < 4; ++q) {
+    m[q].count = msgs28[7 * q];
+    size_t total = 0;
+    if (m[q].count < 0 || m[q].count > 3) { set_error_msg("piso_comm_exchange: at most three segments per message"); return PISO_ERR_INVALID_ARG; }
+    for (int k = 0; k < 3; ++k) {
+      m[q].off[k] = msgs28[7 * q + 1 + k]; m[q].len[k] = msgs28[7 * q + 4 + k];
+      if (k < m[q].count) { if (m[q].off[k] < 0 || m[q].len[k] < 0) { set_error_msg("piso_comm_exchange: negative segment"); return PISO_ERR_INVALID_ARG; } total += (size_t)m[q].len[k]; }
+    }
+    if (total > pc->row_cap) { set_error_msg("piso_comm_exchange: message longer than the communicator's row_capacity"); return PISO_ERR_INVALID_ARG; }
+  }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const PeerView pv = make_view(pc, true);
+  const unsigned seq = ++pc->seq_ex;
+  if (dtype == 0) peer_exchange_segments<float><<<2, 256, 0, stream>>>(pv, static_cast<float*>(vec), m[0], m[1], m[2], m[3], seq, pc->err);
+  else if (dtype == 1) peer_exchange_segments<double><<<2, 256, 0, stream>>>(pv, static_cast<double*>(vec), m[0], m[1], m[2], m[3], seq, pc->err);
+  else if (dtype == 2) peer_exchange_segments<int><<<2, 256, 0, stream>>>(pv, static_cast<int*>(vec), m[0], m[1], m[2], m[3], seq, pc->err);
+  else { set_error_msg("piso_comm_exchange: dtype must be 0 (float), 1 (double) or 2 (int32)"); return PISO_ERR_INVALID_ARG; }
+  PISO_LAUNCH_CHECK();
+  return PISO_OK;
+}
+// did any wait on a peer give up since the last call?  (agreed over the ranks; synchronises the stream)
+int piso_comm_check(void* comm, piso_stream_t stream_) {
+  PisoComm* pc = static_cast<PisoComm*>(comm);
+  if (!pc) { set_error_msg("piso_comm_check: NULL communicator"); return PISO_ERR_INVALID_ARG; }
+  if (pc->transport != TRANSPORT_PEER || pc->world == 1) return PISO_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  int herr = 0;
+  peer_agree_on_error<><<<1, 64, 0, stream>>>(make_view(pc, true), pc->err, ++pc->seq_ar);
+  PISO_HIP_CHECK(hipMemcpyAsync(&herr, pc->err, sizeof(int), hipMemcpyDeviceToHost, stream));
+  PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  if (herr) {
+    PISO_HIP_CHECK(hipMemsetAsync(pc->err, 0, sizeof(int), stream));
+    set_error_msg("piso_comm_check: a wait on a peer's mailbox gave up (peer process gone or not running?)");
+    return PISO_ERR_HIP;
+  }
+  return PISO_OK;
+}
+
 size_t piso_cg_slab_workspace_bytes(int nx, int ny_local, int local_ranks) {
   return (size_t)local_ranks * slab_rank_bytes<double>(nx, ny_local) + align_up((size_t)local_ranks * 16 * sizeof(double), 256) + 4096;
 }

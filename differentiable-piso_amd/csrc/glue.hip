@@ -26,11 +26,13 @@ __device__ __forceinline__ int wrap(int i, int n) { return i < 0 ? i + n : (i >=
 __device__ __forceinline__ int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
 
 // ---- custom_padded + flatten (piso_helpers.py:35-55, piso_tf.py:93): padded u [ny+2][nx+3] then padded v [ny+3][nx+2]
+// (pw: the padded rows a windowed launch fills - u_lo / v_lo are element offsets into the padded u / padded v array)
 __global__ __launch_bounds__(kBlock) void pad_velocity_kernel(const float* __restrict__ vel, float* __restrict__ out, int nx, int ny,
-                                                               int per_x, int per_y) {
+                                                               int per_x, int per_y, FaceWin pw) {
   const int n_u = (nx + 1) * ny;
-  const int pu = (ny + 2) * (nx + 3), pv = (ny + 3) * (nx + 2);
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < pu + pv; k += gridDim.x * kBlock) {
+  const int pu = (ny + 2) * (nx + 3);
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < pw.count(); w += gridDim.x * kBlock) {
+    const int k = pw.map(w);
     if (k < pu) {
       const int jj = k / (nx + 3), ii = k - jj * (nx + 3);
       const int j = per_y ? wrap(jj - 1, ny) : clampi(jj - 1, 0, ny - 1);                 // cross axis: (1, 1)
@@ -48,9 +50,10 @@ __global__ __launch_bounds__(kBlock) void pad_velocity_kernel(const float* __res
 
 // ---- A0 = (1 / (beta - A)) * dx_factor on every face, flat "v-first" (piso_tf.py:53-54, piso_cuda_pressure_solver.py:70)
 __global__ __launch_bounds__(kBlock) void a0_vfirst_kernel(const float* __restrict__ A, float* __restrict__ a0, int n_u, int n_v, float beta,
-                                                            float dx_factor) {
-  for (int k = blockIdx.x * kBlock + threadIdx.x; k < n_u + n_v; k += gridDim.x * kBlock) {
-    const int src = k < n_v ? n_u + k : k - n_v;
+                                                            float dx_factor, FaceWin fw) {
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < fw.count(); w += gridDim.x * kBlock) {
+    const int src = fw.map(w);                              // u-first index of the face
+    const int k = src < n_u ? n_v + src : src - n_u;        // its place in the v-first vector
     a0[k] = (1.0f / (beta - A[src])) * dx_factor;
   }
 }
@@ -98,9 +101,9 @@ __global__ __launch_bounds__(kBlock) void face_forward_kernel(GlueGeom g, const 
                                                                const float* __restrict__ A, const float* __restrict__ in0,
                                                                const float* __restrict__ in1, const float* __restrict__ in2,
                                                                const uint8_t* __restrict__ dmask, float* __restrict__ out0,
-                                                               float* __restrict__ out1) {
-  const int nf = (g.nx + 1) * g.ny + g.nx * (g.ny + 1);
-  for (int f = blockIdx.x * kBlock + threadIdx.x; f < nf; f += gridDim.x * kBlock) {
+                                                               float* __restrict__ out1, FaceWin fw) {
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < fw.count(); w += gridDim.x * kBlock) {
+    const int f = fw.map(w);
     const float gp = face_gradient(g, p, acc, f);
     if (MODE == FACE_RHS) {
       float r = in0[f] * g.beta - gp;
@@ -132,9 +135,9 @@ __device__ __forceinline__ float face_weight(const GlueGeom& g, const float* __r
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void face_backward_kernel(GlueGeom g, const float* __restrict__ A, const uint8_t* __restrict__ dmask,
                                                                 const float* __restrict__ d0, const float* __restrict__ d1,
-                                                                float* __restrict__ g0, float* __restrict__ g1, float* __restrict__ g2) {
-  const int nf = (g.nx + 1) * g.ny + g.nx * (g.ny + 1);
-  for (int f = blockIdx.x * kBlock + threadIdx.x; f < nf; f += gridDim.x * kBlock) {
+                                                                float* __restrict__ g0, float* __restrict__ g1, float* __restrict__ g2, FaceWin fw) {
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < fw.count(); w += gridDim.x * kBlock) {
+    const int f = fw.map(w);
     if (MODE == FACE_RHS) {
       const bool m = dmask && dmask[f];
       const float d = m ? 0.0f : d0[f];
@@ -154,9 +157,9 @@ __global__ __launch_bounds__(kBlock) void face_backward_kernel(GlueGeom g, const
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void gradient_adjoint_kernel(GlueGeom g, const float* __restrict__ acc, const float* __restrict__ A,
                                                                    const uint8_t* __restrict__ dmask, const float* __restrict__ d0,
-                                                                   const float* __restrict__ d1, float* __restrict__ dp) {
+                                                                   const float* __restrict__ d1, float* __restrict__ dp, CellWin cw) {
   const int nx = g.nx, ny = g.ny, n_u = (nx + 1) * ny;
-  for (int c = blockIdx.x * kBlock + threadIdx.x; c < nx * ny; c += gridDim.x * kBlock) {
+  for (int c = cw.lo + blockIdx.x * kBlock + threadIdx.x; c < cw.lo + cw.n; c += gridDim.x * kBlock) {
     const int j = c / nx, i = c - j * nx;
     // scaled, masked gradient w.r.t. the face differences: ((w * mask) / h) * dxdy
     auto wu = [&](int k) { const int f = j * (nx + 1) + k; return ((face_weight<MODE>(g, A, dmask, d0, d1, f) * face_mask(acc, 0, j, k, nx)) / g.hx) * g.dxdy; };
@@ -178,9 +181,9 @@ __global__ __launch_bounds__(kBlock) void gradient_adjoint_kernel(GlueGeom g, co
 
 // ---- finite_volume_divergence (piso_helpers.py:277-289) on flat faces
 __global__ __launch_bounds__(kBlock) void divergence_kernel(const float* __restrict__ faces, float* __restrict__ div, int nx, int ny, float dxdy,
-                                                             float hx, float hy) {
+                                                             float hx, float hy, CellWin cw) {
   const int n_u = (nx + 1) * ny;
-  for (int c = blockIdx.x * kBlock + threadIdx.x; c < nx * ny; c += gridDim.x * kBlock) {
+  for (int c = cw.lo + blockIdx.x * kBlock + threadIdx.x; c < cw.lo + cw.n; c += gridDim.x * kBlock) {
     const int j = c / nx, i = c - j * nx;
     const float dy_term = ((faces[n_u + (j + 1) * nx + i] - faces[n_u + j * nx + i]) * dxdy) / hy;
     const float dx_term = ((faces[j * (nx + 1) + i + 1] - faces[j * (nx + 1) + i]) * dxdy) / hx;
@@ -203,9 +206,10 @@ __device__ __forceinline__ float div_adjoint_axis(const float* __restrict__ dc, 
   return -((hi_term * dxdy) / h) + (lo_term * dxdy) / h;
 }
 __global__ __launch_bounds__(kBlock) void divergence_adjoint_kernel(const float* __restrict__ dc, float* __restrict__ dfaces, int nx, int ny,
-                                                                     int per_x, int per_y, float dxdy, float hx, float hy) {
-  const int n_u = (nx + 1) * ny, nf = n_u + nx * (ny + 1);
-  for (int f = blockIdx.x * kBlock + threadIdx.x; f < nf; f += gridDim.x * kBlock) {
+                                                                     int per_x, int per_y, float dxdy, float hx, float hy, FaceWin fw) {
+  const int n_u = (nx + 1) * ny;
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < fw.count(); w += gridDim.x * kBlock) {
+    const int f = fw.map(w);
     if (f < n_u) {
       const int j = f / (nx + 1), i = f - j * (nx + 1);
       dfaces[f] = div_adjoint_axis(dc, 1, j * nx, i, nx, per_x, dxdy, hx);
@@ -218,8 +222,9 @@ __global__ __launch_bounds__(kBlock) void divergence_adjoint_kernel(const float*
 
 // ---- second corrector: H = M d - (A - beta) d on faces (piso_helpers.py:223), div2 = D(H / (beta - A)) (piso_tf.py:66)
 __global__ __launch_bounds__(kBlock) void h_kernel(const float* __restrict__ Md, const float* __restrict__ delta, const float* __restrict__ A,
-                                                    float beta, float* __restrict__ H, float* __restrict__ Hb, int nf) {
-  for (int f = blockIdx.x * kBlock + threadIdx.x; f < nf; f += gridDim.x * kBlock) {
+                                                    float beta, float* __restrict__ H, float* __restrict__ Hb, FaceWin fw) {
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < fw.count(); w += gridDim.x * kBlock) {
+    const int f = fw.map(w);
     const float h = Md[f] - (A[f] - beta) * delta[f];
     H[f] = h;
     Hb[f] = h / (beta - A[f]);
@@ -227,8 +232,9 @@ __global__ __launch_bounds__(kBlock) void h_kernel(const float* __restrict__ Md,
 }
 // reverse: d_Hb = divergence adjoint (computed by the caller into `dHb`), d_H_total = d_H + d_Hb / bmA
 __global__ __launch_bounds__(kBlock) void h_adjoint_kernel(const float* __restrict__ dH, const float* __restrict__ dHb, const float* __restrict__ A,
-                                                            float beta, float* __restrict__ dMd, float* __restrict__ ddelta, int nf) {
-  for (int f = blockIdx.x * kBlock + threadIdx.x; f < nf; f += gridDim.x * kBlock) {
+                                                            float beta, float* __restrict__ dMd, float* __restrict__ ddelta, FaceWin fw) {
+  for (int w = blockIdx.x * kBlock + threadIdx.x; w < fw.count(); w += gridDim.x * kBlock) {
+    const int f = fw.map(w);
     const float t = (dH ? dH[f] : 0.0f) + dHb[f] / (beta - A[f]);
     dMd[f] = t;
     ddelta[f] = -((A[f] - beta) * t);
@@ -246,8 +252,17 @@ extern "C" {
 int piso_pad_velocity(const float* vel_flat, float* vel_pad, int nx, int ny, int periodic_x, int periodic_y, piso_stream_t stream_) {
   if (!vel_flat || !vel_pad || nx < 1 || ny < 1) { set_error_msg("piso_pad_velocity: invalid argument"); return PISO_ERR_INVALID_ARG; }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const long long n = (long long)(ny + 2) * (nx + 3) + (long long)(ny + 3) * (nx + 2);
-  pad_velocity_kernel<<<glue_grid(n), kBlock, 0, stream>>>(vel_flat, vel_pad, nx, ny, periodic_x, periodic_y);
+  // windowed (slab-decomposed step): only the padded rows the assembly of this rank's face rows reads - padded u rows
+  // [j0, j1 + 1 + last), padded v rows [j0, j1 + 2 + last) (assembly.hip: a u row j reads padded u row j + 1 and padded v rows
+  // j + 1, j + 2; a v row j reads padded u rows j, j + 1 and padded v rows j .. j + 2)
+  const RowWin r = row_window();
+  const int pu = (ny + 2) * (nx + 3);
+  FaceWin pw{0, pu, pu, (ny + 3) * (nx + 2)};
+  if (r.on) {
+    const int u_hi = r.j1 + 1 + r.last, v_hi = r.j1 + 2 + r.last;
+    pw = FaceWin{r.j0 * (nx + 3), (u_hi - r.j0) * (nx + 3), pu + r.j0 * (nx + 2), (v_hi - r.j0) * (nx + 2)};
+  }
+  pad_velocity_kernel<<<glue_grid(pw.count()), kBlock, 0, stream>>>(vel_flat, vel_pad, nx, ny, periodic_x, periodic_y, pw);
   PISO_LAUNCH_CHECK();
   return PISO_OK;
 }
@@ -256,7 +271,8 @@ int piso_a0_vfirst(const float* a_flat, float* a0_vfirst, int nx, int ny, float 
   if (!a_flat || !a0_vfirst || nx < 1 || ny < 1) { set_error_msg("piso_a0_vfirst: invalid argument"); return PISO_ERR_INVALID_ARG; }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int n_u = (nx + 1) * ny, n_v = nx * (ny + 1);
-  a0_vfirst_kernel<<<glue_grid(n_u + n_v), kBlock, 0, stream>>>(a_flat, a0_vfirst, n_u, n_v, beta, dx_factor);
+  const FaceWin fw = face_window(nx, ny);
+  a0_vfirst_kernel<<<glue_grid(fw.count()), kBlock, 0, stream>>>(a_flat, a0_vfirst, n_u, n_v, beta, dx_factor, fw);
   PISO_LAUNCH_CHECK();
   return PISO_OK;
 }
@@ -282,10 +298,11 @@ int piso_face_forward(int mode, int nx, int ny, const int* pad_modes, float dxdy
     return PISO_ERR_INVALID_ARG;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int grid = glue_grid((long long)(nx + 1) * ny + (long long)nx * (ny + 1));
-  if (mode == FACE_RHS) face_forward_kernel<FACE_RHS><<<grid, kBlock, 0, stream>>>(g, p, accessible, a_flat, in0, in1, in2, dirichlet, out0, out1);
-  else if (mode == FACE_CORR1) face_forward_kernel<FACE_CORR1><<<grid, kBlock, 0, stream>>>(g, p, accessible, a_flat, in0, in1, in2, dirichlet, out0, out1);
-  else if (mode == FACE_FINAL) face_forward_kernel<FACE_FINAL><<<grid, kBlock, 0, stream>>>(g, p, accessible, a_flat, in0, in1, in2, dirichlet, out0, out1);
+  const FaceWin fw = face_window(nx, ny);
+  const int grid = glue_grid(fw.count());
+  if (mode == FACE_RHS) face_forward_kernel<FACE_RHS><<<grid, kBlock, 0, stream>>>(g, p, accessible, a_flat, in0, in1, in2, dirichlet, out0, out1, fw);
+  else if (mode == FACE_CORR1) face_forward_kernel<FACE_CORR1><<<grid, kBlock, 0, stream>>>(g, p, accessible, a_flat, in0, in1, in2, dirichlet, out0, out1, fw);
+  else if (mode == FACE_FINAL) face_forward_kernel<FACE_FINAL><<<grid, kBlock, 0, stream>>>(g, p, accessible, a_flat, in0, in1, in2, dirichlet, out0, out1, fw);
   else { set_error_msg("piso_face_forward: unknown mode"); return PISO_ERR_INVALID_ARG; }
   PISO_LAUNCH_CHECK();
   return PISO_OK;
@@ -301,11 +318,13 @@ int piso_face_backward(int mode, int nx, int ny, const int* pad_modes, float dxd
     return PISO_ERR_INVALID_ARG;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int gf = glue_grid((long long)(nx + 1) * ny + (long long)nx * (ny + 1)), gc = glue_grid((long long)nx * ny);
+  const FaceWin fw = face_window(nx, ny);
+  const CellWin cw = cell_window(nx, ny);
+  const int gf = glue_grid(fw.count()), gc = glue_grid(cw.n);
 #define PISO_FACE_BWD(M)                                                                                                 \
   do {                                                                                                                   \
-    face_backward_kernel<M><<<gf, kBlock, 0, stream>>>(g, a_flat, dirichlet, d_out0, d_out1, d_in0, d_in1, d_in2);      \
-    gradient_adjoint_kernel<M><<<gc, kBlock, 0, stream>>>(g, accessible, a_flat, dirichlet, d_out0, d_out1, d_p);        \
+    face_backward_kernel<M><<<gf, kBlock, 0, stream>>>(g, a_flat, dirichlet, d_out0, d_out1, d_in0, d_in1, d_in2, fw);  \
+    gradient_adjoint_kernel<M><<<gc, kBlock, 0, stream>>>(g, accessible, a_flat, dirichlet, d_out0, d_out1, d_p, cw);    \
   } while (0)
   if (mode == FACE_RHS) PISO_FACE_BWD(FACE_RHS);
   else if (mode == FACE_CORR1) PISO_FACE_BWD(FACE_CORR1);
@@ -318,7 +337,8 @@ int piso_face_backward(int mode, int nx, int ny, const int* pad_modes, float dxd
 
 int piso_divergence(const float* faces, float* div, int nx, int ny, float dxdy, float hx, float hy, piso_stream_t stream_) {
   if (!faces || !div || nx < 1 || ny < 1) { set_error_msg("piso_divergence: invalid argument"); return PISO_ERR_INVALID_ARG; }
-  divergence_kernel<<<glue_grid((long long)nx * ny), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(faces, div, nx, ny, dxdy, hx, hy);
+  const CellWin cw = cell_window(nx, ny);
+  divergence_kernel<<<glue_grid(cw.n), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(faces, div, nx, ny, dxdy, hx, hy, cw);
   PISO_LAUNCH_CHECK();
   return PISO_OK;
 }
@@ -326,8 +346,9 @@ int piso_divergence(const float* faces, float* div, int nx, int ny, float dxdy, 
 int piso_divergence_adjoint(const float* d_div, float* d_faces, int nx, int ny, int periodic_x, int periodic_y, float dxdy, float hx, float hy,
                             piso_stream_t stream_) {
   if (!d_div || !d_faces || nx < 2 || ny < 2) { set_error_msg("piso_divergence_adjoint: invalid argument"); return PISO_ERR_INVALID_ARG; }
-  divergence_adjoint_kernel<<<glue_grid((long long)(nx + 1) * ny + (long long)nx * (ny + 1)), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(
-      d_div, d_faces, nx, ny, periodic_x, periodic_y, dxdy, hx, hy);
+  const FaceWin fw = face_window(nx, ny);
+  divergence_adjoint_kernel<<<glue_grid(fw.count()), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(
+      d_div, d_faces, nx, ny, periodic_x, periodic_y, dxdy, hx, hy, fw);
   PISO_LAUNCH_CHECK();
   return PISO_OK;
 }
@@ -335,8 +356,8 @@ int piso_divergence_adjoint(const float* d_div, float* d_faces, int nx, int ny, 
 int piso_h_contribution(const float* m_delta, const float* delta, const float* a_flat, float beta, float* h, float* h_over_bma, int nx, int ny,
                         piso_stream_t stream_) {
   if (!m_delta || !delta || !a_flat || !h || !h_over_bma || nx < 1 || ny < 1) { set_error_msg("piso_h_contribution: invalid argument"); return PISO_ERR_INVALID_ARG; }
-  const int nf = (nx + 1) * ny + nx * (ny + 1);
-  h_kernel<<<glue_grid(nf), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(m_delta, delta, a_flat, beta, h, h_over_bma, nf);
+  const FaceWin fw = face_window(nx, ny);
+  h_kernel<<<glue_grid(fw.count()), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(m_delta, delta, a_flat, beta, h, h_over_bma, fw);
   PISO_LAUNCH_CHECK();
   return PISO_OK;
 }
@@ -344,8 +365,8 @@ int piso_h_contribution(const float* m_delta, const float* delta, const float* a
 int piso_h_contribution_adjoint(const float* d_h, const float* d_h_over_bma, const float* a_flat, float beta, float* d_m_delta, float* d_delta,
                                 int nx, int ny, piso_stream_t stream_) {
   if (!d_h_over_bma || !a_flat || !d_m_delta || !d_delta || nx < 1 || ny < 1) { set_error_msg("piso_h_contribution_adjoint: invalid argument"); return PISO_ERR_INVALID_ARG; }
-  const int nf = (nx + 1) * ny + nx * (ny + 1);
-  h_adjoint_kernel<<<glue_grid(nf), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(d_h, d_h_over_bma, a_flat, beta, d_m_delta, d_delta, nf);
+  const FaceWin fw = face_window(nx, ny);
+  h_adjoint_kernel<<<glue_grid(fw.count()), kBlock, 0, static_cast<hipStream_t>(stream_)>>>(d_h, d_h_over_bma, a_flat, beta, d_m_delta, d_delta, fw);
   PISO_LAUNCH_CHECK();
   return PISO_OK;
 }

@@ -9,9 +9,9 @@ namespace piso {
 template <typename T>
 __global__ __launch_bounds__(kBlock) void laplace_kernel(int nx, int ny, const float* __restrict__ active,
                                                          const float* __restrict__ fluid,
-                                                         const float* __restrict__ a0, T* __restrict__ L) {
-  const int n = nx * ny, ms = nx + 2, n_v = nx * (ny + 1);
-  for (int row = blockIdx.x * kBlock + threadIdx.x; row < n; row += gridDim.x * kBlock) {
+                                                         const float* __restrict__ a0, T* __restrict__ L, CellWin cw) {
+  const int ms = nx + 2, n_v = nx * (ny + 1);
+  for (int row = cw.lo + blockIdx.x * kBlock + threadIdx.x; row < cw.lo + cw.n; row += gridDim.x * kBlock) {
     const int i = row % nx, j = row / nx;
     const int me = (i + 1) + (j + 1) * ms;
     // neighbour order of the reference loops (j = dim_size-1 .. 0): y-before, y-after, x-before, x-after
@@ -39,8 +39,9 @@ static int laplace_launch(int nx, int ny, const float* active, const float* flui
     set_error_msg("piso_laplace_matrix: invalid argument");
     return PISO_ERR_INVALID_ARG;
   }
-  const int g = grid_for((long long)nx * ny, kBlock, 4096);
-  laplace_kernel<T><<<g, kBlock, 0, static_cast<hipStream_t>(stream)>>>(nx, ny, active, fluid, a0, L);
+  const CellWin cw = cell_window(nx, ny);                  // (slab-decomposed step: the rows of this rank's cells)
+  const int g = grid_for((long long)cw.n, kBlock, 4096);
+  laplace_kernel<T><<<g, kBlock, 0, static_cast<hipStream_t>(stream)>>>(nx, ny, active, fluid, a0, L, cw);
   PISO_LAUNCH_CHECK();
   return PISO_OK;
 }

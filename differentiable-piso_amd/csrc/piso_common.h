@@ -137,6 +137,35 @@ __device__ __forceinline__ XcdRange xcd_range(int n) {
   return r;
 }
 
+// ---- row window of a slab-decomposed STEP (one process per GPU, so this is a process-wide setting:
+// piso_set_row_window).  Arrays stay globally indexed; the element-wise / gather kernels of the step (assembly, glue, Laplacian,
+// CSR product) then work on the face / cell rows of this rank's y-slab only and read their neighbours' rows from halo rows that
+// piso_comm_exchange filled.  on = 0: the whole grid (one GPU).
+struct RowWin {
+  int on, j0, j1, last;      // cell rows [j0, j1); last: this rank also owns the duplicate face row v[ny]
+};
+RowWin row_window();
+// flat u-first face vector (u [ny][nx+1] then v [ny+1][nx]): the windowed elements are two intervals, walked as one index space
+struct FaceWin {
+  int u_lo, cu, v_lo, cv;
+  __host__ __device__ int count() const { return cu + cv; }
+  __device__ __forceinline__ int map(int w) const { return w < cu ? u_lo + w : v_lo + (w - cu); }
+};
+inline FaceWin face_window(int nx, int ny) {
+  const RowWin r = row_window();
+  const int n_u = (nx + 1) * ny;
+  if (!r.on) return FaceWin{0, n_u, n_u, nx * (ny + 1)};
+  return FaceWin{r.j0 * (nx + 1), (r.j1 - r.j0) * (nx + 1), n_u + r.j0 * nx, (r.j1 - r.j0 + (r.last ? 1 : 0)) * nx};
+}
+struct CellWin {
+  int lo, n;
+};
+inline CellWin cell_window(int nx, int ny) {
+  const RowWin r = row_window();
+  if (!r.on) return CellWin{0, nx * ny};
+  return CellWin{r.j0 * nx, (r.j1 - r.j0) * nx};
+}
+
 inline int grid_for(long long work_items, int per_block, int cap = kMaxPartials) {
   long long g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;

@@ -27,6 +27,8 @@ struct Options {
   }
 };
 static Options g_opt;
+static RowWin g_rows = {0, 0, 0, 0};
+RowWin row_window() { return g_rows; }
 int opt(Opt o) { return g_opt.v[o]; }
 static int opt_index(const char* name) {
   if (!name) return -1;
@@ -50,6 +52,19 @@ int piso_get_option(const char* name, int* value_out) {
   if (i < 0 || !value_out) { piso::set_error_msg("piso_get_option: unknown option"); return PISO_ERR_INVALID_ARG; }
   *value_out = piso::g_opt.v[i];
   return PISO_OK;
+}
+int piso_set_row_window(int row_begin, int row_end, int owns_last_face_row) {
+  if (row_begin < 0 && row_end < 0) { piso::g_rows = piso::RowWin{0, 0, 0, 0}; return PISO_OK; }
+  if (row_begin < 0 || row_end <= row_begin) { piso::set_error_msg("piso_set_row_window: need 0 <= row_begin < row_end"); return PISO_ERR_INVALID_ARG; }
+  piso::g_rows = piso::RowWin{1, row_begin, row_end, owns_last_face_row ? 1 : 0};
+  return PISO_OK;
+}
+int piso_get_row_window(int* row_begin, int* row_end, int* owns_last_face_row) {
+  const piso::RowWin r = piso::g_rows;
+  if (row_begin) *row_begin = r.on ? r.j0 : -1;
+  if (row_end) *row_end = r.on ? r.j1 : -1;
+  if (owns_last_face_row) *owns_last_face_row = r.last;
+  return r.on;
 }
 int piso_device_count(void) {
   int n = 0;

@@ -102,6 +102,14 @@ lib.piso_comm_peer_connect.argtypes = [_vp, _vp]
 lib.piso_comm_peer_connect.restype = _i
 lib.piso_comm_stats.argtypes = [_vp, C.POINTER(C.c_longlong)]
 lib.piso_comm_stats.restype = _i
+lib.piso_set_row_window.argtypes = [_i, _i, _i]
+lib.piso_set_row_window.restype = _i
+lib.piso_get_row_window.argtypes = [_ip, _ip, _ip]
+lib.piso_get_row_window.restype = _i
+lib.piso_comm_exchange.argtypes = [_vp, _vp, _i, _ip, _vp]
+lib.piso_comm_exchange.restype = _i
+lib.piso_comm_check.argtypes = [_vp, _vp]
+lib.piso_comm_check.restype = _i
 lib.piso_cg_slab_workspace_bytes.argtypes = [_i, _i, _i]
 lib.piso_cg_slab_workspace_bytes.restype = _sz
 lib.piso_cg_solve_slab_f64.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _ip, _vp, _sz, _vp]

@@ -80,6 +80,7 @@ class SlabCommunicator(object):
         if rank is None:
             rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
         self.rank, self.world, self.transport = rank, world, transport
+        self.sharded = False                # set by sharding.StepSharding: solver results stay on the rank's rows (no all-gather)
         device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.device = device
         handle = C.c_void_p()

@@ -30,8 +30,9 @@ FACE_RHS, FACE_CORR1, FACE_FINAL = 0, 1, 2
 class Geometry(object):
     """Sizes, spacings and the pressure pad modes of one step (host scalars handed to the kernels by value)."""
 
-    def __init__(self, nx, ny, dx_yx, beta, p_extrapolation, accessible):
+    def __init__(self, nx, ny, dx_yx, beta, p_extrapolation, accessible, sharding=None):
         self.nx, self.ny = int(nx), int(ny)
+        self.sh = sharding                                   # sharding.StepSharding (slab-decomposed step) or None
         self.hy, self.hx = float(dx_yx[0]), float(dx_yx[1])
         self.dxdy = float(np.prod(dx_yx))
         self.beta = float(beta)
@@ -47,6 +48,13 @@ class Geometry(object):
 
     def f(self, v):
         return C.c_float(np.float32(v))
+
+    def new_like(self, t):
+        """Output buffer of a kernel: a windowed launch (slab-decomposed step) fills this rank's rows, the rest must be zero."""
+        return torch.zeros_like(t) if self.sh is not None else torch.empty_like(t)
+
+    def new(self, n, device):
+        return (torch.zeros if self.sh is not None else torch.empty)(n, dtype=torch.float32, device=device)
 
 
 def flat_faces(x):
@@ -64,16 +72,18 @@ def faces_to_grid(flat, geom, box, extrapolation):
 
 
 def pad_velocity(vel_flat, geom, per_x, per_y):
-    out = torch.empty((geom.ny + 2) * (geom.nx + 3) + (geom.ny + 3) * (geom.nx + 2), dtype=torch.float32, device=vel_flat.device)
+    out = geom.new((geom.ny + 2) * (geom.nx + 3) + (geom.ny + 3) * (geom.nx + 2), vel_flat.device)
     N.check(N.lib.piso_pad_velocity(N.ptr(vel_flat), N.ptr(out), geom.nx, geom.ny, int(per_x), int(per_y), N.stream_ptr()),
             "piso_pad_velocity")
     return out
 
 
 def a0_vfirst(a_flat, geom, dx_factor):
-    out = torch.empty_like(a_flat)
+    out = geom.new_like(a_flat)
     N.check(N.lib.piso_a0_vfirst(N.ptr(a_flat), N.ptr(out), geom.nx, geom.ny, geom.f(geom.beta), geom.f(dx_factor), N.stream_ptr()),
             "piso_a0_vfirst")
+    if geom.sh is not None:
+        geom.sh.halo_faces_vfirst(out)                       # the Laplacian of the slab's last cell row reads the face row above it
     return out
 
 
@@ -87,8 +97,10 @@ class _FaceOp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mode, geom, p, in0, in1, in2, a_flat, dmask):
         p, in0, in1, in2 = _c(p), _c(in0), _c(in1), _c(in2)
-        out0 = torch.empty_like(in0)
-        out1 = torch.empty_like(in0) if mode == FACE_CORR1 else None
+        if geom.sh is not None:
+            geom.sh.halo_cells(p)                            # G(p) on the slab's edge faces reads the neighbours' cell rows
+        out0 = geom.new_like(in0)
+        out1 = geom.new_like(in0) if mode == FACE_CORR1 else None
         N.check(N.lib.piso_face_forward(mode, geom.nx, geom.ny, geom.pad_modes, geom.f(geom.dxdy), geom.f(geom.hx), geom.f(geom.hy),
                                         geom.f(geom.beta), N.ptr(p), N.ptr(geom.accessible), N.ptr(a_flat), N.ptr(in0), N.ptr(in1),
                                         N.ptr(in2), N.ptr(dmask), N.ptr(out0), N.ptr(out1), N.stream_ptr()), "piso_face_forward")
@@ -104,10 +116,13 @@ class _FaceOp(torch.autograd.Function):
         mode, geom = ctx.mode, ctx.geom
         d0 = _c(d0)
         d1 = _c(d1) if mode == FACE_CORR1 else None
-        g0 = torch.empty_like(d0)
-        g1 = torch.empty_like(d0) if (mode == FACE_FINAL or (mode == FACE_RHS and ctx.has[0])) else None
-        g2 = torch.empty_like(d0) if (mode == FACE_RHS and ctx.has[1]) else None
-        dp = torch.empty(geom.nx * geom.ny, dtype=torch.float32, device=d0.device)
+        if geom.sh is not None:                              # d p gathers the face cotangents around every cell of the slab
+            d0 = geom.sh.halo_faces(d0.clone())
+            d1 = geom.sh.halo_faces(d1.clone()) if d1 is not None else None
+        g0 = geom.new_like(d0)
+        g1 = geom.new_like(d0) if (mode == FACE_FINAL or (mode == FACE_RHS and ctx.has[0])) else None
+        g2 = geom.new_like(d0) if (mode == FACE_RHS and ctx.has[1]) else None
+        dp = geom.new(geom.nx * geom.ny, d0.device)
         N.check(N.lib.piso_face_backward(mode, geom.nx, geom.ny, geom.pad_modes, geom.f(geom.dxdy), geom.f(geom.hx), geom.f(geom.hy),
                                          geom.f(geom.beta), N.ptr(geom.accessible), N.ptr(ctx.a_flat), N.ptr(ctx.dmask), N.ptr(d0),
                                          N.ptr(d1), N.ptr(g0), N.ptr(g1), N.ptr(g2), N.ptr(dp), N.stream_ptr()), "piso_face_backward")
@@ -120,7 +135,9 @@ class _Divergence(torch.autograd.Function):
     @staticmethod
     def forward(ctx, faces, geom, per_x, per_y):
         faces = _c(faces)
-        div = torch.empty(geom.nx * geom.ny, dtype=torch.float32, device=faces.device)
+        if geom.sh is not None:
+            geom.sh.halo_faces(faces)                        # the slab's last cell row reads the face row above it
+        div = geom.new(geom.nx * geom.ny, faces.device)
         N.check(N.lib.piso_divergence(N.ptr(faces), N.ptr(div), geom.nx, geom.ny, geom.f(geom.dxdy), geom.f(geom.hx), geom.f(geom.hy),
                                       N.stream_ptr()), "piso_divergence")
         ctx.meta = (geom, int(per_x), int(per_y))
@@ -130,7 +147,9 @@ class _Divergence(torch.autograd.Function):
     def backward(ctx, dc):
         geom, per_x, per_y = ctx.meta
         dc = _c(dc)
-        out = torch.empty(geom.n_u + geom.n_v, dtype=torch.float32, device=dc.device)
+        if geom.sh is not None:
+            dc = geom.sh.halo_cells(dc.clone())
+        out = geom.new(geom.n_u + geom.n_v, dc.device)
         N.check(N.lib.piso_divergence_adjoint(N.ptr(dc), N.ptr(out), geom.nx, geom.ny, per_x, per_y, geom.f(geom.dxdy), geom.f(geom.hx),
                                               geom.f(geom.hy), N.stream_ptr()), "piso_divergence_adjoint")
         return out, None, None, None
@@ -142,7 +161,7 @@ class _HContribution(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m_delta, delta, a_flat, geom):
         m_delta, delta = _c(m_delta), _c(delta)
-        h, hb = torch.empty_like(delta), torch.empty_like(delta)
+        h, hb = geom.new_like(delta), geom.new_like(delta)
         N.check(N.lib.piso_h_contribution(N.ptr(m_delta), N.ptr(delta), N.ptr(a_flat), geom.f(geom.beta), N.ptr(h), N.ptr(hb), geom.nx,
                                           geom.ny, N.stream_ptr()), "piso_h_contribution")
         ctx.a_flat, ctx.geom = a_flat, geom
@@ -152,7 +171,7 @@ class _HContribution(torch.autograd.Function):
     def backward(ctx, dh, dhb):
         geom = ctx.geom
         dh, dhb = _c(dh), _c(dhb)
-        d_md, d_delta = torch.empty_like(dhb), torch.empty_like(dhb)
+        d_md, d_delta = geom.new_like(dhb), geom.new_like(dhb)
         N.check(N.lib.piso_h_contribution_adjoint(N.ptr(dh), N.ptr(dhb), N.ptr(ctx.a_flat), geom.f(geom.beta), N.ptr(d_md),
                                                   N.ptr(d_delta), geom.nx, geom.ny, N.stream_ptr()), "piso_h_contribution_adjoint")
         return d_md, d_delta, None, None
@@ -172,7 +191,10 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
     beta = dxdy / dt                                                               # :26
     per_y, per_x = [bool(b) for b in (sim.bool_periodic if sim.bool_periodic is not None else (False, False))]
     acc = sim.accessible_mask_tensor(dev).reshape(-1)
-    geom = Geometry(nx, ny, velocity.dx, beta, pressure.extrapolation, acc)
+    sh = getattr(sim, "sharding", None)                                            # sharding.StepSharding: this rank's y-slab only
+    if sh is not None and (sh.nx, sh.ny) != (nx, ny):
+        raise ValueError("the step sharding was built for a %d x %d grid" % (sh.nx, sh.ny))
+    geom = Geometry(nx, ny, velocity.dx, beta, pressure.extrapolation, acc, sh)
     staggered_shape = (1, ny + 1, nx + 1, 2)
     if warn is None:
         warn = torch.zeros(1, dtype=torch.uint8, device=dev)
@@ -182,9 +204,26 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
     vel_flat = flat_faces(velocity)
     dmask = sim.dirichlet_mask_flat(dev)
     with torch.no_grad():
+        if sh is not None:
+            sh.halo_faces(vel_flat)                                                # the padding / assembly of the slab's edge rows
+            if sh.pattern is None:                                                 # col / rowptr of the whole grid, once
+                N.check(N.lib.piso_set_row_window(-1, -1, 0), "piso_set_row_window")
+                geom.sh = None
+                try:
+                    pad0 = pad_velocity(torch.zeros_like(vel_flat), geom, per_x, per_y)
+                    _, rp0, col0, _, nnz0 = assemble_from_padded(pad0, nx, ny, velocity.dx, per_x, per_y, dmask, sim.active_mask_tensor(dev),
+                                                                 viscosity, sim.no_slip_flat(dev, ny, nx), beta)
+                finally:
+                    geom.sh = sh
+                    N.check(N.lib.piso_set_row_window(sh.j0, sh.j1, int(sh.last)), "piso_set_row_window")
+                sh.set_pattern(col0, rp0, int(nnz0[0]))
         vel_pad = pad_velocity(vel_flat.detach(), geom, per_x, per_y)
         matrix_values, row_pointers, column_indices, Aflat, matrix_nnz = assemble_from_padded(
-            vel_pad, nx, ny, velocity.dx, per_x, per_y, dmask, sim.active_mask_tensor(dev), viscosity, sim.no_slip_flat(dev, ny, nx), beta)
+            vel_pad, nx, ny, velocity.dx, per_x, per_y, dmask, sim.active_mask_tensor(dev), viscosity, sim.no_slip_flat(dev, ny, nx), beta,
+            pattern=sh.pattern if sh is not None else None)
+        if sh is not None:                                                         # the solvers' transposes, the H product and A0 read
+            sh.halo_csr_values(matrix_values)                                      # the matrix rows / diagonal of the neighbouring face rows
+            sh.halo_faces(Aflat)
 
     # Predictor step (:36-47)
     p_data = pressure.data
@@ -202,15 +241,15 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
     with torch.no_grad():
         a0 = a0_vfirst(Aflat, geom, dx_factor)
     p1, _, Lap1 = sim.pressure_solver.solve_flat(a0, v1div, sim, unrolling_step=unrolling_step)
-    geom1 = geom if pressure_inc1.extrapolation == pressure.extrapolation else Geometry(nx, ny, velocity.dx, beta, pressure_inc1.extrapolation, acc)
+    geom1 = geom if pressure_inc1.extrapolation == pressure.extrapolation else Geometry(nx, ny, velocity.dx, beta, pressure_inc1.extrapolation, acc, sh)
     s2, delta = _FaceOp.apply(FACE_CORR1, geom1, p1, star, None, None, Aflat, None)
 
     # Corrector step 2 (:60-73)
-    m_delta = _CsrMatVec.apply(delta, matrix_values, row_pointers, column_indices, nx, ny)
+    m_delta = _CsrMatVec.apply(delta, matrix_values, row_pointers, column_indices, nx, ny, sh)
     H, Hb = _HContribution.apply(m_delta, delta, Aflat, geom)
     H_div = divergence(Hb, geom, per_x, per_y)
     p2, _, Lap2 = sim.pressure_solver.solve_flat(a0, H_div, sim, unrolling_step=1000 + unrolling_step)
-    geom2 = geom if pressure_inc2.extrapolation == pressure.extrapolation else Geometry(nx, ny, velocity.dx, beta, pressure_inc2.extrapolation, acc)
+    geom2 = geom if pressure_inc2.extrapolation == pressure.extrapolation else Geometry(nx, ny, velocity.dx, beta, pressure_inc2.extrapolation, acc, sh)
     s3 = _FaceOp.apply(FACE_FINAL, geom2, p2, s2, H, None, Aflat, None)
     velocity_s3 = faces_to_grid(s3, geom, velocity.box, velocity.extrapolation)
 

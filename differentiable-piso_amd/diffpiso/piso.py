@@ -86,9 +86,12 @@ def pressure_extrapolation(boundaries):
     return Material.accessible_extrapolation_mode(boundaries)
 
 
-def assemble_from_padded(vel_pad, nx, ny, dx_yx, per_x, per_y, dirichlet_mask_flat, active_mask, viscosity, no_slip_wall_mask, beta):
+def assemble_from_padded(vel_pad, nx, ny, dx_yx, per_x, per_y, dirichlet_mask_flat, active_mask, viscosity, no_slip_wall_mask, beta,
+                         pattern=None):
     """The CentralDifferenceMatrixCsr call of advection_matrix_cuda (piso_tf.py:95-123) on an already padded, flattened
-    velocity.  Returns (matrix_values, row_pointers, column_indices, A_flat, matrix_nnz)."""
+    velocity.  Returns (matrix_values, row_pointers, column_indices, A_flat, matrix_nnz).
+    pattern = (col_indices, row_pointers) of the whole grid (slab-decomposed step, sharding.py): the launch assembles this
+    rank's rows only, rewrites their part of the pattern with the same numbers, and values / diagonal elsewhere are zero."""
     dev = vel_pad.device
     dx = dx_yx
     grid_spacing = np.array([dx[1], dx[0]], dtype=np.float32)               # :96
@@ -97,10 +100,15 @@ def assemble_from_padded(vel_pad, nx, ny, dx_yx, per_x, per_y, dirichlet_mask_fl
     N.lib.piso_csr_nnz(nx, ny, int(per_x), int(per_y), C.byref(nnz_u), C.byref(nnz_v))
     n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
     nnz = nnz_u.value + nnz_v.value
-    csr_val = torch.empty(nnz, dtype=torch.float32, device=dev)
-    csr_col = torch.empty(nnz, dtype=torch.int32, device=dev)
-    csr_row = torch.empty(n_u + n_v + 2, dtype=torch.int32, device=dev)
-    diag = torch.empty(n_u + n_v, dtype=torch.float32, device=dev)
+    if pattern is None:
+        csr_val = torch.empty(nnz, dtype=torch.float32, device=dev)
+        csr_col = torch.empty(nnz, dtype=torch.int32, device=dev)
+        csr_row = torch.empty(n_u + n_v + 2, dtype=torch.int32, device=dev)
+        diag = torch.empty(n_u + n_v, dtype=torch.float32, device=dev)
+    else:
+        csr_col, csr_row = pattern
+        csr_val = torch.zeros(nnz, dtype=torch.float32, device=dev)
+        diag = torch.zeros(n_u + n_v, dtype=torch.float32, device=dev)
     visc = as_tensor(viscosity, dtype=torch.float32, device=dev).reshape(-1).contiguous()
     is_field = int(visc.numel() > 1)
     if is_field and visc.numel() != n_u + n_v:
@@ -140,24 +148,28 @@ class _CsrMatVec(torch.autograd.Function):
     gradient (they come from advection_matrix_cuda), the vector's gradient is the transpose product."""
 
     @staticmethod
-    def forward(ctx, x_flat, values, row_ptr, col_indices, nx, ny):
+    def forward(ctx, x_flat, values, row_ptr, col_indices, nx, ny, sharding=None):
         x_flat = x_flat.contiguous()
-        y = torch.empty_like(x_flat)
+        if sharding is not None:
+            sharding.halo_faces(x_flat)                      # the product gathers x from the face rows around the slab
+        y = (torch.zeros_like if sharding is not None else torch.empty_like)(x_flat)
         N.check(N.lib.piso_csr_matvec_f32(N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(x_flat), N.ptr(y),
                                           nx, ny, 0, N.stream_ptr()), "piso_csr_matvec")
         ctx.save_for_backward(values, row_ptr, col_indices)
-        ctx.meta = (nx, ny)
+        ctx.meta = (nx, ny, sharding)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         values, row_ptr, col_indices = ctx.saved_tensors
-        nx, ny = ctx.meta
+        nx, ny, sharding = ctx.meta
         dy = dy.contiguous()
-        dx = torch.empty_like(dy)
+        if sharding is not None:
+            dy = sharding.halo_faces(dy.clone())
+        dx = (torch.zeros_like if sharding is not None else torch.empty_like)(dy)
         N.check(N.lib.piso_csr_matvec_f32(N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(dy), N.ptr(dx),
                                           nx, ny, 1, N.stream_ptr()), "piso_csr_matvec^T")
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 def explicit_H_csr(matrix_values, row_pointers, column_indices, velocity, staggered_shape, A, beta=0):

@@ -89,7 +89,8 @@ def multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol
     rows of the SpMV inputs travel through the mailboxes) and every rank returns the full solution."""
     if slab_comm is not None and slab_comm.world > 1:
         from .distributed import multi_bicgstab_ilu_slab
-        return multi_bicgstab_ilu_slab(slab_comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn)
+        return multi_bicgstab_ilu_slab(slab_comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn,
+                                       gather=not slab_comm.sharded)
     dt = values.dtype
     assert dt in (torch.float32, torch.float64)
     values, rhs, x0 = values.contiguous(), rhs.to(dt).contiguous(), x0.to(dt).contiguous()
@@ -196,7 +197,8 @@ class PoissonSolver(object):
 
 
 def laplace_matrix_native(nx, ny, active, accessible, a0_vfirst, dtype):
-    L = torch.empty(nx * ny * 5, dtype=dtype, device=a0_vfirst.device)
+    # (a row window - the slab-decomposed step - fills this rank's rows only: the others are zero, not uninitialised)
+    L = (torch.zeros if N.lib.piso_get_row_window(None, None, None) else torch.empty)(nx * ny * 5, dtype=dtype, device=a0_vfirst.device)
     fn = N.lib.piso_laplace_matrix_f64 if dtype == torch.float64 else N.lib.piso_laplace_matrix_f32
     N.check(fn(nx, ny, N.ptr(active), N.ptr(accessible), N.ptr(a0_vfirst.contiguous()), N.ptr(L), N.stream_ptr()),
             "piso_laplace_matrix")
@@ -272,7 +274,14 @@ class PisoPressureSolverCudaCustom(PoissonSolver):
 
     def _cg(self, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient, residual_reset):
         if self.slab_comm is not None and self.slab_comm.world > 1 and L.dtype == torch.float64:
-            from .distributed import cg_solve_slab
+            from .distributed import cg_solve_slab, slab_rows
+            if self.slab_comm.sharded:       # slab-decomposed STEP: L and div are valid on this rank's rows, the result stays there
+                x_loc, it = cg_solve_slab(self.slab_comm, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient,
+                                          residual_reset, gather=False)
+                j0, j1 = slab_rows(self.slab_comm.rank, self.slab_comm.world, ny)
+                x = torch.zeros(nx * ny, dtype=x_loc.dtype, device=x_loc.device)
+                x[j0 * nx:j1 * nx] = x_loc
+                return x, it
             return cg_solve_slab(self.slab_comm, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient,
                                  residual_reset)
         return cg_solve_native(nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient, residual_reset)

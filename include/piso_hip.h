@@ -241,6 +241,18 @@ int piso_conv2d_wgrad(const float* in, const float* grad_out, float* dw, int H, 
 int piso_comm_peer_create(int rank, int world, int row_capacity, void** comm_out, void* ipc_handle64_out);
 int piso_comm_peer_connect(void* comm, const void* ipc_handles64_all_ranks);
 int piso_comm_stats(void* comm, long long* out6);
+/* The slab-decomposed STEP (new design, SURVEY.md 8e: assembly, stencil glue and Laplacian on the rows of the rank's y-slab).
+ * piso_set_row_window(j0, j1, owns_last): from now on piso_assemble_csr, piso_pad_velocity, piso_a0_vfirst, piso_face_forward /
+ * _backward, piso_divergence(_adjoint), piso_h_contribution(_adjoint), piso_laplace_matrix_* and piso_csr_matvec_f32 work on the
+ * cell rows [j0, j1) of the GLOBALLY indexed arrays only (u rows [j0, j1), v rows [j0, j1 + owns_last)); (-1, -1, 0) = whole
+ * grid.  Process-wide (one process per GPU).  piso_get_row_window returns 1 if a window is set.
+ * piso_comm_exchange fills halo rows: msgs28 = 4 x {count <= 3, off[3], len[3]} element segments of `vec` {sent to the upper
+ * neighbour, sent to the lower, received from the lower, received from the upper} (ring neighbours); dtype 0 float, 1 double,
+ * 2 int32; peer transport; a no-op on one rank.  piso_comm_check: has a wait on a peer given up (agreed over the ranks)? */
+int piso_set_row_window(int row_begin, int row_end, int owns_last_face_row);
+int piso_get_row_window(int* row_begin, int* row_end, int* owns_last_face_row);
+int piso_comm_exchange(void* comm, void* vec, int dtype, const int* msgs28, piso_stream_t stream);
+int piso_comm_check(void* comm, piso_stream_t stream);
 /* Slab-decomposed ILU(0)-BiCGStab (peer transport): same arguments as piso_multi_bicgstab_ilu_*, all arrays FULL on every rank
  * (the assembly is cheap and replicated); the rank works on the face rows of its ny / world cell rows, which must be whole
  * preconditioner bands (ny / world a multiple of the band height: then the banded ILU(0) is the single-GPU one and the iterates

@@ -77,10 +77,14 @@ def test_config3_temporal_mixing_layer_512x256_four_steps_fwd_adjoint():
     va, pa, vn, pn, warn = dp.unroll_piso_steps(velocity, pressure, c["dt"], P["sim"], step_count=meta["steps"])
     assert float(sum(w.sum() for w in warn)) == 0
     _check("cfg3 u_4", vn.staggered_tensor(), d["vel_sub"], float(d["vel_norm"]), stride, 1e-5)
-    _check("cfg3 p_4", pn.data, d["p_sub"], float(d["p_norm"]), stride, 1e-4)     # pressure level ~ solver tolerance x condition
+    _check("cfg3 p_4", pn.data, d["p_sub"], float(d["p_norm"]), stride, 1e-5)     # (measured 2.4e-6)
     (0.5 * (vn.staggered_tensor() ** 2).sum()).backward()
     _check("cfg3 dL/du_0", vel_t.grad, d["d_vel_sub"], float(d["d_vel_norm"]), stride, 1e-5)
-    _check("cfg3 dL/dp_0", p_t.grad, d["d_p_sub"], float(d["d_p_norm"]), stride, 1e-4)
+    # dL/dp_0 = G^T(-lambda) (+ the pressure cotangent of the later steps) cancels to a few % of its summands lambda dxdy / dx with
+    # dL/du_0 = beta lambda: measured against their root-sum-square (see _bench_step); 5e-5 relative to the result itself
+    dy, dx = (float(v) for v in c["dx_yx"])
+    summands = np.sqrt(2.0) * float(c["dt"]) / min(dx, dy) * float(d["d_vel_norm"])
+    _check("cfg3 dL/dp_0", p_t.grad, d["d_p_sub"], float(d["d_p_norm"]), stride, 1e-5, scale_norm=max(summands, float(d["d_p_norm"])))
 
 
 def test_config4_spatial_mixing_layer_1024x256_cnn_closure_16_step_unroll():
@@ -106,7 +110,7 @@ def test_config4_spatial_mixing_layer_1024x256_cnn_closure_16_step_unroll():
     vn, pn, warn = out[3], out[4], out[6]
     assert float(sum(w.sum() for w in warn)) == 0
     _check("cfg4 u_16", vn.staggered_tensor(), d["vel_sub"], float(d["vel_norm"]), stride, 1e-5)
-    _check("cfg4 p_16", pn.data, d["p_sub"], float(d["p_norm"]), stride, 1e-4)
+    _check("cfg4 p_16", pn.data, d["p_sub"], float(d["p_norm"]), stride, 1e-5)    # (measured 1.6e-6)
     (0.5 * (vn.staggered_tensor() ** 2).sum()).backward()
     _check("cfg4 dL/du_0", vel_t.grad, d["d_vel_sub"], float(d["d_vel_norm"]), stride, 1e-5)
     errs = [rel(w.grad.cpu().numpy(), d["w%d_grad" % k]) for k, w in enumerate(net.weights)]

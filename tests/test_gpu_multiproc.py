@@ -139,7 +139,10 @@ def test_decomposed_step_two_ranks_matches_one_gpu():
     l1, l2 = one["config"]["loss"], two["config"]["loss"]
     print(one["config"], two["config"])
     assert abs(l1 - l2) <= 1e-5 * abs(l1), (l1, l2)
+    assert abs(one["config"]["grad_norm"] - two["config"]["grad_norm"]) <= 1e-5 * one["config"]["grad_norm"]     # |dL/du_0|, summed over the ranks
     assert one["config"]["last_bicgstab_iterations"] == two["config"]["last_bicgstab_iterations"]
+    # the WHOLE step is sharded: every rank assembled / updated its own rows only and nothing was all-gathered
+    assert two["sharded"]["ranks_seen"] == 2 and two["sharded"]["halo_exchanges"] > 0 and two["sharded"]["verification_failures"] == 0
     # (the shifted, rank-deficient operator: CG iteration counts are not reproducible between summation orders - DESIGN.md 4 - and
     # the stopping test runs every 5th iteration)
     assert abs(one["config"]["last_cg_iterations_fwd"] - two["config"]["last_cg_iterations_fwd"]) <= 30
@@ -194,3 +197,17 @@ def test_weak_scaled_decomposed_step_two_ranks_matches_one_gpu():
     assert abs(l1 - l2) <= 1e-5 * abs(l1), (l1, l2)
     assert one["config"]["last_bicgstab_iterations"] == two["config"]["last_bicgstab_iterations"]
     assert abs(two["value"] - 2 * 1e3 / two["ms_per_step"]) <= 1e-6 * two["value"]      # a step of the box counts as two steps at 256^2
+
+
+def test_sharded_step_four_ranks_weak_box_matches_one_gpu():
+    """Four ranks, ONE 128 x 512 periodic box (a 128^2 slab each), two unrolled steps forward + reverse sweep with every kernel of
+    the step on the rank's rows: loss and |dL/du_0| against the same box on one GPU."""
+    common = ["--steps", "2", "--warmup", "0", "--grid", "128", "--no-cpu-baseline", "--no-extras", "--tol", "1e-7"]
+    one = _bench({}, ["--gpus", "1", "--grid-ny", "512"] + common, 1)
+    four = _bench({"PISO_BENCH_SHARE_GPU": "1", "PISO_BENCH_SLAB_CHECK": "0"}, ["--gpus", "4", "--decomp", "slab-weak"] + common, 4)
+    print(one["config"], four["config"], four["sharded"])
+    assert four["config"]["grid"] == [512, 128] == one["config"]["grid"] and four["sharded"]["ranks_seen"] == 4
+    assert abs(one["config"]["loss"] - four["config"]["loss"]) <= 1e-5 * abs(one["config"]["loss"])
+    assert abs(one["config"]["grad_norm"] - four["config"]["grad_norm"]) <= 1e-5 * one["config"]["grad_norm"]
+    assert one["config"]["last_bicgstab_iterations"] == four["config"]["last_bicgstab_iterations"]
+    assert four["sharded"]["verification_failures"] == 0 and four["config"]["warn"] == 0.0
