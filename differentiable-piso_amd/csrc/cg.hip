@@ -28,6 +28,7 @@ struct HostPoll {
 constexpr int kPersistDefaultExchanges = 1;   // grid-wide exchanges per persistent iteration when cg_exchanges is not set
 static std::atomic<unsigned> g_persist_launches{0};   // persistent launches so far: the high half of their exchange tags
 static int g_persist_fallbacks = 0;            // solves that were restarted on the two-kernel path after an exchange timed out
+static bool g_xcd_local_failed = false;        // an XCD-local launch gave up once (the device does not behave as assumed): not tried again
 static long long g_verify_runs = 0;            // solves whose final state was checked against the true residual (cg_verify_gap)
 static int g_verify_failures = 0;              // ... and failed: restarted on the two-kernel path
 // one per device and thread (events belong to the device that was current when they were created); ensure_poll() selects
@@ -178,7 +179,9 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   // ---- persistent segments (cg_persist.h): applicable when every wave's region fits on chip
   int persist_R = 0, persist_NQ = 0, persist_grid = 0;
   PersistCtl pc;
-  pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr; pc.epoch0 = 0;
+  pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr; pc.epoch0 = 0; pc.xcd = nullptr; pc.local_n = 0;
+  bool xcd_local = false;                                // the solve runs on the workgroups of one XCD (cg_persist1<..., LOCAL>)
+  constexpr int kXcdCus = 32;                            // CUs of one MI355X XCD
   const int force = opt(OPT_CG_PERSIST), force_r = opt(OPT_CG_PERSIST_R);   // -1: automatic
   int exchanges = (opt(OPT_CG_EXCHANGES) == 1 || opt(OPT_CG_EXCHANGES) == 2) ? opt(OPT_CG_EXCHANGES) : kPersistDefaultExchanges;
   if (sizeof(T) != 8) exchanges = 2;   // cg_persist1 is tuned for fp64 state (the fp32 instantiations spill registers)
@@ -186,8 +189,15 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     int dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const PersistShape shape = persist_shape(nx, ny, V, cus, force_r);
+    PersistShape shape = persist_shape(nx, ny, V, cus, force_r);
+    // XCD-local mode: symmetric compact coefficients, fp64, one exchange, at most one XCD's worth of workgroups
+    constexpr bool kLocalKernel = RECON && sizeof(CT) == 4 && sizeof(T) == 8;
+    const bool local_ok = kLocalKernel && symmetric && exchanges == 1 && opt(OPT_CG_XCD_LOCAL) != 0 && !g_xcd_local_failed &&
+                          cus == kXcds * kXcdCus;
+    // (measured at 2048^2-class work per workgroup: regions of 4 rows to make a 64-workgroup grid fit one XCD lose more in the row
+    // loops than the shorter exchange wins - 512^2: 6.2 against 4.5 us per iteration; 256^2, 16 workgroups either way: 3.8 against 4.3)
     persist_R = shape.R; persist_NQ = shape.NQ; persist_grid = shape.grid; pc.nreg = shape.nreg; pc.ntx = shape.ntx;
+    xcd_local = local_ok && (persist_R == 2 || persist_R == 4) && persist_grid <= kXcdCus;
     if (persist_R && n < 16384 && force != 1 && !a.nx_true) persist_R = 0;    // tiny grids: two-kernel path (a padded grid is here BECAUSE it is small)
   }
   if (persist_R == 8) exchanges = 2;   // (two regions of 8 rows per wave: cg_persist1 spills there; rare shape)
@@ -197,6 +207,8 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     constexpr bool kRaggedKernel = RECON && sizeof(CT) == 4 && sizeof(T) == 8;
     if (!kRaggedKernel || !symmetric || exchanges != 1 || persist_R == 8) persist_R = 0;
   }
+  if (!persist_R) xcd_local = false;
+  const int launch_grid = xcd_local ? kXcds * persist_grid : persist_grid;   // (XCD-local: some XCD is dealt a full group)
   if (persist_R) {
     // the exchanges spin: EVERY workgroup must be resident at the same time.  What the occupancy calculator says one CU can
     // hold (LDS, registers) times the CUs of the device must cover the grid; what it cannot see (another process, a CU mask)
@@ -208,16 +220,18 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     PISO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPersistThreads, 0));
-    if ((long long)per_cu * cus < persist_grid) persist_R = 0;
+    if ((long long)per_cu * cus < launch_grid) persist_R = 0;
   }
   if (persist_R) {
     pc.rec = reinterpret_cast<unsigned long long*>(persist_ws);
     pc.err = reinterpret_cast<int*>(persist_ws + kPersistWsWords - 16);
     PISO_HIP_CHECK(hipMemsetAsync(persist_ws, 0, kPersistWsWords * sizeof(unsigned), stream));
-    if (persist_grid > kPersistMaxGrid) persist_R = 0;
+    pc.xcd = reinterpret_cast<int*>(persist_ws + (size_t)2 * kPersistMaxGrid * 32);   // 9 words behind the records, before the error flag
+    pc.local_n = xcd_local ? persist_grid : 0;
+    if (launch_grid > kPersistMaxGrid) persist_R = 0;
     if (kPersistDiag && opt_on(OPT_CG_PERSIST_TIMING)) {   // diagnostic builds only: per-phase clocks of every workgroup
-      PISO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&pc.timing), 12 * persist_grid * sizeof(unsigned long long)));
-      PISO_HIP_CHECK(hipMemsetAsync(pc.timing, 0, 12 * persist_grid * sizeof(unsigned long long), stream));
+      PISO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&pc.timing), 12 * launch_grid * sizeof(unsigned long long)));
+      PISO_HIP_CHECK(hipMemsetAsync(pc.timing, 0, 12 * launch_grid * sizeof(unsigned long long), stream));
     }
   }
   auto launch_segment = [&](int kb, int ke) -> int {
@@ -225,9 +239,20 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     // record left by an earlier launch - in memory or in some XCD's L2 - can never pass for one of this launch.  The records are
     // zeroed as well, which covers the counter's wrap.
     pc.epoch0 = (g_persist_launches.fetch_add(1, std::memory_order_relaxed) & 0xffffu) << 16;
-    PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 128, stream));
+    PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 128 + 16 * sizeof(int), stream));   // records + XCD arrivals
     constexpr bool kCanSym = RECON && sizeof(CT) == 4;     // the symmetric variant exists for the compact coefficient path
     if constexpr (kCanSym && sizeof(T) == 8) {
+      if (xcd_local) {                                       // (symmetric, one exchange, regions of 2 / 4 rows: checked above)
+        if (ragged) {
+          if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, true, false, true, true><<<launch_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
+          else cg_persist1<T, CT, 4, 2, RECON, true, false, true, true><<<launch_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
+        } else {
+          if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, true, false, false, true><<<launch_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
+          else cg_persist1<T, CT, 4, 2, RECON, true, false, false, true><<<launch_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
+        }
+        PISO_LAUNCH_CHECK();
+        return PISO_OK;
+      }
       if (ragged) {                                          // padded-grid mode (symmetric, one exchange: checked above)
         if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, true, false, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
         else if (persist_R == 4) cg_persist1<T, CT, 4, 2, RECON, true, false, true><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
@@ -299,6 +324,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
           // A grid-wide exchange gave up: some workgroups were not resident (another kernel or process holds CUs).  The
           // segment's state is unusable; the two-kernel path needs no co-residency: run the whole solve again on it.
           ++g_persist_fallbacks;
+          if (xcd_local) g_xcd_local_failed = true;
           if (pc.timing) { PISO_HIP_CHECK(hipFree(pc.timing)); pc.timing = nullptr; }
           return cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out,
                                          kernel_ms_out, stream, false);

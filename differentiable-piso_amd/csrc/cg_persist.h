@@ -38,6 +38,9 @@ struct PersistCtl {
   int nreg, ntx;        // regions (= waves with work), strips per row
   unsigned epoch0;      // tags of this launch's exchanges are epoch0 + 1, epoch0 + 2, ...: no record of an earlier launch can match
   unsigned long long* timing;   // diagnostics (-DPISO_PERSIST_DIAG + PISO_CG_PERSIST_TIMING): [5][grid] 100 MHz ticks per phase / exchange
+  // XCD-local mode of cg_persist1 (small grids: all participating workgroups on ONE XCD, exchanges through that XCD's L2):
+  int* xcd;             // [0..7] arrivals per XCD, [8] 1 + the XCD that runs the solve (0: not decided yet); zeroed before every launch
+  int local_n;          // workgroups that take part (the launch has 8 x local_n: some XCD is dealt at least local_n of them)
 };
 #ifdef PISO_PERSIST_DIAG
 constexpr bool kPersistDiag = true;     // per-phase clocks of wave 0 (PISO_CG_PERSIST_TIMING=1); costs a few registers

@@ -157,8 +157,11 @@ __device__ __forceinline__ double wave_reduce_scatter8(const double (&v)[8]) {
   c += lanes_xor32(c);
   return c;
 }
-template <typename T, typename F = NoPrefetch>
-__device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Values], unsigned epoch, T* smem,
+// slot / nslots: this workgroup's record and the number of records in play (blockIdx.x / gridDim.x, or the rank / size of the
+// XCD-local group).  LOCAL: every participant runs on the same XCD - records are stored without sc1 (they stay in that XCD's L2)
+// and polled with sc1 loads (L1 bypassed, L2-served): an L2 round trip instead of two trips through the fabric.
+template <typename T, bool LOCAL = false, typename F = NoPrefetch>
+__device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Values], unsigned epoch, T* smem, int slot, int nslots,
                                                F after_drain = F(), unsigned long long* tsub = nullptr) {
   // tsub (diagnostic builds): clocks of [0] reduction + drain of this wave's stores, [1] first barrier, [2] publish + polling,
   // [3] wave sums + second barrier
@@ -194,8 +197,10 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
     for (int w = 0; w < kPersistWaves; ++w) s += sm[vq * kPersistWaves + w];
     const u64 bits = (u64)__double_as_longlong((double)s);
     const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
-    if (lane < kX1RecWords)
-      __hip_atomic_store(rec + (size_t)blockIdx.x * kX1RecWords + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < kX1RecWords) {
+      if constexpr (LOCAL) __hip_atomic_store(rec + (size_t)slot * kX1RecWords + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_store(rec + (size_t)slot * kX1RecWords + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   // (Tried: no barrier here - every wave counts itself in through LDS and the LAST one publishes.  Wave 0 waits 2.3 us of a 7 us
   // exchange in this barrier, but without it the exchange took 8.3 us and the row loops slowed down - 21 us per iteration
@@ -208,7 +213,7 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       w[i] = 0;
-      okl[i] = ((wave * 8 + i) * 4 + sub) >= (int)gridDim.x;   // records beyond the grid count as arrived (payload 0)
+      okl[i] = ((wave * 8 + i) * 4 + sub) >= nslots;           // records beyond the grid count as arrived (payload 0)
     }
     unsigned spins = 0;
     while (true) {
@@ -371,10 +376,19 @@ constexpr int kSystem = 17;                       // buffer cache policy sc0 | s
 
 // RAGGED = true: padded-grid mode (CgArgs::nx_true / ny_true): the rank-1 shift skips the cells of the padding - everything else
 // about them is zero by construction (zero coefficients, zero right-hand side).
-template <typename T, typename CT, int R, int NQ, bool RECON, bool SYM, bool SLAB = false, bool RAGGED = false>
+// LOCAL = true: XCD-local mode for grids that need at most one XCD's worth of workgroups (the small BASELINE configurations,
+// where an iteration is nothing but the exchange: 4.3 us with 16 workgroups spread over the chip).  The launch has 8 x c.local_n
+// workgroups; every one counts itself in on its XCD (HW_REG_XCC_ID), the workgroup that completes the first quota of c.local_n
+// names its XCD the winner, the c.local_n first arrivals there run the solve with their arrival ranks as workgroup numbers and
+// everybody else exits.  Some XCD always collects a quota (8 x local_n workgroups over 8 XCDs), whatever the dispatcher does:
+// placement decides nothing but speed.  Inside the group, published data and records are stored WITHOUT sc1 (they stay in the
+// XCD's L2) and read with sc1 loads (L1 bypassed, L2-served).
+template <typename T, typename CT, int R, int NQ, bool RECON, bool SYM, bool SLAB = false, bool RAGGED = false, bool LOCAL = false>
 __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, PersistCtl c, int k_begin, int k_end, int sv, int pend,
                                                                std::conditional_t<SLAB, SlabCtl, NoSlab> sl = {}) {
   static_assert(!(SLAB && RAGGED), "a slab is never padded");
+  static_assert(!(SLAB && LOCAL), "a slab's neighbours are other GPUs");
+  constexpr int kPub = LOCAL ? kPlain : kAgent;            // cache policy of what other workgroups read inside the launch
   constexpr int V = 16 / sizeof(T);                        // 16-byte lane accesses
   static_assert(R * NQ <= 16 && 2 * R <= 64, "at most 16 rows per wave; the edge columns of a region fit one wave-wide load");
   static_assert(!SLAB || sizeof(T) == 8, "mailbox rows hold 8-byte elements");
@@ -399,6 +413,35 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar branches, SGPRs
   int wg = blockIdx.x;                                     // XCD-contiguous bands (block b is observed on XCD b % 8)
   if (gridDim.x % kXcds == 0) wg = (blockIdx.x % kXcds) * (gridDim.x / kXcds) + blockIdx.x / kXcds;
+  int nslots = (int)gridDim.x;                             // workgroups that take part in the exchanges
+  if constexpr (LOCAL) {
+    __shared__ int local_rank_s;
+    if (threadIdx.x == 0) {
+      const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);       // HW_REG_XCC_ID[3:0]
+      const int arrival = __hip_atomic_fetch_add(c.xcd + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int rank = -1;
+      if (arrival < c.local_n) {
+        if (arrival == c.local_n - 1) {                    // my XCD's quota is complete: the first such XCD wins
+          int none = 0;
+          __hip_atomic_compare_exchange_strong(c.xcd + 8, &none, xcc + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int winner = 0;
+        unsigned spins = 0;
+        while ((winner = __hip_atomic_load(c.xcd + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+          if (++spins > (1u << 22)) break;                 // (cannot happen: some XCD completes a quota; never hang all the same)
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (winner == xcc + 1) rank = arrival;
+        else if (winner == 0) { *c.err = 1; }
+      }
+      local_rank_s = rank;
+    }
+    __syncthreads();
+    wg = local_rank_s;
+    if (wg < 0) return;                                    // not in the group that runs the solve
+    nslots = c.local_n;
+  }
+  const int slot = LOCAL ? wg : (int)blockIdx.x;           // my exchange record
   int j0[NQ], tx0[NQ];
   bool has[NQ];
 #pragma unroll
@@ -694,7 +737,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   auto publish = [&](rsrc_t Rd, int q, int jj, const Vec<T, V>& val) __attribute__((always_inline)) {
     const unsigned sT = row_base(q, jj, rowT);
     if (jj == 0 || jj == R - 1) {
-      bst<T, V, kAgent>(Rd, vT[q], sT, val);
+      bst<T, V, kPub>(Rd, vT[q], sT, val);
       if constexpr (SLAB) {
         // my first row is the row ABOVE the lower neighbour's slab (its side 1), my last row the row BELOW the upper one's (side 0)
         if (jj == 0 && bot[q] && nb_lo) bst<T, V, kSystem>(make_rsrc(sl.rows_lo, mbz), vT[q], zoff_lo, val);
@@ -705,12 +748,12 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       // too and never read), every other lane carries an offset beyond the buffer and its store is dropped by the range check -
       // no exec mask to build, no data to select (2 compares + 2 selects per row in a loop that is bound by VALU issue)
       if constexpr (kLean) {
-        bst<T, V, kAgent>(Rd, vEnd[q], sT, val);
+        bst<T, V, kPub>(Rd, vEnd[q], sT, val);
       } else {
         const bool last = lane == 63;
         const T dat = last ? val.v[V - 1] : val.v[0];
         const unsigned off = vT[q] + (last ? (unsigned)((V - 1) * sizeof(T)) : 0u);
-        if (lane == 0 || last) bst1<T, kAgent>(Rd, off, sT, dat);
+        if (lane == 0 || last) bst1<T, kPub>(Rd, off, sT, dat);
       }
     }
   };
@@ -835,7 +878,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         }
       }
     };
-    healthy = grid_exchange8<T>(c, sD, epoch, smem, prefetch_u, (kPersistDiag && c.timing) ? tsub : nullptr);
+    healthy = grid_exchange8<T, LOCAL>(c, sD, epoch, smem, slot, nslots, prefetch_u, (kPersistDiag && c.timing) ? tsub : nullptr);
     if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl.pv, sD, epoch, smem + 2 * kX1Sm); }
     tick(1);
     if (!healthy) break;
@@ -938,7 +981,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   if (!first && healthy && !st.done) {
     T sX[kX1Values] = {0, 0, 0, 0, 0, 0, lU[0], lU[1]};
     ++epoch;
-    healthy = grid_exchange8<T>(c, sX, epoch, smem);
+    healthy = grid_exchange8<T, LOCAL>(c, sX, epoch, smem, slot, nslots);
     if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl.pv, sX, epoch, smem + 2 * kX1Sm); }
     tOut[1] = sX[6]; tOut[2] = sX[7];
   }
@@ -966,7 +1009,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         }
       }
   }
-  if (blockIdx.x == 0) {
+  if (wg == 0) {                                           // (= blockIdx.x 0, or the first arrival of the XCD-local group)
     // the next launch (cg_k1 with do_check, or another segment) finds the last K2-totals in record 0 of partsB
     for (int b = threadIdx.x; b < a.nB; b += kPersistThreads) {
 #pragma unroll
