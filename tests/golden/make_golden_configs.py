@@ -177,6 +177,13 @@ BENCH_SOLVER = dict(lin_tol=1e-6, lin_max_it=10000, lin_double=False, p_tol=1e-6
 TIGHT_SOLVER = dict(lin_tol=1e-9, lin_max_it=300, lin_double=False, p_tol=1e-12, p_max_it=400000, p_reset=1000)
 
 
+# 2048^2: the ADJOINT pressure solves (right-hand side = an O(1) cotangent) cannot reach an absolute residual of 1e-12 in fp64 - the
+# oracle ran both into a 400000-iteration cap (2.5 h here) - while the forward solves (right-hand side O(1e-3)) do.  The solver's
+# `accuracy` is a plain attribute that is read at every solve (it "may be re-assigned between steps", solvers.py), so the fixture
+# and the test set 1e-12 for the forward step and 1e-10 for the reverse sweep, on both sides alike.
+TIGHT_SOLVER_2048 = dict(TIGHT_SOLVER, p_tol_adjoint=1e-10, p_max_it=200000)
+
+
 def make_bench2048(n=2048, solver=BENCH_SOLVER, name="bench%d_step"):
     BENCH_SOLVER = solver
     import bench
@@ -187,11 +194,15 @@ def make_bench2048(n=2048, solver=BENCH_SOLVER, name="bench%d_step"):
     dt = 0.5 * dx / float(np.abs(vel).max())
     st = (1, n + 1, n + 1, 2)
     ones = np.ones((1, n + 2, n + 2, 1), f32)
-    s = R.OracleSetup(n, n, (dx, dx), (True, True), np.zeros(st, bool), ones, ones, viscosity=1e-3, **BENCH_SOLVER)
     p0 = np.zeros((n, n), f32)
     dv = np.zeros(st, f32)
+    s_kw = dict(BENCH_SOLVER)
+    p_tol_adjoint = s_kw.pop("p_tol_adjoint", None)
+    s = R.OracleSetup(n, n, (dx, dx), (True, True), np.zeros(st, bool), ones, ones, viscosity=1e-3, **s_kw)
     v1, p1, tape = R.piso_step(s, vel, p0, dt, dv, None)
     print("bench%d fwd" % n, tape["it1"], tape["it2"], tape["lin_its"], "%.0fs" % (time.time() - t0), flush=True)
+    if p_tol_adjoint is not None:       # the reverse sweep's pressure solves run at their own tolerance (see TIGHT_SOLVER_2048)
+        s.p_tol = p_tol_adjoint
     g = R.piso_step_backward(s, tape, v1, np.zeros_like(p1))
     print("bench%d bwd" % n, tape["adjoint_its"], "%.0fs" % (time.time() - t0), flush=True)
     meta = dict(grid=n, solver=BENCH_SOLVER, seconds=time.time() - t0, cg_iterations_fwd=[tape["it1"], tape["it2"]],
@@ -215,7 +226,7 @@ if __name__ == "__main__":
     if "bench1024_tight" in which:
         make_bench2048(1024, TIGHT_SOLVER, "bench%d_tight_step")
     if "bench2048_tight" in which:       # (~20 min on 8 cores)
-        make_bench2048(2048, TIGHT_SOLVER, "bench%d_tight_step")
+        make_bench2048(2048, TIGHT_SOLVER_2048, "bench%d_tight_step")
     if "bench512_tight" in which:
         make_bench2048(512, TIGHT_SOLVER, "bench%d_tight_step")
     if "bench512" in which:       # quick look at the workload at a small size (not committed)
