@@ -3,6 +3,7 @@
 #include "cg_kernels.h"
 #include "cg_persist.h"
 #include "cg_persist1.h"
+#include "cg_tiny.h"
 #include "options.h"
 #include <cstdio>
 #include <vector>
@@ -28,6 +29,7 @@ struct HostPoll {
 constexpr int kPersistDefaultExchanges = 1;   // grid-wide exchanges per persistent iteration when cg_exchanges is not set
 static std::atomic<unsigned> g_persist_launches{0};   // persistent launches so far: the high half of their exchange tags
 static int g_persist_fallbacks = 0;            // solves that were restarted on the two-kernel path after an exchange timed out
+static long long g_tiny_solves = 0;            // solves that ran inside one workgroup (cg_tiny.h)
 static bool g_xcd_local_failed = false;        // an XCD-local launch gave up once (the device does not behave as assumed): not tried again
 static long long g_verify_runs = 0;            // solves whose final state was checked against the true residual (cg_verify_gap)
 static int g_verify_failures = 0;              // ... and failed: restarted on the two-kernel path
@@ -480,6 +482,29 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const size_t n_true = (size_t)nx * ny;
+  if (n_true <= (size_t)kTinyMaxCells && opt(OPT_CG_TINY) != 0 && opt(OPT_CG_PERSIST) < 0) {   // (a forced / forbidden persistent path: tests)
+    // a tiny grid (the lid-driven cavity): the whole solve in ONE workgroup, one launch (cg_tiny.h)
+    CgState* st_dev = reinterpret_cast<CgState*>(ws);
+    const int total = fixed ? fixed : max_iterations;
+    hipEvent_t* ev = nullptr;
+    if (kernel_ms_out) {
+      { const int rc = ensure_poll(); if (rc != PISO_OK) return rc; }
+      ev = tl_poll.seg_ev;
+      if (!ev[0]) { PISO_HIP_CHECK(hipEventCreate(&ev[0])); PISO_HIP_CHECK(hipEventCreate(&ev[1])); }
+      PISO_HIP_CHECK(hipEventRecord(ev[0], stream));
+    }
+    cg_tiny<T><<<1, kTinyThreads, 0, stream>>>(L, b, x_out, nx, ny, per_x, per_y, fixed ? -1.0f : accuracy, total, fixed ? 0 : reset,
+                                               rank_deficient, st_dev);
+    PISO_LAUNCH_CHECK();
+    if (ev) PISO_HIP_CHECK(hipEventRecord(ev[1], stream));
+    CgState hst;
+    PISO_HIP_CHECK(hipMemcpyAsync(&hst, st_dev, sizeof(CgState), hipMemcpyDeviceToHost, stream));
+    PISO_HIP_CHECK(hipStreamSynchronize(stream));
+    ++g_tiny_solves;
+    if (iterations_out) *iterations_out = (!fixed && hst.done) ? hst.iterations : total;
+    if (ev) { float ms = 0; PISO_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[1])); kernel_ms_out[0] = total > 0 ? ms / (float)total : 0.f; kernel_ms_out[1] = 0.f; }
+    return PISO_OK;
+  }
   int nxp = nx, nyp = ny;
   const bool padded = opt(OPT_CG_PERSIST) != 0 && opt(OPT_CG_PAD) != 0 &&
                       padded_dims(nx, ny, per_x, per_y, (int)sizeof(T), &nxp, &nyp);      // (see padded_dims)
@@ -596,6 +621,7 @@ void piso_cg_profile_enable(int enable, int stride) {
 }
 
 int piso_cg_persist_fallbacks(void) { return g_persist_fallbacks; }
+long long piso_cg_tiny_solves(void) { return g_tiny_solves; }
 void piso_cg_verify_stats(long long* runs_out, int* failures_out) {
   if (runs_out) *runs_out = g_verify_runs;
   if (failures_out) *failures_out = g_verify_failures;

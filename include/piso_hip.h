@@ -180,6 +180,9 @@ void piso_cg_profile_read(double* ms_sum, long long* count);
 /* Solves (since load) that were restarted on the two-kernel path because a grid-wide exchange of the persistent kernel timed
  * out (workgroups not co-resident: CU mask, another process on the GPU).  0 on a dedicated GPU. */
 int piso_cg_persist_fallbacks(void);
+/* Solves of grids of at most 4 608 cells run inside ONE workgroup, one launch for the whole solve (csrc/cg_tiny.h: the lid-driven
+ * cavity of BASELINE.json's config 1); same iteration and control flow as the chip-wide paths.  Option "cg_tiny": 0 = never. */
+long long piso_cg_tiny_solves(void);
 /* Every fp64 solve that ran iterations inside the persistent kernel is VERIFIED before it returns: the recurrence residual r must
  * equal b - (L x + c sum x) for the returned x to 1e-5 max|b| (one extra stencil pass).  The persistent kernel publishes perimeter
  * rows without release / acquire fences; a value read before it was visible would break exactly this identity.  A failed check

@@ -368,6 +368,7 @@ def test_cg_padded_grid_mode(shape, rank_deficient, reset, piso_option):
     from diffpiso.solvers import cg_solve_native
     nx, ny = shape
     L, b = case(nx, ny, walls=True)
+    piso_option("cg_tiny", 0)                     # (grids of <= 4 608 cells would run inside one workgroup, csrc/cg_tiny.h: not what is tested here)
     runs0, fails0 = N.cg_verify_stats()
     fb0 = N.lib.piso_cg_persist_fallbacks()
     for nit in (2, 7, 25, 60):
@@ -403,3 +404,31 @@ def test_cg_padded_grid_mode(shape, rank_deficient, reset, piso_option):
         xo_t = torch.tensor(xo, device="cuda")
         ro = xo_t - xo_t.mean() if rank_deficient else xo_t
         assert float((ro - got).abs().max() / ro.abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("shape,reset", [((65, 64), 10), ((16, 12), 1000), ((48, 96), 25), ((36, 128), 7)])
+def test_cg_tiny_single_workgroup_matches_oracle(name, shape, reset):
+    """Grids of at most 4 608 cells (the lid-driven cavity's 64 x 65) are solved inside ONE workgroup in one launch (csrc/cg_tiny.h),
+    residual resets included: fixed-iteration trajectories against the oracle to round-off, the stopping cadence, the rank-1 shift."""
+    from diffpiso.solvers import cg_solve_native
+    from diffpiso import _native as N
+    s, L, b = _laplace_case(name, shape[0], shape[1], seed=7)
+    px, py = s.periodic_yx[1], s.periodic_yx[0]
+    before = int(N.lib.piso_cg_tiny_solves())
+    for rank_def in (False, True):
+        for nit in (1, 2, 3, 9, 10, 11, 23, 47):
+            x, it = cg_solve_native(s.nx, s.ny, px, py, dev(L), dev(b), 1e-30, nit, rank_def, reset)
+            xo, ito = O.cg_solve(s.nx, s.ny, px, py, L, b, 1e-30, nit, rank_def, reset)
+            assert it == ito == nit
+            if not rank_def:      # (with the shift the operator is indefinite: trajectories depend on the summation order, DESIGN.md 4)
+                assert np.abs(x.cpu().numpy() - xo).max() <= (1e-9 if nit <= 23 else 1e-6) * np.abs(xo).max(), (rank_def, nit)
+    x, it = cg_solve_native(s.nx, s.ny, px, py, dev(L), dev(b), 1e-9, 6000, False, reset)
+    xo, ito = O.cg_solve(s.nx, s.ny, px, py, L, b, 1e-9, 6000, False, reset)
+    if ito < 6000:
+        assert abs(it - ito) <= max(5, 0.1 * ito), (it, ito)
+        assert it % 5 == 0 and it >= 10
+        assert np.abs(x.cpu().numpy() - xo).max() <= 1e-6 * np.abs(xo).max()
+    else:
+        assert it == 6000
+    assert int(N.lib.piso_cg_tiny_solves()) - before == 2 * 8 + 1, "the single-workgroup kernel did not run"
