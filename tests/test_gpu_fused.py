@@ -140,8 +140,13 @@ def test_fused_step_matches_the_torch_transcription(name):
     print("fused vs torch glue:", name, {k: "%.1e" % v for k, v in errs.items()})
     # (cavity: the rank-deficient CG stops at slightly different iterations for 1-ulp different inputs, tests/test_gpu_configs.py)
     assert errs["u"] < (2e-5 if name == "cavity" else 2e-6) and errs["p"] < 2e-5
-    assert errs["d_vel"] < 1e-5 and errs["d_forcing"] < 1e-5
-    assert errs["d_p"] < 5e-4            # cancels to ~1 % of its summands (DESIGN.md "Oracle", findings)
+    # cavity: the two runs' ADJOINT pressure solves see right-hand sides that differ by 1 ulp, and on the shifted, inconsistent
+    # system (absolute tolerance 1e-6) they then stop at different iterations: the gradients agree at the solver-tolerance level
+    # only (measured 6e-3 with the single-workgroup CG this 24 x 40 grid runs on, 1e-5 by luck of an identical stopping iteration
+    # with the chip-wide kernels).  The glue itself is held to round-off by the other three set-ups and the per-kernel tests above.
+    g_tol = 2e-2 if name == "cavity" else 1e-5
+    assert errs["d_vel"] < g_tol and errs["d_forcing"] < g_tol
+    assert errs["d_p"] < (2e-2 if name == "cavity" else 5e-4)            # cancels to ~1 % of its summands (DESIGN.md "Oracle", findings)
     # cavity: the adjoint pressure solves are rank deficient; their constant mode (mean(b) / (c N), round-off of the CG) is
     # invisible to every interior face but feeds the wall faces through the divergence adjoint: d/d(dirichlet) is not a
     # reproducible quantity there (the two paths differ by O(1), the oracle likewise)
