@@ -50,32 +50,55 @@ __global__ __launch_bounds__(kBlock) void conv_forward_kernel(ConvGeom g, const 
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int ky = 0; ky < KS; ++ky) {
-    const int yy = y + ky - g.pad;
-    if (yy < 0 || yy >= g.H) continue;                       // (wave-uniform: a whole tap row of zero padding)
+  if constexpr (CINP >= 16) {
+    // Software pipeline over the K-blocks (tap row, tap column, block of 16 channels): the operands of block s + 1 are loaded while
+    // the 16 MT NT / 4 MFMAs of block s run - issued and consumed in the same block the loop ran at the latency of one L2 round
+    // trip per block (forward 3 x 3, 64 -> 64: 264 us at 256 x 896, 40 % of the fp32 MFMA peak).
+    constexpr int CB = CINP / 16, NSEQ = KS * CB;
+    auto load_ab = [&](int yy, int sidx, f32x4 (&a)[MT], f32x4 (&b)[NT], int ky) __attribute__((always_inline)) {
+      const int kx = sidx / CB, cb = sidx - kx * CB;
 #pragma unroll
-    for (int kx = 0; kx < KS; ++kx) {
-      if constexpr (CINP >= 16) {
+      for (int m = 0; m < MT; ++m) {
+        const int xx = x0 + 16 * m + ai + kx - g.pad;
+        a[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (xx >= 0 && xx < g.W) a[m] = *reinterpret_cast<const f32x4*>(in + ((size_t)yy * g.W + xx) * g.cin + 16 * cb + 4 * ak);
+      }
 #pragma unroll
-        for (int cb = 0; cb < CINP / 16; ++cb) {
-          f32x4 a[MT], b[NT];
+      for (int n = 0; n < NT; ++n)
+        b[n] = *reinterpret_cast<const f32x4*>(w + ((((size_t)(ky * KS + kx) * CB + cb) * 4 + ak) * COUTP + 16 * n + ai) * 4);
+    };
+    for (int ky = 0; ky < KS; ++ky) {
+      const int yy = y + ky - g.pad;
+      if (yy < 0 || yy >= g.H) continue;                     // (wave-uniform: a whole tap row of zero padding)
+      f32x4 a0[MT], b0[NT], a1[MT], b1[NT];
+      load_ab(yy, 0, a0, b0, ky);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const int xx = x0 + 16 * m + ai + kx - g.pad;
-            a[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (xx >= 0 && xx < g.W) a[m] = *reinterpret_cast<const f32x4*>(in + ((size_t)yy * g.W + xx) * g.cin + 16 * cb + 4 * ak);
-          }
+      for (int sq = 0; sq < NSEQ; sq += 2) {
+        if (sq + 1 < NSEQ) load_ab(yy, sq + 1, a1, b1, ky);
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
-            b[n] = *reinterpret_cast<const f32x4*>(w + ((((size_t)(ky * KS + kx) * (CINP / 16) + cb) * 4 + ak) * COUTP + 16 * n + ai) * 4);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m][j], b0[n][j], acc[m][n], 0, 0, 0);
+        if (sq + 1 < NSEQ) {
+          if (sq + 2 < NSEQ) load_ab(yy, sq + 2, a0, b0, ky);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-              for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][j], b[n][j], acc[m][n], 0, 0, 0);
+              for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m][j], b1[n][j], acc[m][n], 0, 0, 0);
         }
-      } else {
+      }
+    }
+  } else {
+  for (int ky = 0; ky < KS; ++ky) {
+    const int yy = y + ky - g.pad;
+    if (yy < 0 || yy >= g.H) continue;                       // (wave-uniform: a whole tap row of zero padding)
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      {
         static_assert(CINP == 4, "up to 4 input channels: one K-step per tap");
         float a[MT], b[NT];
 #pragma unroll
@@ -91,6 +114,7 @@ __global__ __launch_bounds__(kBlock) void conv_forward_kernel(ConvGeom g, const 
           for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
       }
     }
+  }
   }
   // C/D layout: column (co) = lane & 15, row (pixel) = (lane >> 4) * 4 + register
 #pragma unroll
@@ -200,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad64_kernel(ConvGeom g, const 
   constexpr int TAPS = KS * KS, U = 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ai = lane & 15, ak = lane >> 4;
-  const int tap = blockIdx.y * 4 + wave;
+  const int tap = blockIdx.y * 3 + wave;                   // (workgroups of three waves: the nine taps of a 3 x 3 kernel fill three of them)
   if (tap >= TAPS) return;
   const int ky = tap / KS, kx = tap - ky * KS;
   f32x4 acc[4][4];
@@ -259,7 +283,9 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_reduce_kernel(const float* 
   if (wave == 0 && k < n) dw[k] = ((sm[threadIdx.x] + sm[64 + threadIdx.x]) + sm[128 + threadIdx.x]) + sm[192 + threadIdx.x];
 }
 
-constexpr int kWgradMaxBlocks = 128;          // row bands = partial sums per weight: what the second stage has to add (and re-read)
+// row bands = partial sums per weight: what the second stage has to add (and re-read).  256: one output row per band at config 4's
+// size - with bands of two rows the 9 x 126 waves of the 64 -> 64 layer left SIMDs with two waves next to SIMDs with one
+constexpr int kWgradMaxBlocks = 256;
 
 template <int KS, int CINP, int NT>
 static int launch_forward(const ConvGeom& g, const float* in, const float* w, float* out, int leaky, hipStream_t stream) {
@@ -291,7 +317,36 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 using namespace piso;
 
+namespace piso {
+// g' = g * leaky'(pre-activation) from the layer's saved OUTPUT (a leaky ReLU with a positive slope keeps the sign): the gradient of
+// the pre-activation that both the input gradient and the weight gradient consume.  One pass (torch: a multiply and a where).
+__global__ __launch_bounds__(kBlock) void leaky_backward_kernel(const float* __restrict__ g, const float* __restrict__ out, float* __restrict__ gp, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (size_t)gridDim.x * kBlock) {
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i], ov = reinterpret_cast<const f32x4*>(out)[i];
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = ov[q] > 0.f ? gv[q] : kLeakySlope * gv[q];
+    reinterpret_cast<f32x4*>(gp)[i] = r;
+  }
+}
+__global__ __launch_bounds__(kBlock) void leaky_backward_tail_kernel(const float* __restrict__ g, const float* __restrict__ out, float* __restrict__ gp, size_t begin, size_t n) {
+  const size_t i = begin + (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) gp[i] = out[i] > 0.f ? g[i] : kLeakySlope * g[i];
+}
+}  // namespace piso
+
 extern "C" {
+int piso_leaky_relu_backward(const float* grad_out, const float* out, float* grad_pre, size_t n, piso_stream_t stream_) {
+  using namespace piso;
+  if (!grad_out || !out || !grad_pre) { set_error_msg("piso_leaky_relu_backward: invalid argument"); return PISO_ERR_INVALID_ARG; }
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(grad_pre)) & 15) == 0;
+  const size_t n4 = aligned ? n / 4 : 0;
+  if (n4 > 0) leaky_backward_kernel<<<grid_for((long long)n4, kBlock * 2, 4096), kBlock, 0, stream>>>(grad_out, out, grad_pre, n4);
+  if (n4 * 4 < n) leaky_backward_tail_kernel<<<(int)((n - n4 * 4 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(grad_out, out, grad_pre, n4 * 4, n);
+  PISO_LAUNCH_CHECK();
+  return PISO_OK;
+}
 
 static inline int padded_cin(int cin) { return cin <= 4 ? 4 : round_up(cin, 16); }
 
@@ -345,7 +400,7 @@ int piso_conv2d_wgrad(const float* in, const float* grad_out, float* dw, int H, 
   if (cin == 64 && cout == 64 && ks == 3) {      // (measured: 304 us against 329 us for the generic kernel at 250 x 876; the 1 x 1
     // layer has a single tap, i.e. one busy wave per workgroup here, and stays on the generic kernel: 130 us against 219 us)
     const int rows_per_block = (g.Ho + kWgradMaxBlocks - 1) / kWgradMaxBlocks, nblocks = (g.Ho + rows_per_block - 1) / rows_per_block;
-    conv_wgrad64_kernel<3><<<dim3(nblocks, 3), kBlock, 0, stream>>>(g, in, grad_out, part, rows_per_block);
+    conv_wgrad64_kernel<3><<<dim3(nblocks, 3), 192, 0, stream>>>(g, in, grad_out, part, rows_per_block);
     PISO_LAUNCH_CHECK();
     conv_wgrad_reduce_kernel<<<(ks * ks * 4096 + 63) / 64, kBlock, 0, stream>>>(part, dw, nblocks, ks * ks, 64, 64, 64, 64);
     PISO_LAUNCH_CHECK();

@@ -90,6 +90,8 @@ lib.piso_conv2d_forward.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _
 lib.piso_conv2d_forward.restype = _i
 lib.piso_conv2d_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]
 lib.piso_conv2d_wgrad.restype = _i
+lib.piso_leaky_relu_backward.argtypes = [_vp, _vp, _vp, _sz, _vp]
+lib.piso_leaky_relu_backward.restype = _i
 
 lib.piso_comm_unique_id.argtypes = [_vp]
 lib.piso_comm_unique_id.restype = _i

@@ -76,7 +76,12 @@ class _Conv2dLeaky(torch.autograd.Function):
         pad, leaky, Ho, Wo = ctx.meta
         cout, cin, k, _ = w_oihw.shape
         _, H, W, _ = x.shape
-        g = (torch.where(out > 0, g, 0.2 * g) if leaky else g).contiguous()
+        g = g.contiguous()
+        if leaky:                                            # g' = g leaky'(pre-activation): one fused pass
+            gp = torch.empty_like(g)
+            N.check(N.lib.piso_leaky_relu_backward(N.ptr(g), N.ptr(out), N.ptr(gp), C.c_size_t(g.numel()), N.stream_ptr()),
+                    "piso_leaky_relu_backward")
+            g = gp
         dx = dw = None
         if ctx.needs_input_grad[0]:
             # dx = conv(g', Wd), Wd[ky][kx][co][ci] = W[k-1-ky][k-1-kx][ci][co], zero padding k - 1 - pad

@@ -212,6 +212,8 @@ int piso_conv2d_forward(const float* in, const float* w_laid_out, float* out, in
                         int leaky_out, piso_stream_t stream);
 int piso_conv2d_wgrad(const float* in, const float* grad_out, float* dw, int H, int W, int cin, int cout, int ks, int pad,
                       void* workspace, size_t workspace_bytes, piso_stream_t stream);
+/* grad_pre = grad_out * leaky_relu'(pre-activation) (slope 0.2), from the layer's saved output (same sign as the pre-activation). */
+int piso_leaky_relu_backward(const float* grad_out, const float* out, float* grad_pre, size_t n, piso_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Slab-decomposed pressure CG (no counterpart in the reference, which is single-GPU).
