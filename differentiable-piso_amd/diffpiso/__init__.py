@@ -21,7 +21,8 @@ from .stencils import (arrange_rhs_term_tf, calculate_centered_shape, calculate_
                        custom_padded, finite_volume_divergence, finite_volume_gradient_tensor, flatten_staggered_data,
                        padded_velocity_flat, stagger_flattened_data, vorticity)
 from .datamanagement import create_base_dir, data_path_assembler, load_frame, load_function, make_dataset, save_frame, save_source
-from .evaluation_tools import EK_spectrum_1D_tf, EK_spectrum_2D, EK_spectrum_2D_tf, tf_fftshift
+from .evaluation_tools import (EK_spectrum_1D_tf, EK_spectrum_2D, EK_spectrum_2D_tf, EK_spectrum_3D, spectral_analysis_1Dspace,
+                               spectral_analysis_2Dspace, spectral_analysis_time, tf_fftshift, vorticity_correlation, vorticity_structure)
 from .les import smagorinsky_eddy_viscosity, strain_tensor, strain_tensor_centered
 from .losses import L2_field_loss, multistep_averaging_loss, spectral_energy_loss, strain_rate_loss
 from .setups import (compute_mixingLayer_masks, spatialMixingLayer_setup, sponge_viscosity_field, temporal_mixing_layer_masks,

@@ -348,6 +348,15 @@ class StaggeredGrid(object):
     def unstack(self):
         return self.data
 
+    def padded(self, widths):
+        """staggered_grid.py:222-228: every component padded by `widths` cells with its extrapolation mode, the box grown to match."""
+        comps = [c.padded(widths).data for c in self.data]
+        if isinstance(widths, int):
+            widths = [[widths, widths]] * self.rank
+        w_lo, w_hi = np.array([w[0] for w in widths]), np.array([w[1] for w in widths])
+        box = AABox(self.box.lower - w_lo * self.dx, self.box.upper + w_hi * self.dx)
+        return StaggeredGrid(comps, box, extrapolation=self.extrapolation)
+
     def at(self, other):
         """staggered_grid.py `at`: every component resampled to the matching face points of `other` (a StaggeredGrid over
         any resolution / box).  A component is a cell-centred array over the box grown by half a cell along its own axis."""

@@ -140,7 +140,39 @@ def main_resample():
     print("wrote resample.npz with", len(out), "arrays")
 
 
+def main_eval_extra():
+    """The post-processing helpers of evaluation_tools.py that are off the hot path (:10-90, :115-155, :222-254): temporal / 1-D /
+    2-D spectral analyses, the vorticity structure / correlation functions and the 3-D spectrum, run as the reference runs them."""
+    import matplotlib
+    matplotlib.use("Agg")
+    EV = _load_ref_module("evaluation_tools.py", "evaluation_tools")
+    rng = np.random.default_rng(77)
+    out = {}
+    series = rng.standard_normal((24, 10, 12, 2))            # [t, y, x, (v, u)]
+    f, vy, ux, ek = EV.spectral_analysis_time(series, 4, 2, 8, 3, 11, 1.0, 0.25)
+    out["time/velocity"], out["time/args"] = series, np.array([4, 2, 8, 3, 11, 1.0, 0.25])
+    out["time/freq"], out["time/uy_dft"], out["time/ux_dft"], out["time/Ek"] = np.asarray(f), np.asarray(vy), np.asarray(ux), np.asarray(ek)
+    km, ekm = EV.spectral_analysis_1Dspace(series, 2, 20, (5, 9), 4, (1, 11), 0.3, 1.0)
+    out["space1d/km"], out["space1d/Ekm"] = np.asarray(km), np.asarray(ekm)
+    kp, ekp, num, kx, ky = EV.spectral_analysis_2Dspace(series, 2, 20, 7, ((1, 9), (2, 12)), 0.3, 1.0)
+    out["space2d/kp"], out["space2d/Ekp"], out["space2d/num"], out["space2d/kx"], out["space2d/ky"] = (np.asarray(kp), np.asarray(ekp), np.asarray(num),
+                                                                                                        np.asarray(kx), np.asarray(ky))
+    res, size = (16, 16), (8.0, 8.0)       # (the reference's radial bins overflow on most non-square grids: a square one, as its scripts use)
+    domain = pf.Domain(list(res), boundaries=pf.PERIODIC, box=pf.box[0:size[0], 0:size[1]])
+    vel_t = rng.standard_normal((1, res[0] + 1, res[1] + 1, 2)).astype(np.float32)
+    vel = pf.StaggeredGrid.sample(vel_t, domain=domain)
+    out["vort/resolution"], out["vort/box"], out["vort/vel_in"] = np.array(res), np.array(size), vel_t
+    out["vort/structure"] = np.asarray(EV.vorticity_structure(vel))
+    out["vort/correlation"] = np.asarray(EV.vorticity_correlation(vel))
+    v3 = rng.standard_normal((1, 8, 8, 8, 3))
+    k3, e3 = EV.EK_spectrum_3D(v3, None)
+    out["spec3d/velocity_centered"], out["spec3d/wavenumbers"], out["spec3d/energy"] = v3, np.asarray(k3, np.float64), np.asarray(e3, np.float64)
+    np.savez_compressed(os.path.join(HERE, "eval_extra.npz"), **out)
+    print("wrote eval_extra.npz with", len(out), "arrays")
+
+
 if __name__ == "__main__":
     main()
     main_setups()
     main_resample()
+    main_eval_extra()

@@ -194,3 +194,34 @@ def test_resampling_of_data_frames_against_reference_golden(golden_dir, tag, dev
     visc[:, :, 3:, :] += np.linspace(0, 0.1, int(lr[1]) - 3, dtype=np.float32)[None, None, :, None]
     flat = dp.flatten_staggered_data(dp.CenteredGrid(torch.tensor(visc, device=device), box).at(lr_vel), coord_flip=True)
     np.testing.assert_allclose(flat.detach().cpu().numpy(), dp.sponge_viscosity_field(lr, 2e-3, 3, 0.1), rtol=1e-6, atol=1e-9)
+
+
+def test_analysis_helpers_match_reference_golden():
+    """The post-processing helpers of evaluation_tools.py (:10-90, :115-155, :222-254) against vectors the reference's own functions
+    produced on PhiFlow's numpy backend (tests/golden/make_golden_eval.py::main_eval_extra)."""
+    import diffpiso as dp
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval_extra.npz"))
+    series = d["time/velocity"]
+    a = d["time/args"]
+    f, uy, ux, ek = dp.spectral_analysis_time(series, int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), float(a[5]), float(a[6]))
+    np.testing.assert_allclose(f, d["time/freq"], rtol=1e-12)
+    np.testing.assert_allclose(uy, d["time/uy_dft"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(ux, d["time/ux_dft"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(ek, d["time/Ek"], rtol=1e-10)
+    km, ekm = dp.spectral_analysis_1Dspace(series, 2, 20, (5, 9), 4, (1, 11), 0.3, 1.0)
+    np.testing.assert_allclose(km, d["space1d/km"], rtol=1e-12)
+    np.testing.assert_allclose(ekm, d["space1d/Ekm"], rtol=1e-10, atol=1e-14)
+    kp, ekp, num, kx, ky = dp.spectral_analysis_2Dspace(series, 2, 20, 7, ((1, 9), (2, 12)), 0.3, 1.0)
+    np.testing.assert_allclose(kp, d["space2d/kp"], rtol=1e-12)
+    np.testing.assert_allclose(ekp, d["space2d/Ekp"], rtol=1e-10, atol=1e-16)
+    np.testing.assert_array_equal(num, d["space2d/num"])
+    np.testing.assert_allclose(kx, d["space2d/kx"], rtol=1e-12)
+    np.testing.assert_allclose(ky, d["space2d/ky"], rtol=1e-12)
+    res, size = [int(v) for v in d["vort/resolution"]], [float(v) for v in d["vort/box"]]
+    domain = dp.Domain(res, boundaries=dp.PERIODIC, box=dp.box[0:size[0], 0:size[1]])
+    vel = dp.StaggeredGrid.sample(torch.tensor(d["vort/vel_in"]), domain=domain)
+    np.testing.assert_allclose(dp.vorticity_structure(vel), d["vort/structure"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dp.vorticity_correlation(vel), d["vort/correlation"], rtol=1e-5, atol=1e-6)
+    k3, e3 = dp.EK_spectrum_3D(d["spec3d/velocity_centered"], None)
+    np.testing.assert_allclose(k3, d["spec3d/wavenumbers"], rtol=1e-12)
+    np.testing.assert_allclose(e3, d["spec3d/energy"], rtol=1e-10)
