@@ -92,3 +92,45 @@ def test_slab_rows_rejects_uneven_split():
     from diffpiso.distributed import slab_rows
     with pytest.raises(ValueError):
         slab_rows(0, 3, 64)
+
+
+def test_step_sharding_halo_messages_are_consistent():
+    """Host logic of the sharded step (diffpiso/sharding.py): for every pair of ring neighbours the segments a rank SENDS are the
+    segments its neighbour expects to RECEIVE (same offsets in the globally indexed vector, same lengths), the duplicate face row
+    v[ny] crosses the periodic seam with the last slab's rows, and the row window is what the kernels are told."""
+    import ctypes as C
+    import diffpiso._native as N
+    from diffpiso.sharding import HALO, StepSharding
+
+    class FakeComm(object):
+        def __init__(self, rank, world):
+            self.rank, self.world, self.handle, self.sharded = rank, world, None, False
+
+    def msgs(arr):
+        out = []
+        for q in range(4):
+            cnt = arr[7 * q]
+            out.append([(arr[7 * q + 1 + k], arr[7 * q + 4 + k]) for k in range(cnt)])
+        return out        # to_upper, to_lower, from_lower, from_upper
+
+    nx, ny = 12, 48
+    n_u = (nx + 1) * ny
+    try:
+        for world in (2, 4, 8):
+            sh = [StepSharding(FakeComm(r, world), nx, ny) for r in range(world)]
+            for r in range(world):
+                j0, j1, last = C.c_int(), C.c_int(), C.c_int()
+                StepSharding(FakeComm(r, world), nx, ny)
+                assert N.lib.piso_get_row_window(C.byref(j0), C.byref(j1), C.byref(last)) == 1
+                assert (j0.value, j1.value, last.value) == (r * ny // world, (r + 1) * ny // world, int(r == world - 1))
+                up, lo = (r + 1) % world, (r - 1) % world
+                for kind in ("msgs_faces", "msgs_faces_vfirst", "msgs_cells"):
+                    mine, theirs_up, theirs_lo = msgs(getattr(sh[r], kind)), msgs(getattr(sh[up], kind)), msgs(getattr(sh[lo], kind))
+                    assert mine[0] == theirs_up[2], (world, r, kind)         # what I send up is what my upper neighbour receives from below
+                    assert mine[1] == theirs_lo[3], (world, r, kind)         # what I send down is what my lower neighbour receives from above
+            # the last slab sends its HALO last v rows AND the duplicate row v[ny] upwards (across the seam to rank 0)
+            top = msgs(sh[world - 1].msgs_faces)[0]
+            assert top[1] == (n_u + (ny - HALO) * nx, (HALO + 1) * nx)
+            assert msgs(sh[0].msgs_faces)[2][1] == top[1]
+    finally:
+        N.lib.piso_set_row_window(-1, -1, 0)
