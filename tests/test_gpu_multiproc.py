@@ -80,6 +80,12 @@ def test_bench_two_ranks_on_one_gpu():
     assert p.returncode == 0 and lines, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    # the headline of an N > 1 run is the SHARDED step (one 1024 x 2048 box here, a 1024^2 slab per rank), measured in a child process per
+    # rank; the replicas figure stands beside it
+    assert d.get("sharded_run") is None, d.get("sharded_run")
+    assert d["sharded"]["ranks_seen"] == 2 and d["sharded"]["halo_exchanges"] > 0 and d["sharded"]["verification_failures"] == 0
+    assert d["config"]["grid"] == [2048, 1024] and d["replicas"]["value"] > 0 and d["parallel_efficiency_vs_replicas"] > 0
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     chk = d["slab_cg_self_check"]
     print(chk)
     assert chk["ok"] and chk["ok_all_ranks"], chk
