@@ -1,6 +1,6 @@
 // Pressure CG of a TINY grid (at most kTinyMaxCells = 4 608 cells: the lid-driven cavity of BASELINE.json's config 1, 64 x 65) inside ONE
-// workgroup: no grid-wide exchange, no launch per iteration - the two reductions of a CG iteration are block reductions between
-// two __syncthreads, and the residual resets of the reference's default residual_reset = 10 happen in the same launch.
+// workgroup: no grid-wide exchange, no launch per iteration - the ONE reduction of a CG iteration (merged as in cg_persist1.h) is
+// a block reduction, and the residual resets of the reference's default residual_reset = 10 happen in the same launch.
 //
 // Why: on such a grid an iteration of the chip-wide paths is nothing but latency - two dependent launches (~13 us) or one grid
 // exchange (~3.6 us even with all workgroups on one XCD) for 4 160 cells of arithmetic; here it is ~1 us.
@@ -18,8 +18,8 @@
 
 namespace piso {
 
-constexpr int kTinyThreads = 768;             // 12 waves = 3 per SIMD: 168 VGPRs per lane hold coefficients, r, x, p, z of 6 cells
-constexpr int kTinyCellsPerThread = 6;
+constexpr int kTinyThreads = 512;             // 8 waves = 2 per SIMD: 256 VGPRs per lane hold the coefficients, p and z' of 9 cells
+constexpr int kTinyCellsPerThread = 9;
 constexpr int kTinyMaxCells = 4608;                                    // four fp64 vectors of the grid fit the LDS (4 x 36 KB)
 
 // sum of NV values over the workgroup, the same bits in every thread (fixed order: lanes by butterfly, then the 16 waves in order)
@@ -34,14 +34,13 @@ __device__ __forceinline__ void tiny_block_sum(T (&v)[NV], T* smem /* [NV * 16] 
     for (int q = 0; q < NV; ++q) smem[q * 16 + wave] = v[q];
   }
   __syncthreads();
-  // a fixed TREE over the waves' sums (the loop runs on the latency of dependent fp64 additions: depth 4 instead of 12)
+  // a fixed TREE over the waves' sums (the loop runs on the latency of dependent fp64 additions: depth 3 instead of 8)
   constexpr int NW = kTinyThreads / 64;
-  static_assert(NW == 12, "the tree below adds twelve wave sums");
+  static_assert(NW == 8, "the tree below adds eight wave sums");
 #pragma unroll
   for (int q = 0; q < NV; ++q) {
     const T* w = smem + q * 16;
-    const T a0 = w[0] + w[1], a1 = w[2] + w[3], a2 = w[4] + w[5], a3 = w[6] + w[7], a4 = w[8] + w[9], a5 = w[10] + w[11];
-    v[q] = ((a0 + a1) + (a2 + a3)) + (a4 + a5);
+    v[q] = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
   }
 }
 
@@ -55,7 +54,7 @@ __global__ __launch_bounds__(kTinyThreads) void cg_tiny(const T* __restrict__ L,
   __shared__ T rbuf[kTinyMaxCells], xbuf[kTinyMaxCells];    // r and x of a thread's own cells (168 VGPRs per lane hold the coefficients,
                                                             // p and z' of six cells; r and x on top of them spill)
   __shared__ T bbuf[kTinyMaxCells];                         // the right-hand side (read again at every residual reset)
-  __shared__ T smem[3 * 16];                                 // (block sums: up to 16 waves)
+  __shared__ T smem[8 * 16];                                 // (block sums: up to 16 waves)
   const int n = nx * ny;
   const int t = threadIdx.x;
   T cS[C], cW[C], cC[C], cE[C], cN[C], pm[C];
@@ -99,60 +98,90 @@ __global__ __launch_bounds__(kTinyThreads) void cg_tiny(const T* __restrict__ L,
     return z;
   };
   CgState st = {0, 0, 0, 0};
-  T pz = 1, vs = 0;                                         // (cg_init: SC_PZ = 1, SC_VS = 0)
-  T tB[3] = {0, 0, 0};                                      // r.z', sum r, #cells with !(|r| < accuracy) of the previous iteration
+  // ONE block reduction per iteration, as in cg_persist1.h: D(k) sums  sum p, p.r, p.z', r.z', z'.z', sum z'  and, left over from
+  // U(k-1),  sum r_k, #{|r_k| >= accuracy};  alpha_k, then  r_{k+1}.z'_k = r.z' - alpha (z'.z' + vs sum z')  and
+  // sum r_{k+1} = sum r_k - alpha (sum z' + N vs)  give beta_{k+1} without a second reduction (one-step recurrences from directly
+  // summed quantities).  The stopping test of iteration k is evaluated behind that reduction, before x and r move on: a converged
+  // solve stops in exactly the reference's state (x_k, iterations = k).
+  T pz = 1, vs = 0, rz_next = 0, sumr = 0;                  // (cg_init: SC_PZ = 1, SC_VS = 0)
+  T lr = 0, lc = 0;                                         // this thread's part of sum r_k and of #{|r_k| >= accuracy}
+#pragma unroll
+  for (int m = 0; m < C; ++m) if (own[m]) { const T rv = rbuf[t + m * kTinyThreads]; lr += rv; lc += (absval(rv) < accuracy) ? (T)0 : (T)1; }
+  const T ncells = (T)n;
   for (int k = 0; k < total && !st.done; ++k) {
     const bool is_reset = reset > 0 && ((k + 1) % reset == 0);
-    // ---- top of iteration k: the stopping test of iteration k - 1 and beta (cg_k1 with do_check)
     T beta = 0;
-    if (k > 0) {
-      if ((k % 5) == 0) {
-        const int exceeded = tB[2] > 0;
-        if (st.flag && !exceeded) { st.done = 1; st.iterations = k; }
-        else st.flag = 1;
-      }
-      if (st.done) break;
-      if (!is_reset) beta = -(tB[0] + vs * tB[1]) / pz;     // unguarded, as coded (:351-352)
-    }
+    if (k > 0 && !is_reset) beta = -(rz_next + vs * sumr) / pz;     // unguarded, as coded (:351-352)
+    bool tested = false;
     T z[C];
     if (is_reset) {
-      st.flag = 0;                                          // initVariablesWithGuess clears the device flag
-      // r = b - (L x + c sum x), then the common path with beta = 0: p = r                (:260-274)
-      T sx[1] = {0};
+      // the test of iteration k belongs in front of the restart (cg_k1 MODE_RESET with do_check): #{|r_k| >= accuracy} travels with sum x
+      T sx[2] = {0, lc};
 #pragma unroll
       for (int m = 0; m < C; ++m) { pm[m] = 0; if (own[m]) { const T xv = xbuf[t + m * kTinyThreads]; pm[m] = xv; pbuf[t + m * kTinyThreads] = xv; sx[0] += xv; } }
       __syncthreads();
 #pragma unroll
       for (int m = 0; m < C; ++m) z[m] = stencil(m);
-      tiny_block_sum<T, 1>(sx, smem);                       // (its barriers also end the stencil's reads of x)
+      tiny_block_sum<T, 2>(sx, smem);                       // (its barriers also end the stencil's reads of x)
+      if (k > 0 && (k % 5) == 0) {
+        const int exceeded = sx[1] > 0;
+        if (st.flag && !exceeded) { st.done = 1; st.iterations = k; }
+        else st.flag = 1;
+      }
+      if (st.done) break;
+      tested = true;
+      st.flag = 0;                                          // initVariablesWithGuess clears the device flag
+      // r = b - (L x + c sum x), then the common path with beta = 0: p = r                (:260-274)
       const T vsx = sc_c * sx[0];
+      lr = 0; lc = 0;
 #pragma unroll
       for (int m = 0; m < C; ++m) {
-        if (own[m]) { const int i = t + m * kTinyThreads; rbuf[i] = bbuf[i] - (z[m] + vsx); }
+        if (own[m]) {
+          const int i = t + m * kTinyThreads;
+          const T rn = bbuf[i] - (z[m] + vsx);
+          rbuf[i] = rn; lr += rn; lc += (absval(rn) < accuracy) ? (T)0 : (T)1;
+        }
         pm[m] = 0;                                          // (p = r + 0 p below)
       }
     }
-    // (no barrier here: the two block sums of the previous iteration separate its stencil reads from these writes)
+    // (no barrier here: the block sum of the previous iteration separates its stencil reads from these writes)
 #pragma unroll
     for (int m = 0; m < C; ++m) {
       if (own[m]) { const int i = t + m * kTinyThreads; pm[m] = fma(beta, pm[m], rbuf[i]); pbuf[i] = pm[m]; }   // p = r + beta p (k = 0, resets: p = r)
     }
     __syncthreads();
-    // ---- K1: z' = L p; sum p, p.r, p.z'
-    T sA[3] = {0, 0, 0};
+    // ---- D(k): z' = L p and the sums
+    T sD[8] = {0, 0, 0, 0, 0, 0, lr, lc};
 #pragma unroll
     for (int m = 0; m < C; ++m) {
       z[m] = stencil(m);
-      sA[0] += pm[m];
-      if (own[m]) sA[1] = fma(pm[m], rbuf[t + m * kTinyThreads], sA[1]);
-      sA[2] = fma(pm[m], z[m], sA[2]);
+      if (own[m]) {
+        const T rv = rbuf[t + m * kTinyThreads];
+        sD[0] += pm[m];
+        sD[1] = fma(pm[m], rv, sD[1]);
+        sD[2] = fma(pm[m], z[m], sD[2]);
+        sD[3] = fma(rv, z[m], sD[3]);
+        sD[4] = fma(z[m], z[m], sD[4]);
+        sD[5] += z[m];
+      }
     }
-    tiny_block_sum<T, 3>(sA, smem);
-    // ---- K2: alpha; x += alpha p; r -= alpha (z' + c sum p); r.z', sum r, #{|r| >= accuracy}
-    vs = sc_c * sA[0];
-    pz = sA[2] + vs * sA[0];
-    const T alpha = (absval(pz) > 0) ? sA[1] / pz : (T)0;   // (:301-302)
-    tB[0] = tB[1] = tB[2] = 0;
+    tiny_block_sum<T, 8>(sD, smem);
+    // ---- the stopping test of iteration k (:312-335), behind the reduction but before anything moves
+    if (!tested && k > 0 && (k % 5) == 0) {
+      const int exceeded = sD[7] > 0;
+      if (st.flag && !exceeded) { st.done = 1; st.iterations = k; }
+      else st.flag = 1;
+    }
+    if (st.done) break;
+    // ---- alpha (:301-302) and what beta of the next iteration needs
+    sumr = sD[6];
+    vs = sc_c * sD[0];
+    pz = sD[2] + vs * sD[0];
+    const T alpha = (absval(pz) > 0) ? sD[1] / pz : (T)0;
+    rz_next = sD[3] - alpha * (sD[4] + vs * sD[5]);
+    sumr = sumr - alpha * (sD[5] + ncells * vs);
+    // ---- U(k): x += alpha p; r -= alpha (z' + c sum p)
+    lr = 0; lc = 0;
 #pragma unroll
     for (int m = 0; m < C; ++m) {
       if (own[m]) {
@@ -160,12 +189,10 @@ __global__ __launch_bounds__(kTinyThreads) void cg_tiny(const T* __restrict__ L,
         xbuf[i] = fma(alpha, pm[m], xbuf[i]);
         const T rn = fma(-alpha, z[m] + vs, rbuf[i]);
         rbuf[i] = rn;
-        tB[0] = fma(rn, z[m], tB[0]);
-        tB[1] += rn;
-        tB[2] += (absval(rn) < accuracy) ? (T)0 : (T)1;    // NaN counts as exceeding
+        lr += rn;
+        lc += (absval(rn) < accuracy) ? (T)0 : (T)1;       // NaN counts as exceeding
       }
     }
-    tiny_block_sum<T, 3>(tB, smem);
   }
 #pragma unroll
   for (int m = 0; m < C; ++m) if (own[m]) x_out[t + m * kTinyThreads] = xbuf[t + m * kTinyThreads];
