@@ -22,3 +22,9 @@ python3 $R/scripts/summarize_pmc.py /tmp/prof_fetch /tmp/prof_write /tmp/calib_f
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bicg -o bicg -- python3 $R/scripts/bench_bicg.py 2048 > $OUT/${TAG}_bicg_run.log 2>&1
 for f in $(find /tmp/prof_bicg -name "*kernel_stats.csv"); do cp $f $OUT/${TAG}_bicgstab2048_kernel_stats.csv; done
 python3 $R/scripts/make_traffic_json.py $OUT/${TAG}_bench2048_pmc_fetch_write_summary.txt $TAG > $OUT/traffic.json 2> $OUT/${TAG}_traffic.log
+# 6. the bench line of the SAME sources with the traffic record just taken (bench.py reads profiles/traffic.json and uses it only if the
+#    sha of the kernel sources matches): fail loudly if it does not
+cp $OUT/traffic.json $R/profiles/traffic.json
+python3 $R/scripts/check_traffic_sha.py || { echo "traffic.json does not match the kernel sources" >&2; exit 1; }
+python3 $R/bench.py > $OUT/${TAG}_bench2048.json 2> $OUT/${TAG}_bench_run.log
+python3 $R/scripts/check_traffic_sha.py $OUT/${TAG}_bench2048.json $TAG

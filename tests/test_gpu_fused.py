@@ -139,7 +139,7 @@ def test_fused_step_matches_the_torch_transcription(name):
     errs = {n: rel(x, y) for n, x, y in zip(names, a[:6], b[:6]) if float(y.abs().max()) > 0}
     print("fused vs torch glue:", name, {k: "%.1e" % v for k, v in errs.items()})
     # (cavity: the rank-deficient CG stops at slightly different iterations for 1-ulp different inputs, tests/test_gpu_configs.py)
-    assert errs["u"] < (2e-5 if name == "cavity" else 2e-6) and errs["p"] < 2e-5
+    assert errs["u"] < (1e-4 if name == "cavity" else 2e-6) and errs["p"] < 2e-5      # (cavity: solver-tolerance level, see below)
     # cavity: the two runs' ADJOINT pressure solves see right-hand sides that differ by 1 ulp, and on the shifted, inconsistent
     # system (absolute tolerance 1e-6) they then stop at different iterations: the gradients agree at the solver-tolerance level
     # only (measured 6e-3 with the single-workgroup CG this 24 x 40 grid runs on, 1e-5 by luck of an identical stopping iteration
