@@ -104,6 +104,9 @@ struct SlabCtl {
 #ifndef PISO_PERSIST1_PREFETCH_BEHIND_DRAIN
 #define PISO_PERSIST1_PREFETCH_BEHIND_DRAIN 0    // (measured: no gain - the first barrier of the exchange waits for the slowest wave, not for the drain)
 #endif
+#ifndef PISO_PERSIST1_POLL_DELAY
+#define PISO_PERSIST1_POLL_DELAY 24             // s_sleep units (64 cycles) between publishing a record and the first polling pass
+#endif
 #ifndef PISO_PERSIST1_POLL_SLEEP
 #define PISO_PERSIST1_POLL_SLEEP 1              // s_sleep units (64 cycles) between two polling passes
 #endif
@@ -216,6 +219,9 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
       okl[i] = ((wave * 8 + i) * 4 + sub) >= nslots;           // records beyond the grid count as arrived (payload 0)
     }
     unsigned spins = 0;
+    // a first poll that finds every record beats two passes: the records of 256 workgroups that finish their row loops together
+    // need ~0.6 us to become visible; measured at 2048^2: no delay 11.7, s_sleep 16 .. 32 11.4, 48 11.7, 64 11.9 us per iteration
+    if constexpr (!LOCAL) { if (PISO_PERSIST1_POLL_DELAY > 0) __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_DELAY); }
     while (true) {
       bool ok = true;
 #pragma unroll
