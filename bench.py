@@ -522,7 +522,23 @@ def main():
         from diffpiso.distributed import SlabCommunicator
         from diffpiso.sharding import StepSharding
         # mailbox rows: the longest halo message is two face rows of u and three of v, five matrix values each
-        P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=26 * n + 64)
+        comm_err = None
+        try:
+            P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=26 * n + 64)
+        except Exception as e:
+            comm_err = repr(e)
+        if args.sharded_child:
+            # the 'auto' mode's child: a transport this environment refuses (hipIpc handles, peer access) is REPORTED by the parent, not
+            # fatal - every rank learns of it here, prints the reason and leaves with code 0; anything that fails later is an error
+            okt = torch.tensor([0.0 if comm_err else 1.0], device="cpu" if share_gpu else device)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if okt.item() <= 0:
+                if rank == 0:
+                    print(json.dumps({"sharded_unavailable": comm_err or "another rank could not set up the peer transport"}), flush=True)
+                dist.destroy_process_group()
+                sys.exit(0)
+        elif comm_err:
+            raise RuntimeError("the peer transport could not be set up: " + comm_err)
         P["lin"].slab_comm = P["ps"].slab_comm       # the ILU(0)-BiCGStab is cut into the same slabs (dot products all-reduced)
         P["sharding"] = P["sim"].sharding = StepSharding(P["ps"].slab_comm, n, ny_grid)   # ... and so is everything else of the step
 
@@ -739,7 +755,10 @@ def main():
         if rank == 0:
             replicas = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak",
                         "note": "one independent %d^2 problem per GPU, no data-path collective (the run timed first)" % n}
-            if all_ok and child is not None:
+            if all_ok and child is not None and "sharded_unavailable" in child:
+                out["sharded_run"] = {"skipped": "peer transport could not be set up here: " + str(child["sharded_unavailable"])}
+                out["replicas_only"] = True
+            elif all_ok and child is not None:
                 for k in ("value", "ms_per_step", "scaling", "config", "roofline", "phases", "sharded"):
                     if k in child:
                         out[k] = child[k]

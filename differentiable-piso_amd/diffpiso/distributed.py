@@ -83,17 +83,34 @@ class SlabCommunicator(object):
         self.sharded = False                # set by sharding.StepSharding: solver results stay on the rank's rows (no all-gather)
         device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.device = device
+        self.handle = None
         handle = C.c_void_p()
         if transport == "peer":
+            # Setting the transport up is a collective: a rank where a step fails (hipIpc handles or peer access refused by the
+            # environment) still takes part in the exchanges below, and EVERY rank raises - nobody is left waiting for a peer that gave up.
             mine = (C.c_ubyte * 64)()
+            failure = None
             with torch.cuda.device(device):
-                N.check(N.lib.piso_comm_peer_create(rank, world, int(row_capacity), C.byref(handle), mine), "piso_comm_peer_create")
-                self.handle = handle
-                everybody = all_gather_bytes(bytes(mine), rank, world, device)
-                raw = (C.c_ubyte * (64 * world)).from_buffer_copy(everybody)
-                N.check(N.lib.piso_comm_peer_connect(handle, raw), "piso_comm_peer_connect")
-            if world > 1:
-                dist.barrier()                      # nobody writes into a mailbox that is not mapped everywhere yet
+                status = N.lib.piso_comm_peer_create(rank, world, int(row_capacity), C.byref(handle), mine)
+                if status != 0:
+                    failure = "piso_comm_peer_create failed with status %d: %s" % (status, N.lib.piso_last_error_string().decode())
+                else:
+                    self.handle = handle
+                everybody = all_gather_bytes(bytes(mine) + bytes([1 if failure else 0]), rank, world, device)
+                failed = [r for r in range(world) if everybody[65 * r + 64]]
+                if not failed:
+                    raw = (C.c_ubyte * (64 * world)).from_buffer_copy(b"".join(everybody[65 * r:65 * r + 64] for r in range(world)))
+                    status = N.lib.piso_comm_peer_connect(handle, raw)
+                    if status != 0:
+                        failure = "piso_comm_peer_connect failed with status %d: %s" % (status, N.lib.piso_last_error_string().decode())
+                    # (also the barrier: nobody writes into a mailbox that is not mapped everywhere yet)
+                    if max_over_ranks(1.0 if failure else 0.0, device) > 0:
+                        failed = [-1]
+            if failed:
+                if self.handle:                     # (no barrier here: the ranks whose mailbox never existed would not join it)
+                    N.lib.piso_comm_destroy(self.handle)
+                    self.handle = None
+                raise N.PisoNativeError(failure or "the peer transport could not be set up on rank(s) %s" % (failed,))
         elif transport == "rccl":
             uid = exchange_unique_id(rank, world, device)
             raw = (C.c_ubyte * 128)(*[int(v) for v in uid.tolist()])
