@@ -493,8 +493,16 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
       if (!ev[0]) { PISO_HIP_CHECK(hipEventCreate(&ev[0])); PISO_HIP_CHECK(hipEventCreate(&ev[1])); }
       PISO_HIP_CHECK(hipEventRecord(ev[0], stream));
     }
-    cg_tiny<T><<<1, kTinyThreads, 0, stream>>>(L, b, x_out, nx, ny, per_x, per_y, fixed ? -1.0f : accuracy, total, fixed ? 0 : reset,
-                                               rank_deficient, st_dev);
+    const bool cols = nx <= 64 && ny <= kColsMaxNy && (!per_x || nx == 64) && opt(OPT_CG_TINY) != 2;    // (cg_tiny = 2: the general kernel, tests)
+    if (cols && per_x)
+      cg_tiny_cols<T, true><<<1, kTinyThreads, 0, stream>>>(L, b, x_out, nx, ny, per_y, fixed ? -1.0f : accuracy, total, fixed ? 0 : reset,
+                                                            rank_deficient, st_dev);
+    else if (cols)
+      cg_tiny_cols<T, false><<<1, kTinyThreads, 0, stream>>>(L, b, x_out, nx, ny, per_y, fixed ? -1.0f : accuracy, total, fixed ? 0 : reset,
+                                                             rank_deficient, st_dev);
+    else
+      cg_tiny<T><<<1, kTinyThreads, 0, stream>>>(L, b, x_out, nx, ny, per_x, per_y, fixed ? -1.0f : accuracy, total, fixed ? 0 : reset,
+                                                 rank_deficient, st_dev);
     PISO_LAUNCH_CHECK();
     if (ev) PISO_HIP_CHECK(hipEventRecord(ev[1], stream));
     CgState hst;

@@ -15,6 +15,7 @@
 #pragma once
 #include "cg_kernels.h"
 #include "cg_persist.h"
+#include "cg_persist1.h"
 
 namespace piso {
 
@@ -198,5 +199,250 @@ __global__ __launch_bounds__(kTinyThreads) void cg_tiny(const T* __restrict__ L,
   for (int m = 0; m < C; ++m) if (own[m]) x_out[t + m * kTinyThreads] = xbuf[t + m * kTinyThreads];
   if (t == 0) *state_out = st;
 }
+
+// ---- the same solve with a COLUMN layout: lane = x (nx <= 64), wave w owns the rows [9 w, 9 w + 9) (ny <= 72: the lid-driven
+// cavity is 64 x 65).  p, r, x, b, z' and the five coefficients of a thread's nine vertically adjacent cells all live in
+// registers; the south / north neighbours of the direction are the thread's own registers (the rows next to another wave's rows
+// travel through LDS: two rows per wave and iteration), west / east come from the neighbouring lanes through the DPP wavefront
+// shifts.  LDS traffic per iteration: 2 row writes + 2 row reads per wave and one line of wave sums (cg_tiny: ~90 accesses per
+// thread).  The block reduction is the exchange of cg_persist1.h in small: reduce-scatter butterfly of the eight partial sums
+// inside a wave (lane l ends with value l & 7), one LDS line [8 values][8 waves], ONE barrier, one LDS read per lane and a
+// three-step tree over the waves - every wave computes the same bits.
+// PERX (periodic x) needs nx == 64: the wavefront ROTATES are the wrap-around.
+#ifndef PISO_TINY_COLS_FULL
+#define PISO_TINY_COLS_FULL 0                 // 1: waves whose nine rows and 64 lanes are all cells run an instance without masks (measured: it spills)
+#endif
+constexpr int kColsRows = 9;                  // rows per wave
+constexpr int kColsMaxNy = 8 * kColsRows;
+
+template <bool UP, bool WRAP, typename S>
+__device__ __forceinline__ S cols_shift(S v) {      // lane l <- lane l - 1 (UP) / l + 1; the lane without a source: 0, or the other end (WRAP)
+  constexpr int ctrl = WRAP ? (UP ? 0x13C /* wave_ror:1 */ : 0x134 /* wave_rol:1 */) : (UP ? 0x138 /* wave_shr:1 */ : 0x130 /* wave_shl:1 */);
+  if constexpr (sizeof(S) == 8) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, ctrl, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), ctrl, 0xf, 0xf, false);
+    return (S)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  } else {
+    return (S)__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int((float)v), ctrl, 0xf, 0xf, false));
+  }
+}
+
+// eight partial sums per thread -> the block totals, the same bits in every thread (v[] is overwritten)
+template <typename T>
+__device__ __forceinline__ void cols_block_sum8(T (&v)[8], double* red /* [64] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double d[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) d[q] = (double)v[q];
+  const double mine = wave_reduce_scatter8(d);              // lane l: this wave's total of value l & 7
+  if (lane < 8) red[lane * 8 + wave] = mine;
+  __syncthreads();
+  double t = red[lane];                                     // lane l: value l >> 3 of wave l & 7
+  t += dpp_move<0xB1>(t);                                   // (w0 + w1), (w2 + w3), ...
+  t += dpp_move<0x4E>(t);                                   // ((w0 + w1) + (w2 + w3)), ...
+  t += lanes_xor4(t);                                       // all eight waves: lanes 8 q .. 8 q + 7 hold the total of value q
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = (T)read_lane_c(t, 8 * q);
+}
+
+// FULL: all nine rows and all 64 lanes of this wave are cells (no masks); the waves of a workgroup may run different instances -
+// they execute the same sequence of barriers.
+template <typename T, bool PERX, bool FULL>
+__device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __restrict__ b, T* __restrict__ x_out, int nx, int ny, int per_y,
+                                           float accuracy_f, int total, int reset, int rank_deficient, CgState* state_out,
+                                           T (*halo)[kTinyThreads / 64][64], double* red, T* bbuf, T* xbuf) {
+  constexpr int C = kColsRows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = wave * C;
+  const int rows = FULL ? C : min(max(ny - j0, 0), C);      // (wave-uniform)
+  const bool col = FULL || lane < nx;
+  const int n = nx * ny;
+  const int wlast = (ny - 1) / C;                           // the wave that owns the top row of the grid
+  // where my south / north halo rows come from (-1: nowhere - a wall or an open boundary, the coefficient there multiplies 0)
+  const int srcS = rows == 0 ? -1 : (wave > 0 ? wave - 1 : (per_y ? wlast : -1));
+  const int srcN = rows == 0 ? -1 : (j0 + rows < ny ? wave + 1 : (per_y ? 0 : -1));
+  T cS[C], cW[C], cC[C], cE[C], cN[C], p[C], r[C], z[C];
+  T* xmine = xbuf + j0 * 64 + lane;                         // x of my cells: read and written once per iteration, off the dependent chain
+  T* bmine = bbuf + j0 * 64 + lane;                         // the right-hand side of my cells (read again at every residual reset)
+  T dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int m = 0; m < C; ++m) {
+    cS[m] = cW[m] = cC[m] = cE[m] = cN[m] = 0; p[m] = r[m] = z[m] = 0;
+    xmine[m * 64] = 0;
+    if (m < rows && col) {
+      const int i = (j0 + m) * nx + lane;
+      const T* row = L + (size_t)i * 5;
+      cS[m] = row[0]; cW[m] = row[1]; cC[m] = row[2]; cE[m] = row[3]; cN[m] = row[4];
+      r[m] = b[i]; bmine[m * 64] = r[m];
+      dsum[0] += absval(row[2]);
+    }
+  }
+  cols_block_sum8<T>(dsum, red);
+  const T sc_c = rank_deficient ? dsum[0] * (T)(.1 / (double)n) : (T)0;            // cg_init
+  const T accuracy = (T)accuracy_f;
+  // z' = L v for my cells, v in registers (phantom rows and lanes hold 0)
+  auto apply = [&](const T (&v)[C]) __attribute__((always_inline)) {
+    // my first and last rows to the waves below and above, theirs to me
+    if (rows > 0) {
+      halo[0][wave][lane] = v[0];
+#pragma unroll
+      for (int m = 0; m < C; ++m) if (m == rows - 1) halo[1][wave][lane] = v[m];
+    }
+    __syncthreads();
+    const T hS = srcS >= 0 ? halo[1][srcS][lane] : (T)0;
+    const T hN = srcN >= 0 ? halo[0][srcN][lane] : (T)0;
+#pragma unroll
+    for (int mm = 0; mm < C; ++mm) {
+      const int m = mm < C - 2 ? mm + 1 : (mm == C - 2 ? 0 : C - 1);     // the rows next to the halo rows last: their LDS reads are in flight
+      const T vS = m == 0 ? hS : v[m - 1];
+      T vN = m + 1 < C ? v[m + 1] : hN;
+      if (m + 1 == rows) vN = hN;                            // (wave-uniform: only the wave with the grid's top row has rows < C)
+      const T vW = cols_shift<true, PERX>(v[m]), vE = cols_shift<false, PERX>(v[m]);
+      T acc = 0;                                             // summation order of calcZ_v4 (:81-90): S, W, C, E, N
+      acc = fma(cS[m], vS, acc);
+      acc = fma(cW[m], vW, acc);
+      acc = fma(cC[m], v[m], acc);
+      acc = fma(cE[m], vE, acc);
+      acc = fma(cN[m], vN, acc);
+      z[m] = acc;
+      __builtin_amdgcn_sched_barrier(0);                     // (one row at a time: the shifted copies of ALL rows at once do not fit the registers)
+    }
+  };
+  CgState st = {0, 0, 0, 0};
+  T pz = 1, vs = 0, rz_next = 0, sumr = 0;                  // (cg_init: SC_PZ = 1, SC_VS = 0)
+  T lr = 0;
+  int lc = 0;                                               // this thread's part of sum r_k and of #{|r_k| >= accuracy}
+#pragma unroll
+  for (int m = 0; m < C; ++m) if (m < rows && col) { lr += r[m]; lc += (absval(r[m]) < accuracy) ? 0 : 1; }
+  const T ncells = (T)n;
+#ifdef PISO_TINY_DIAG
+  long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define TINY_TICK(q) { __builtin_amdgcn_sched_barrier(0); const long long tn = clock64(); tph[q] += tn - tlast; tlast = tn; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define TINY_TICK(q)
+#endif
+  T beta_next = 0;
+  int to_reset = reset > 0 ? reset - 1 : -1;                // iterations until the next restart (no integer division in the loop)
+  int to_test = 0;                                          // k % 5
+  for (int k = 0; k < total && !st.done; ++k) {
+    const bool is_reset = to_reset == 0;
+    to_reset = is_reset ? reset - 1 : to_reset - 1;
+    const bool test_now = k > 0 && to_test == 0;            // the stopping test of iteration k
+    const bool count_now = to_test == 4;                    // ... needs #{|r_k| >= accuracy}, counted by U(k - 1)
+    to_test = to_test == 4 ? 0 : to_test + 1;
+    const T beta = is_reset ? (T)0 : beta_next;
+    bool tested = false;
+    if (is_reset) {
+      // the test of iteration k belongs in front of the restart (cg_k1 MODE_RESET with do_check): #{|r_k| >= accuracy} travels with sum x
+      T sx[8] = {0, (T)lc, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < C; ++m) { p[m] = xmine[m * 64]; sx[0] += p[m]; }     // (p = r + 0 p follows)
+      apply(p);
+      cols_block_sum8<T>(sx, red);
+      if (test_now) {
+        const int exceeded = sx[1] > 0;
+        if (st.flag && !exceeded) { st.done = 1; st.iterations = k; }
+        else st.flag = 1;
+      }
+      if (st.done) break;
+      tested = true;
+      st.flag = 0;                                          // initVariablesWithGuess clears the device flag
+      // r = b - (L x + c sum x), then the common path with beta = 0: p = r                (:260-274)
+      const T vsx = sc_c * sx[0];
+      lr = 0; lc = 0;
+#pragma unroll
+      for (int m = 0; m < C; ++m) {
+        if (m < rows && col) {
+          r[m] = bmine[m * 64] - (z[m] + vsx);
+          lr += r[m]; lc += (absval(r[m]) < accuracy) ? 0 : 1;
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < C; ++m) p[m] = fma(beta, p[m], r[m]);       // p = r + beta p (k = 0, resets: beta = 0; phantoms stay 0)
+    // ---- D(k): z' = L p and the sums
+    TINY_TICK(0)                                            // loop top, p update
+    apply(p);
+    TINY_TICK(1)                                            // halo exchange + stencil
+    T sD[8] = {0, 0, 0, 0, 0, 0, lr, (T)lc};
+#pragma unroll
+    for (int m = 0; m < C; ++m) {
+      sD[0] += p[m];
+      sD[1] = fma(p[m], r[m], sD[1]);
+      sD[2] = fma(p[m], z[m], sD[2]);
+      sD[3] = fma(r[m], z[m], sD[3]);
+      sD[4] = fma(z[m], z[m], sD[4]);
+      sD[5] += z[m];
+    }
+    TINY_TICK(2)                                            // partial sums
+    cols_block_sum8<T>(sD, red);
+    TINY_TICK(3)                                            // block reduction
+    // ---- the stopping test of iteration k (:312-335), behind the reduction but before anything moves
+    if (!tested && test_now) {
+      const int exceeded = sD[7] > 0;
+      if (st.flag && !exceeded) { st.done = 1; st.iterations = k; }
+      else st.flag = 1;
+    }
+    if (st.done) break;
+    // ---- alpha (:301-302) and what beta of the next iteration needs
+    sumr = sD[6];
+    vs = sc_c * sD[0];
+    pz = sD[2] + vs * sD[0];
+    const T alpha = (absval(pz) > 0) ? sD[1] / pz : (T)0;
+    rz_next = sD[3] - alpha * (sD[4] + vs * sD[5]);
+    sumr = sumr - alpha * (sD[5] + ncells * vs);
+    beta_next = -(rz_next + vs * sumr) / pz;                // beta of iteration k + 1: unguarded, as coded (:351-352); same divisor as alpha
+    TINY_TICK(4)                                            // test, alpha, beta
+    // ---- U(k): x += alpha p; r -= alpha (z' + c sum p)
+    lr = 0; lc = 0;
+    if (count_now) {             // (the count is only read by the test of iteration k + 1)
+#pragma unroll
+      for (int m = 0; m < C; ++m) {
+        xmine[m * 64] = fma(alpha, p[m], xmine[m * 64]);
+        if (m < rows && col) {
+          r[m] = fma(-alpha, z[m] + vs, r[m]);
+          lr += r[m];
+          lc += (absval(r[m]) < accuracy) ? 0 : 1;          // NaN counts as exceeding
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < C; ++m) {
+        xmine[m * 64] = fma(alpha, p[m], xmine[m * 64]);
+        if (m < rows && col) {
+          r[m] = fma(-alpha, z[m] + vs, r[m]);
+          lr += r[m];
+        }
+      }
+    }
+    TINY_TICK(5)                                            // U
+  }
+#ifdef PISO_TINY_DIAG
+  if (lane == 0 && (wave == 0 || wave == 7))
+    printf("cg_tiny_cols wave %d: clocks per phase: top %lld, halo + stencil %lld, sums %lld, reduction %lld, scalars %lld, U %lld\n", wave, tph[0], tph[1],
+           tph[2], tph[3], tph[4], tph[5]);
+#endif
+#pragma unroll
+  for (int m = 0; m < C; ++m) if (m < rows && col) x_out[(j0 + m) * nx + lane] = xmine[m * 64];
+  if (threadIdx.x == 0) *state_out = st;
+}
+
+template <typename T, bool PERX>
+__global__ __launch_bounds__(kTinyThreads) void cg_tiny_cols(const T* __restrict__ L, const T* __restrict__ b, T* __restrict__ x_out, int nx, int ny,
+                                                              int per_y, float accuracy_f, int total, int reset, int rank_deficient,
+                                                              CgState* state_out) {
+  // One buffer each: a halo exchange and a block sum always alternate, and each has a barrier between its writes and its reads -
+  // whoever writes a buffer again has passed the other one's barrier, which every wave reaches only after its reads of this one.
+  __shared__ T halo[2][kTinyThreads / 64][64];              // [0]: a wave's first row, [1]: its last row
+  __shared__ double red[64];
+  __shared__ T bbuf[kColsMaxNy * 64], xbuf[kColsMaxNy * 64];
+  const int wave = threadIdx.x >> 6;
+  if (PISO_TINY_COLS_FULL && nx == 64 && (wave + 1) * kColsRows <= ny)
+    cols_solve<T, PERX, true>(L, b, x_out, nx, ny, per_y, accuracy_f, total, reset, rank_deficient, state_out, halo, red, bbuf, xbuf);
+  else
+    cols_solve<T, PERX, false>(L, b, x_out, nx, ny, per_y, accuracy_f, total, reset, rank_deficient, state_out, halo, red, bbuf, xbuf);
+}
+
 
 }  // namespace piso

@@ -158,7 +158,7 @@ def ptr(t):
         raise PisoNativeError("libpiso_hip needs device tensors; got a %s tensor (no CPU fallback exists)" % t.device)
     if not t.is_contiguous():
         raise PisoNativeError("non-contiguous tensor passed to libpiso_hip")
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != torch._C._cuda_getDevice():
         # the kernels are launched on the CURRENT device's stream: a tensor of another GPU would be a wild pointer there
         raise PisoNativeError("tensor lives on %s but the current HIP device is cuda:%d (wrap the call in "
                               "`with torch.cuda.device(t.device)`)" % (t.device, torch.cuda.current_device()))
@@ -166,7 +166,8 @@ def ptr(t):
 
 
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (torch.cuda.current_stream() builds a Stream object and walks os.environ on the way: ~35 us per call, 15 calls per step)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 _workspaces = {}

@@ -407,12 +407,19 @@ def test_cg_padded_grid_mode(shape, rank_deficient, reset, piso_option):
 
 
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("shape,reset", [((65, 64), 10), ((16, 12), 1000), ((48, 96), 25), ((36, 128), 7)])
-def test_cg_tiny_single_workgroup_matches_oracle(name, shape, reset):
+@pytest.mark.parametrize("shape,reset,general", [((65, 64), 10, False), ((65, 64), 10, True), ((16, 12), 1000, False), ((48, 96), 25, False),
+                                                 ((36, 128), 7, False), ((72, 64), 10, False), ((40, 48), 7, False), ((9, 64), 5, False),
+                                                 ((10, 64), 3, False)])
+def test_cg_tiny_single_workgroup_matches_oracle(name, shape, reset, general, request):
     """Grids of at most 4 608 cells (the lid-driven cavity's 64 x 65) are solved inside ONE workgroup in one launch (csrc/cg_tiny.h),
-    residual resets included: fixed-iteration trajectories against the oracle to round-off, the stopping cadence, the rank-1 shift."""
+    residual resets included: fixed-iteration trajectories against the oracle to round-off, the stopping cadence, the rank-1 shift.
+    Shapes with nx <= 64, ny <= 72 take the column-layout kernel (cg_tiny_cols; periodic x only at nx = 64), the others - and
+    `general` (option cg_tiny = 2) - the general one."""
     from diffpiso.solvers import cg_solve_native
     from diffpiso import _native as N
+    if general:
+        N.set_option("cg_tiny", 2)
+        request.addfinalizer(lambda: N.set_option("cg_tiny", -1))
     s, L, b = _laplace_case(name, shape[0], shape[1], seed=7)
     px, py = s.periodic_yx[1], s.periodic_yx[0]
     before = int(N.lib.piso_cg_tiny_solves())
