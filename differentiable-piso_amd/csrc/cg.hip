@@ -471,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void cg_copy_rows(const T* __restrict__ src
 template <typename T>
 static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b, T* x_out, float accuracy,
                     int max_iterations, int rank_deficient, int reset, int fixed, int* iterations_out,
-                    float* kernel_ms_out, void* ws, size_t ws_bytes, piso_stream_t stream_) {
+                    float* kernel_ms_out, void* ws, size_t ws_bytes, piso_stream_t stream_, int* iterations_dev = nullptr) {
   if (nx < 1 || ny < 1 || !L || !b || !x_out || !ws || max_iterations < 0 || reset < 1) {
     set_error_msg("piso_cg_solve: invalid argument");
     return PISO_ERR_INVALID_ARG;
@@ -493,25 +493,31 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
       if (!ev[0]) { PISO_HIP_CHECK(hipEventCreate(&ev[0])); PISO_HIP_CHECK(hipEventCreate(&ev[1])); }
       PISO_HIP_CHECK(hipEventRecord(ev[0], stream));
     }
+    const bool async = iterations_dev != nullptr;         // the iteration count stays on the device: nothing waits for the solve
     const bool cols = nx <= 64 && ny <= kColsMaxNy && (!per_x || nx == 64) && opt(OPT_CG_TINY) != 2;    // (cg_tiny = 2: the general kernel, tests)
     if (cols && per_x)
       cg_tiny_cols<T, true><<<1, kTinyThreads, 0, stream>>>(L, b, x_out, nx, ny, per_y, fixed ? -1.0f : accuracy, total, fixed ? 0 : reset,
-                                                            rank_deficient, st_dev);
+                                                            rank_deficient, st_dev, iterations_dev);
     else if (cols)
       cg_tiny_cols<T, false><<<1, kTinyThreads, 0, stream>>>(L, b, x_out, nx, ny, per_y, fixed ? -1.0f : accuracy, total, fixed ? 0 : reset,
-                                                             rank_deficient, st_dev);
+                                                             rank_deficient, st_dev, iterations_dev);
     else
       cg_tiny<T><<<1, kTinyThreads, 0, stream>>>(L, b, x_out, nx, ny, per_x, per_y, fixed ? -1.0f : accuracy, total, fixed ? 0 : reset,
-                                                 rank_deficient, st_dev);
+                                                 rank_deficient, st_dev, iterations_dev);
     PISO_LAUNCH_CHECK();
+    ++g_tiny_solves;
+    if (async) return PISO_OK;
     if (ev) PISO_HIP_CHECK(hipEventRecord(ev[1], stream));
     CgState hst;
     PISO_HIP_CHECK(hipMemcpyAsync(&hst, st_dev, sizeof(CgState), hipMemcpyDeviceToHost, stream));
     PISO_HIP_CHECK(hipStreamSynchronize(stream));
-    ++g_tiny_solves;
     if (iterations_out) *iterations_out = (!fixed && hst.done) ? hst.iterations : total;
     if (ev) { float ms = 0; PISO_HIP_CHECK(hipEventElapsedTime(&ms, ev[0], ev[1])); kernel_ms_out[0] = total > 0 ? ms / (float)total : 0.f; kernel_ms_out[1] = 0.f; }
     return PISO_OK;
+  }
+  if (iterations_dev) {
+    set_error_msg("piso_cg_solve_async: this grid is solved with the host in the loop (segments, stopping test): call piso_cg_solve");
+    return PISO_ERR_NEEDS_HOST;
   }
   int nxp = nx, nyp = ny;
   const bool padded = opt(OPT_CG_PERSIST) != 0 && opt(OPT_CG_PAD) != 0 &&
@@ -612,6 +618,22 @@ int piso_cg_solve_f32(int nx, int ny, int periodic_x, int periodic_y, const floa
                       int* iterations_out, void* workspace, size_t workspace_bytes, piso_stream_t stream) {
   return cg_solve<float>(nx, ny, periodic_x, periodic_y, laplace, divergence, x_out, accuracy, max_iterations,
                          rank_deficient, residual_reset, 0, iterations_out, nullptr, workspace, workspace_bytes, stream);
+}
+
+int piso_cg_solve_async_f64(int nx, int ny, int periodic_x, int periodic_y, const double* laplace, const double* divergence,
+                            double* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
+                            int* iterations_dev, void* workspace, size_t workspace_bytes, piso_stream_t stream) {
+  if (!iterations_dev) { set_error_msg("piso_cg_solve_async: iterations_dev is NULL"); return PISO_ERR_INVALID_ARG; }
+  return cg_solve<double>(nx, ny, periodic_x, periodic_y, laplace, divergence, x_out, accuracy, max_iterations,
+                          rank_deficient, residual_reset, 0, nullptr, nullptr, workspace, workspace_bytes, stream, iterations_dev);
+}
+
+int piso_cg_solve_async_f32(int nx, int ny, int periodic_x, int periodic_y, const float* laplace, const float* divergence,
+                            float* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
+                            int* iterations_dev, void* workspace, size_t workspace_bytes, piso_stream_t stream) {
+  if (!iterations_dev) { set_error_msg("piso_cg_solve_async: iterations_dev is NULL"); return PISO_ERR_INVALID_ARG; }
+  return cg_solve<float>(nx, ny, periodic_x, periodic_y, laplace, divergence, x_out, accuracy, max_iterations,
+                         rank_deficient, residual_reset, 0, nullptr, nullptr, workspace, workspace_bytes, stream, iterations_dev);
 }
 
 int piso_cg_fixed_iterations_f64(int nx, int ny, int periodic_x, int periodic_y, const double* laplace,

@@ -49,7 +49,7 @@ __device__ __forceinline__ void tiny_block_sum(T (&v)[NV], T* smem /* [NV * 16] 
 template <typename T>
 __global__ __launch_bounds__(kTinyThreads) void cg_tiny(const T* __restrict__ L, const T* __restrict__ b, T* __restrict__ x_out, int nx, int ny,
                                                          int per_x, int per_y, float accuracy_f, int total, int reset, int rank_deficient,
-                                                         CgState* state_out) {
+                                                         CgState* state_out, int* iterations_dev) {
   constexpr int C = kTinyCellsPerThread;
   __shared__ T pbuf[kTinyMaxCells + 1];                     // the direction (slot n: the zero every missing neighbour reads)
   __shared__ T rbuf[kTinyMaxCells], xbuf[kTinyMaxCells];    // r and x of a thread's own cells (168 VGPRs per lane hold the coefficients,
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kTinyThreads) void cg_tiny(const T* __restrict__ L,
   }
 #pragma unroll
   for (int m = 0; m < C; ++m) if (own[m]) x_out[t + m * kTinyThreads] = xbuf[t + m * kTinyThreads];
-  if (t == 0) *state_out = st;
+  if (t == 0) { *state_out = st; if (iterations_dev) *iterations_dev = st.done ? st.iterations : total; }
 }
 
 // ---- the same solve with a COLUMN layout: lane = x (nx <= 64), wave w owns the rows [9 w, 9 w + 9) (ny <= 72: the lid-driven
@@ -250,7 +250,7 @@ __device__ __forceinline__ void cols_block_sum8(T (&v)[8], double* red /* [64] *
 // they execute the same sequence of barriers.
 template <typename T, bool PERX, bool FULL>
 __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __restrict__ b, T* __restrict__ x_out, int nx, int ny, int per_y,
-                                           float accuracy_f, int total, int reset, int rank_deficient, CgState* state_out,
+                                           float accuracy_f, int total, int reset, int rank_deficient, CgState* state_out, int* iterations_dev,
                                            T (*halo)[kTinyThreads / 64][64], double* red, T* bbuf, T* xbuf) {
   constexpr int C = kColsRows;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -425,13 +425,13 @@ __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __r
 #endif
 #pragma unroll
   for (int m = 0; m < C; ++m) if (m < rows && col) x_out[(j0 + m) * nx + lane] = xmine[m * 64];
-  if (threadIdx.x == 0) *state_out = st;
+  if (threadIdx.x == 0) { *state_out = st; if (iterations_dev) *iterations_dev = st.done ? st.iterations : total; }
 }
 
 template <typename T, bool PERX>
 __global__ __launch_bounds__(kTinyThreads) void cg_tiny_cols(const T* __restrict__ L, const T* __restrict__ b, T* __restrict__ x_out, int nx, int ny,
                                                               int per_y, float accuracy_f, int total, int reset, int rank_deficient,
-                                                              CgState* state_out) {
+                                                              CgState* state_out, int* iterations_dev) {
   // One buffer each: a halo exchange and a block sum always alternate, and each has a barrier between its writes and its reads -
   // whoever writes a buffer again has passed the other one's barrier, which every wave reaches only after its reads of this one.
   __shared__ T halo[2][kTinyThreads / 64][64];              // [0]: a wave's first row, [1]: its last row
@@ -439,9 +439,9 @@ __global__ __launch_bounds__(kTinyThreads) void cg_tiny_cols(const T* __restrict
   __shared__ T bbuf[kColsMaxNy * 64], xbuf[kColsMaxNy * 64];
   const int wave = threadIdx.x >> 6;
   if (PISO_TINY_COLS_FULL && nx == 64 && (wave + 1) * kColsRows <= ny)
-    cols_solve<T, PERX, true>(L, b, x_out, nx, ny, per_y, accuracy_f, total, reset, rank_deficient, state_out, halo, red, bbuf, xbuf);
+    cols_solve<T, PERX, true>(L, b, x_out, nx, ny, per_y, accuracy_f, total, reset, rank_deficient, state_out, iterations_dev, halo, red, bbuf, xbuf);
   else
-    cols_solve<T, PERX, false>(L, b, x_out, nx, ny, per_y, accuracy_f, total, reset, rank_deficient, state_out, halo, red, bbuf, xbuf);
+    cols_solve<T, PERX, false>(L, b, x_out, nx, ny, per_y, accuracy_f, total, reset, rank_deficient, state_out, iterations_dev, halo, red, bbuf, xbuf);
 }
 
 

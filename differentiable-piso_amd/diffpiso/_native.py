@@ -47,6 +47,10 @@ lib.piso_cg_workspace_bytes.restype = _sz
 for _n in ("piso_cg_solve_f64", "piso_cg_solve_f32"):
     getattr(lib, _n).argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _i, _ip, _vp, _sz, _vp]
     getattr(lib, _n).restype = _i
+for _n in ("piso_cg_solve_async_f64", "piso_cg_solve_async_f32"):
+    getattr(lib, _n).argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _f, _i, _i, _i, _vp, _vp, _sz, _vp]
+    getattr(lib, _n).restype = _i
+ERR_NEEDS_HOST = 5      # include/piso_hip.h: PISO_ERR_NEEDS_HOST
 lib.piso_cg_fixed_iterations_f64.argtypes = [_i, _i, _i, _i, _vp, _vp, _vp, _i, _i, C.POINTER(C.c_float), _vp, _sz, _vp]
 lib.piso_cg_fixed_iterations_f64.restype = _i
 lib.piso_cg_profile_enable.argtypes = [_i, _i]

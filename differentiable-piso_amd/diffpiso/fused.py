@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from .grids import CenteredGrid, StaggeredGrid, as_tensor, axis_extrapolation
+from .grids import CenteredGrid, StaggeredGrid, as_tensor, axis_extrapolation, device_constant
 
 _PAD = {"constant": 0, "boundary": 1, "replicate": 1, "symmetric": 1, "periodic": 2, "circular": 2}
 FACE_RHS, FACE_CORR1, FACE_FINAL = 0, 1, 2
@@ -227,8 +227,8 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
 
     # Predictor step (:36-47)
     p_data = pressure.data
-    forcing_flat = flat_faces(as_tensor(forcing_term, device=dev)) if forcing_term is not None else None
-    dv_flat = flat_faces(as_tensor(dirichlet_values, dtype=torch.float32, device=dev))
+    forcing_flat = flat_faces(device_constant(forcing_term, device=dev)) if forcing_term is not None else None
+    dv_flat = flat_faces(device_constant(dirichlet_values, dtype=torch.float32, device=dev))
     implicit_rhs = _FaceOp.apply(FACE_RHS, geom, p_data, vel_flat, forcing_flat, dv_flat, None, dmask)
     sol = sim.linear_solver.solve(-matrix_values, row_pointers, column_indices, implicit_rhs, staggered_shape, vel_flat, offset=1,
                                   transpose=False, unrolling_step=unrolling_step, warn=warn)

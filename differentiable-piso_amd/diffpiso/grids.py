@@ -20,6 +20,29 @@ def default_device():
     return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
 
 
+_constant_uploads = {}
+
+
+def device_constant(x, dtype=None, device=None):
+    """as_tensor for inputs a caller hands over again every step (the reference's scripts pass `sim.dirichlet_values`, a numpy
+    array, to every piso_step: lid_driven_cavity_2d.py:57-61).  A pageable host-to-device copy is stream-ordered - it waits for
+    every kernel queued before it - so a small numpy array is uploaded ONCE and found again by identity + checksum (an array
+    modified in place is uploaded again); tensors and large arrays go through as_tensor."""
+    if isinstance(x, np.ndarray) and 0 < x.nbytes <= (1 << 20) and device is not None:
+        import zlib
+        key = (id(x), x.shape, str(x.dtype), str(dtype), str(device))
+        crc = zlib.adler32(x if x.flags.c_contiguous else np.ascontiguousarray(x))
+        hit = _constant_uploads.get(key)
+        if hit is not None and hit[0] == crc:
+            return hit[1]
+        if len(_constant_uploads) > 32:
+            _constant_uploads.clear()
+        t = as_tensor(x, dtype=dtype, device=device)
+        _constant_uploads[key] = (crc, t)
+        return t
+    return as_tensor(x, dtype=dtype, device=device)
+
+
 def as_tensor(x, dtype=None, device=None):
     """numpy / python / torch -> torch tensor on the working device (no copy if already there)."""
     if isinstance(x, torch.Tensor):

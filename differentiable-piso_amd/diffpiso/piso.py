@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _native as N
-from .grids import CenteredGrid, Material, StaggeredGrid, as_tensor, default_device
+from .grids import CenteredGrid, Material, StaggeredGrid, as_tensor, default_device, device_constant
 from .stencils import (arrange_rhs_term_tf, finite_volume_divergence, finite_volume_gradient_tensor, flatten_staggered_data,
                        padded_velocity_flat, stagger_flattened_data)
 
@@ -86,6 +86,9 @@ def pressure_extrapolation(boundaries):
     return Material.accessible_extrapolation_mode(boundaries)
 
 
+_scalar_constants = {}
+
+
 def assemble_from_padded(vel_pad, nx, ny, dx_yx, per_x, per_y, dirichlet_mask_flat, active_mask, viscosity, no_slip_wall_mask, beta,
                          pattern=None):
     """The CentralDifferenceMatrixCsr call of advection_matrix_cuda (piso_tf.py:95-123) on an already padded, flattened
@@ -109,7 +112,16 @@ def assemble_from_padded(vel_pad, nx, ny, dx_yx, per_x, per_y, dirichlet_mask_fl
         csr_col, csr_row = pattern
         csr_val = torch.zeros(nnz, dtype=torch.float32, device=dev)
         diag = torch.zeros(n_u + n_v, dtype=torch.float32, device=dev)
-    visc = as_tensor(viscosity, dtype=torch.float32, device=dev).reshape(-1).contiguous()
+    if isinstance(viscosity, (int, float, np.floating, np.integer)):
+        # a constant: ONE upload per (value, device) - a pageable host-to-device copy per step would wait for everything queued before it
+        key = (float(viscosity), str(dev))
+        visc = _scalar_constants.get(key)
+        if visc is None:
+            if len(_scalar_constants) > 64:
+                _scalar_constants.clear()
+            visc = _scalar_constants[key] = torch.full((1,), float(viscosity), dtype=torch.float32, device=dev)
+    else:
+        visc = as_tensor(viscosity, dtype=torch.float32, device=dev).reshape(-1).contiguous()
     is_field = int(visc.numel() > 1)
     if is_field and visc.numel() != n_u + n_v:
         raise ValueError("viscosity field must have n_u + n_v entries (u first)")
@@ -226,7 +238,7 @@ def _piso_step_reference(velocity, pressure, pressure_inc1, pressure_inc2, dt, s
     # Predictor step (:36-47)
     implicit_rhs = vel_tensor * beta - finite_volume_gradient_tensor(pressure, sim)
     if forcing_term is not None:
-        implicit_rhs = implicit_rhs + as_tensor(forcing_term, device=dev) * dxdy
+        implicit_rhs = implicit_rhs + device_constant(forcing_term, device=dev) * dxdy
     implicit_rhs = arrange_rhs_term_tf(implicit_rhs, sim.dirichlet_mask, dirichlet_values, beta, coord_flip=True)
     sol = sim.linear_solver.solve(-matrix_values, row_pointers, column_indices, implicit_rhs, staggered_shape,
                                   flatten_staggered_data(velocity, True), offset=1, transpose=False,

@@ -205,12 +205,84 @@ def laplace_matrix_native(nx, ny, active, accessible, a0_vfirst, dtype):
     return L
 
 
+class DeferredInt(object):
+    """An iteration count that still lives on the device (asynchronous solves, piso_cg_solve_async_*): behaves like an int and
+    reads its value - ONE synchronising copy - the first time somebody looks at it.  Sums of such counts (solver.stats) stay
+    deferred, so a training loop that never looks never waits."""
+    __slots__ = ("_base", "_pending")
+
+    def __init__(self, base=0, pending=()):
+        self._base, self._pending = int(base), list(pending)
+
+    def device_tensor(self):
+        """The count as an int32 device tensor [1] (the reference's `iterations` output) without a host round trip."""
+        if len(self._pending) == 1 and self._base == 0:
+            return self._pending[0]
+        return torch.tensor([int(self)], dtype=torch.int32, device=self._pending[0].device if self._pending else None)
+
+    def __int__(self):
+        if self._pending:
+            self._base += int(torch.stack([t.reshape(()) for t in self._pending]).sum().item())
+            self._pending = []
+        return self._base
+
+    __index__ = __int__
+
+    def __add__(self, other):
+        if isinstance(other, DeferredInt):
+            out = DeferredInt(self._base + other._base, self._pending + other._pending)
+        else:
+            out = DeferredInt(self._base + int(other), self._pending)
+        if len(out._pending) > 64:          # (a long run that never looks: fold the pending counts on the device, still no wait)
+            out._pending = [torch.stack([t.reshape(()) for t in out._pending]).sum().to(torch.int64)]
+        return out
+
+    __radd__ = __add__
+
+    def __float__(self): return float(int(self))
+    def __bool__(self): return int(self) != 0
+    def __hash__(self): return hash(int(self))
+    def __repr__(self): return repr(int(self))
+    def __str__(self): return str(int(self))
+    def __format__(self, spec): return format(int(self), spec)
+    def __eq__(self, o): return int(self) == o
+    def __ne__(self, o): return int(self) != o
+    def __lt__(self, o): return int(self) < o
+    def __le__(self, o): return int(self) <= o
+    def __gt__(self, o): return int(self) > o
+    def __ge__(self, o): return int(self) >= o
+    def __sub__(self, o): return int(self) - o
+    def __rsub__(self, o): return o - int(self)
+    def __mul__(self, o): return int(self) * o
+    __rmul__ = __mul__
+    def __mod__(self, o): return int(self) % o
+    def __truediv__(self, o): return int(self) / o
+    def __rtruediv__(self, o): return o / int(self)
+    def __floordiv__(self, o): return int(self) // o
+    def __neg__(self): return -int(self)
+    def __abs__(self): return abs(int(self))
+
+
+_ASYNC_MAX_CELLS = 4608          # csrc/cg_tiny.h: kTinyMaxCells (the library answers PISO_ERR_NEEDS_HOST for anything it cannot run in one launch)
+
+
 def cg_solve_native(nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient, residual_reset):
+    """-> (x, iterations).  Grids the library solves in ONE launch (tiny grids: the lid-driven cavity) are queued without waiting
+    for the result; `iterations` is then a DeferredInt."""
     dt = L.dtype
     div = div.reshape(-1).to(dt).contiguous()
     x = torch.empty_like(div)
     elem = 8 if dt == torch.float64 else 4
     ws = N.workspace(N.lib.piso_cg_workspace_bytes(nx, ny, elem), div.device, "cg")
+    if nx * ny <= _ASYNC_MAX_CELLS:
+        it_dev = torch.empty(1, dtype=torch.int32, device=div.device)
+        fn = N.lib.piso_cg_solve_async_f64 if dt == torch.float64 else N.lib.piso_cg_solve_async_f32
+        st = fn(nx, ny, int(per_x), int(per_y), N.ptr(L), N.ptr(div), N.ptr(x), C.c_float(accuracy), int(max_iterations),
+                int(bool(rank_deficient)), int(residual_reset), N.ptr(it_dev), N.ptr(ws), C.c_size_t(ws.numel()), N.stream_ptr())
+        if st == 0:
+            return x, DeferredInt(0, [it_dev])
+        if st != N.ERR_NEEDS_HOST:
+            N.check(st, "piso_cg_solve_async")
     it = C.c_int(0)
     fn = N.lib.piso_cg_solve_f64 if dt == torch.float64 else N.lib.piso_cg_solve_f32
     st = fn(nx, ny, int(per_x), int(per_y), N.ptr(L), N.ptr(div), N.ptr(x), C.c_float(accuracy), int(max_iterations),
@@ -232,7 +304,7 @@ class _PressureSolveFn(torch.autograd.Function):
         solver.stats["iterations"] += it
         ctx.save_for_backward(L)
         ctx.meta = (solver, nx, ny, per_x, per_y, rank_deficient, divergence.shape)
-        iterations = torch.tensor([it], dtype=torch.int32, device=divergence.device)
+        iterations = it.device_tensor() if isinstance(it, DeferredInt) else torch.tensor([it], dtype=torch.int32, device=divergence.device)
         return x.reshape(divergence.shape).to(torch.float32), iterations
 
     @staticmethod

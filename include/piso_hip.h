@@ -36,6 +36,7 @@ extern "C" {
 #define PISO_ERR_HIP 2               /* a HIP runtime call failed (piso_last_error_string() has the text) */
 #define PISO_ERR_UNSUPPORTED_PATTERN 3 /* CSR input is not a 5-point staggered-grid matrix */
 #define PISO_ERR_NO_DEVICE 4
+#define PISO_ERR_NEEDS_HOST 5        /* piso_cg_solve_async_*: this grid is solved with the host in the loop, call piso_cg_solve_* */
 
 typedef void* piso_stream_t;
 
@@ -162,6 +163,17 @@ int piso_cg_solve_f64(int nx, int ny, int periodic_x, int periodic_y, const doub
 int piso_cg_solve_f32(int nx, int ny, int periodic_x, int periodic_y, const float* laplace, const float* divergence,
                       float* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
                       int* iterations_out, void* workspace, size_t workspace_bytes, piso_stream_t stream);
+
+/* The same solve WITHOUT a host round trip, where the library can run it in one launch (today: grids of at most 4 608 cells,
+ * csrc/cg_tiny.h - the lid-driven cavity of lid_driven_cavity_2d.py): the call returns as soon as the kernel is queued and the
+ * iteration count (the reference's `iterations` output tensor, pressure_solve_op.cc:60-76) is written to DEVICE memory.
+ * Any other grid: PISO_ERR_NEEDS_HOST and nothing has been queued - call piso_cg_solve_*. */
+int piso_cg_solve_async_f64(int nx, int ny, int periodic_x, int periodic_y, const double* laplace, const double* divergence,
+                            double* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
+                            int* iterations_dev, void* workspace, size_t workspace_bytes, piso_stream_t stream);
+int piso_cg_solve_async_f32(int nx, int ny, int periodic_x, int periodic_y, const float* laplace, const float* divergence,
+                            float* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
+                            int* iterations_dev, void* workspace, size_t workspace_bytes, piso_stream_t stream);
 
 /* Fixed-work variant for bandwidth measurements: runs exactly `iterations` CG iterations (no convergence test),
  * optionally timing the kernels with HIP events on `stream`; kernel_ms_out (NULL to skip): host float[2] = average ms per
