@@ -439,3 +439,33 @@ def test_cg_tiny_single_workgroup_matches_oracle(name, shape, reset, general, re
     else:
         assert it == 6000
     assert int(N.lib.piso_cg_tiny_solves()) - before == 2 * 8 + 1, "the single-workgroup kernel did not run"
+
+
+def test_cg_async_entry_for_tiny_grids_only():
+    """piso_cg_solve_async_*: a grid the library solves in one launch is queued without a host round trip (the count arrives in
+    device memory and equals the synchronous entry's); any other grid answers PISO_ERR_NEEDS_HOST and queues nothing."""
+    import ctypes as C
+    from diffpiso import _native as N
+    from diffpiso.solvers import DeferredInt, cg_solve_native
+    s, L, b = _laplace_case("cavity", 65, 64, seed=3)
+    Ld, bd = dev(L), dev(b)
+    x, it = cg_solve_native(s.nx, s.ny, False, False, Ld, bd, 1e-9, 3000, True, 10)
+    assert isinstance(it, DeferredInt)
+    xs = torch.empty_like(bd)
+    ws = N.workspace(N.lib.piso_cg_workspace_bytes(s.nx, s.ny, 8), bd.device, "cg")
+    its = C.c_int(0)
+    N.check(N.lib.piso_cg_solve_f64(s.nx, s.ny, 0, 0, N.ptr(Ld), N.ptr(bd), N.ptr(xs), C.c_float(1e-9), 3000, 1, 10, C.byref(its), N.ptr(ws),
+                                    C.c_size_t(ws.numel()), N.stream_ptr()), "piso_cg_solve_f64")
+    assert it == its.value and 0 < its.value < 3000 and torch.equal(x, xs)
+    s2, L2, b2 = _laplace_case("periodic", 128, 128, seed=3)
+    L2d, b2d = dev(L2), dev(b2)
+    x2 = torch.full_like(b2d, 123.0)
+    it_dev = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    ws2 = N.workspace(N.lib.piso_cg_workspace_bytes(128, 128, 8), b2d.device, "cg")
+    st = N.lib.piso_cg_solve_async_f64(128, 128, 1, 1, N.ptr(L2d), N.ptr(b2d), N.ptr(x2), C.c_float(1e-9), 100, 1, 10, N.ptr(it_dev), N.ptr(ws2),
+                                       C.c_size_t(ws2.numel()), N.stream_ptr())
+    torch.cuda.synchronize()
+    assert st == N.ERR_NEEDS_HOST and int(it_dev[0]) == -1 and float(x2.min()) == 123.0
+    _, it2 = cg_solve_native(128, 128, True, True, L2d, b2d, 1e-9, 100, True, 10)
+    assert isinstance(it2, int)
+

@@ -29,6 +29,27 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in N.lib.piso_version()
 
 
+def test_deferred_iteration_count_behaves_like_an_int():
+    """Asynchronous solves (piso_cg_solve_async_*) leave their iteration count on the device: solvers.DeferredInt reads it on first
+    use and sums stay deferred (solver.stats in a training loop never waits)."""
+    from diffpiso.solvers import DeferredInt
+    a = DeferredInt(0, [torch.tensor([7], dtype=torch.int32)])
+    b = DeferredInt(0, [torch.tensor([5], dtype=torch.int32)])
+    total = 0
+    total += a
+    total += b
+    total += 3
+    assert isinstance(total, DeferredInt) and len(total._pending) == 2          # nothing has been read yet
+    assert a.device_tensor().dtype == torch.int32 and int(a.device_tensor()[0]) == 7
+    assert total == 15 and int(total) == 15 and total._pending == []
+    assert a == 7 and a != 8 and a < 8 and a >= 7 and a % 5 == 2 and abs(a - 9) == 2 and a / 2 == 3.5 and max(a, b) == 7
+    assert "%d %s" % (a, b) == "7 5" and [0] * 10 and list(range(10))[b] == 5
+    many = 0
+    for _ in range(200):
+        many += DeferredInt(0, [torch.tensor([2], dtype=torch.int32)])
+    assert len(many._pending) <= 65 and many == 400
+
+
 def test_workspace_queries_and_nnz_closed_form():
     assert N.lib.piso_cg_workspace_bytes(2048, 2048, 8) > 9 * 2048 * 2048 * 8
     assert N.lib.piso_bicgstab_workspace_bytes(64, 64, 4) > 18 * (65 * 64 + 64 * 65) * 4
