@@ -61,7 +61,7 @@ PERSIST_PUBLISHED_VECTORS = {1: 1, 2: 2}   # exchanges per iteration -> vectors 
 EXCHANGE_US = 4.4            # one tagged-record grid exchange over 256 workgroups
 FP64_ISSUE_CYCLES = 4.75     # cycles per fp64 VALU instruction per SIMD with two waves resident
 FP64_INSTR_PER_CELL = {1: 29.2, 2: 38}   # counted in the ISA of cg_persist1: 935 fp64 add / fma per wave and iteration, 32 cells per lane
-VALU_INSTR_PER_CELL = {1: 63.6, 2: None}   # ... of 2034 VALU instructions in all (conversions, DPP shifts, lane reads, moves): EVERY
+VALU_INSTR_PER_CELL = {1: 52.3, 2: None}   # ... of 1674 VALU instructions in all (round 2: 2034) (conversions, DPP shifts, lane reads, moves): EVERY
                                            # VALU instruction of a 64-wide wave costs ~4.5 SIMD cycles (scripts/fp64_rate.hip)
 CLOCK_GHZ = 2.4
 
@@ -604,10 +604,9 @@ def main():
         k2_ms = ms_sum[1] / max(cnt[1], 1)
         k1_gbs = K1_BYTES_PER_CELL * ncell / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
         k2_gbs = K2_BYTES_PER_CELL * ncell / (k2_ms * 1e-3) / 1e9 if k2_ms > 0 else 0.0
-        exchanges = N.get_option("cg_exchanges")
-        exchanges = exchanges if exchanges in (1, 2) else int(N.lib.piso_cg_default_exchanges())
+        exchanges = 1          # grid-wide exchanges per persistent iteration (cg_persist1; the two-exchange kernel of rounds 1-2 is gone)
         if cnt[2] > 0:
-            # the CG iterations ran inside persistent segment launches (cg_persist.h): one launch = `its` iterations
+            # the CG iterations ran inside persistent segment launches (cg_persist1.h): one launch = `its` iterations
             its = cnt[2] / max(cnt[3], 1)
             seg_ms = ms_sum[2] / max(cnt[3], 1)
             it_us = 1e3 * ms_sum[2] / cnt[2]
@@ -633,7 +632,7 @@ def main():
             serial_floor = floors["fp64_valu_issue"] + floors["grid_exchanges"]   # the exchange cannot overlap the arithmetic it feeds
             roofline = {"bound": "hbm",       # (the contract's enum: the roofline `frac` is priced against; what BINDS the kernel is `binds`)
                         "binds": "valu_issue+exchange",
-                        "kernel": "cg_persist (one launch = %.0f CG iterations: r, p in registers, x in LDS, float coefficients "
+                        "kernel": "cg_persist1 (one launch = %.0f CG iterations: r, p in registers, x in LDS, float coefficients "
                                   "streamed, %d grid exchange%s per iteration, fp64)" % (its, exchanges, "" if exchanges == 1 else "s"),
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "frac_source": frac_source,

@@ -26,7 +26,6 @@ struct HostPoll {
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipEvent_t seg_ev[2] = {nullptr, nullptr};   // timing events around persistent segments (profiling only; created once)
 };
-constexpr int kPersistDefaultExchanges = 1;   // grid-wide exchanges per persistent iteration when cg_exchanges is not set
 static std::atomic<unsigned> g_persist_launches{0};   // persistent launches so far: the high half of their exchange tags
 static int g_persist_fallbacks = 0;            // solves that were restarted on the two-kernel path after an exchange timed out
 static long long g_tiny_solves = 0;            // solves that ran inside one workgroup (cg_tiny.h)
@@ -91,9 +90,9 @@ static size_t cg_workspace_bytes(int nx_in, int ny_in) {
 }
 
 template <typename T, typename CT, bool RECON, bool SYMV>
-static const void* persist_kernel(int R, int exchanges, bool ragged = false) {
+static const void* persist_kernel(int R, bool ragged = false) {
   if constexpr (sizeof(T) == 8 && RECON && SYMV) {
-    if (ragged && exchanges == 1) {
+    if (ragged) {
       switch (R) {
         case 2: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 2, RECON, SYMV, false, true>);
         case 4: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 4, 2, RECON, SYMV, false, true>);
@@ -101,19 +100,10 @@ static const void* persist_kernel(int R, int exchanges, bool ragged = false) {
       }
     }
   }
-  if (exchanges == 1) {
-    switch (R) {
-      case 2: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 2, RECON, SYMV>);
-      case 4: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 4, 2, RECON, SYMV>);
-      case 8: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 8, 2, RECON, SYMV>);
-      default: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 16, 1, RECON, SYMV>);
-    }
-  }
   switch (R) {
-    case 2: return reinterpret_cast<const void*>(&cg_persist<T, CT, 2, 2, RECON, SYMV>);
-    case 4: return reinterpret_cast<const void*>(&cg_persist<T, CT, 4, 2, RECON, SYMV>);
-    case 8: return reinterpret_cast<const void*>(&cg_persist<T, CT, 8, 2, RECON, SYMV>);
-    default: return reinterpret_cast<const void*>(&cg_persist<T, CT, 16, 1, RECON, SYMV>);
+    case 2: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 2, RECON, SYMV>);
+    case 4: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 4, 2, RECON, SYMV>);
+    default: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 16, 1, RECON, SYMV>);
   }
 }
 
@@ -178,23 +168,28 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   };
   bool pending = false;                                  // x still lacks alpha_k p_k of the last executed iteration
   int k_last = -1;
-  // ---- persistent segments (cg_persist.h): applicable when every wave's region fits on chip
+  // ---- persistent segments (cg_persist1.h): applicable when every wave's region fits on chip
   int persist_R = 0, persist_NQ = 0, persist_grid = 0;
   PersistCtl pc;
   pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr; pc.epoch0 = 0; pc.xcd = nullptr; pc.local_n = 0;
   bool xcd_local = false;                                // the solve runs on the workgroups of one XCD (cg_persist1<..., LOCAL>)
   constexpr int kXcdCus = 32;                            // CUs of one MI355X XCD
   const int force = opt(OPT_CG_PERSIST), force_r = opt(OPT_CG_PERSIST_R);   // -1: automatic
-  int exchanges = (opt(OPT_CG_EXCHANGES) == 1 || opt(OPT_CG_EXCHANGES) == 2) ? opt(OPT_CG_EXCHANGES) : kPersistDefaultExchanges;
-  if (sizeof(T) != 8) exchanges = 2;   // cg_persist1 is tuned for fp64 state (the fp32 instantiations spill registers)
+  // fp32 state: the 16-row instance keeps its registers only for a symmetric matrix with rebuilt diagonals (the others spill
+  // 26-84 VGPRs); any other fp32 system is tiled with regions of 4 / 2 rows (no spills), or iterates on the two-kernel path
+  const bool f32_small_regions = sizeof(T) != 8 && !(symmetric && RECON);
   if (V == 16 / (int)sizeof(T) && a.per_y != 2 && allow_persist && force != 0) {
     int dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     PersistShape shape = persist_shape(nx, ny, V, cus, force_r);
+    if (f32_small_regions && shape.R == 16) {
+      shape = PersistShape();
+      if (force_r <= 0) { shape = persist_shape(nx, ny, V, cus, 4); if (!shape.R) shape = persist_shape(nx, ny, V, cus, 2); }
+    }
     // XCD-local mode: symmetric compact coefficients, fp64, one exchange, at most one XCD's worth of workgroups
     constexpr bool kLocalKernel = RECON && sizeof(CT) == 4 && sizeof(T) == 8;
-    const bool local_ok = kLocalKernel && symmetric && exchanges == 1 && opt(OPT_CG_XCD_LOCAL) != 0 && !g_xcd_local_failed &&
+    const bool local_ok = kLocalKernel && symmetric && opt(OPT_CG_XCD_LOCAL) != 0 && !g_xcd_local_failed &&
                           cus == kXcds * kXcdCus;
     // (measured at 2048^2-class work per workgroup: regions of 4 rows to make a 64-workgroup grid fit one XCD lose more in the row
     // loops than the shorter exchange wins - 512^2: 6.2 against 4.5 us per iteration; 256^2, 16 workgroups either way: 3.8 against 4.3)
@@ -202,12 +197,11 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     xcd_local = local_ok && (persist_R == 2 || persist_R == 4) && persist_grid <= kXcdCus;
     if (persist_R && n < 16384 && force != 1 && !a.nx_true) persist_R = 0;    // tiny grids: two-kernel path (a padded grid is here BECAUSE it is small)
   }
-  if (persist_R == 8) exchanges = 2;   // (two regions of 8 rows per wave: cg_persist1 spills there; rare shape)
   const bool ragged = a.nx_true != 0;
   if (ragged && persist_R) {
     // the padded-grid variant exists for the common case only: fp64 state, one exchange, exact-float symmetric coefficients
     constexpr bool kRaggedKernel = RECON && sizeof(CT) == 4 && sizeof(T) == 8;
-    if (!kRaggedKernel || !symmetric || exchanges != 1 || persist_R == 8) persist_R = 0;
+    if (!kRaggedKernel || !symmetric) persist_R = 0;
   }
   if (!persist_R) xcd_local = false;
   const int launch_grid = xcd_local ? kXcds * persist_grid : persist_grid;   // (XCD-local: some XCD is dealt a full group)
@@ -216,8 +210,8 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     // hold (LDS, registers) times the CUs of the device must cover the grid; what it cannot see (another process, a CU mask)
     // is caught by the spin bound -> restart on the two-kernel path (below).
     constexpr bool kCanSymO = RECON && sizeof(CT) == 4;
-    const void* kfn = persist_kernel<T, CT, RECON, false>(persist_R, exchanges);
-    if constexpr (kCanSymO) { if (symmetric) kfn = persist_kernel<T, CT, RECON, true>(persist_R, exchanges, ragged); }
+    const void* kfn = persist_kernel<T, CT, RECON, false>(persist_R);
+    if constexpr (kCanSymO) { if (symmetric) kfn = persist_kernel<T, CT, RECON, true>(persist_R, ragged); }
     int per_cu = 0, dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -265,16 +259,9 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     }
 #define PISO_PERSIST_LAUNCH(SYMV)                                                                                            \
     do {                                                                                                                     \
-      if (exchanges == 1) {                                                                                                  \
-        if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);        \
-        else if (persist_R == 4) cg_persist1<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
-        else if (persist_R == 8) cg_persist1<T, CT, 8, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
-        else cg_persist1<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);                      \
-      } else                                                                                                                 \
-      if (persist_R == 2) cg_persist<T, CT, 2, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);        \
-      else if (persist_R == 4) cg_persist<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
-      else if (persist_R == 8) cg_persist<T, CT, 8, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
-      else cg_persist<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);                      \
+      if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);        \
+      else if (persist_R == 4) cg_persist1<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
+      else cg_persist1<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);                      \
     } while (0)
     if constexpr (kCanSym) {
       if (symmetric) {
@@ -396,7 +383,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
                                      kernel_ms_out, stream, false);
     }
   }
-  // ---- The persistent kernel lets workgroups read what others published without release / acquire fences (cg_persist.h).  That
+  // ---- The persistent kernel lets workgroups read what others published without release / acquire fences (cg_persist1.h).  That
   // is checked here at run time instead of being trusted: r - the CG recurrence - must still equal b - A^ x for the x the solve
   // returns (to eps * condition * |b|; a stale perimeter value would leave an O(alpha |z'|) gap that nothing removes before the
   // next residual reset).  One stencil pass per solve; a failure restarts the solve on the two-kernel path and is counted.
@@ -424,12 +411,10 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     std::vector<unsigned long long> h(12 * persist_grid);
     PISO_HIP_CHECK(hipMemcpy(h.data(), pc.timing, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     PISO_HIP_CHECK(hipFree(pc.timing));
-    const char* names2[5] = {"phaseA", "barrierA", "phaseB", "barrierB", "-"};
-    const char* names1[9] = {"D (p update, stencil, sums, publish)", "exchange", "U (stencil, x / r update, ring)", "-", "-",
+    const char* names[9] = {"D (p update, stencil, sums, publish)", "exchange", "U (stencil, x / r update, ring)", "-", "-",
                              "  exchange: wave sums + drain of the perimeter stores", "  exchange: first barrier", "  exchange: publish + polling",
                              "  exchange: record sums + second barrier"};
-    const char** names = exchanges == 1 ? names1 : names2;
-    for (int q = 0; q < (exchanges == 1 ? 9 : 5); ++q) {
+    for (int q = 0; q < 9; ++q) {
       double s = 0, mn = 1e300, mx = 0;
       for (int b = 0; b < persist_grid; ++b) { const double v = (double)h[q * persist_grid + b]; s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
       fprintf(stderr, "cg_persist %s: avg %.2f us/iter  min %.2f  max %.2f\n", names[q], 0.01 * s / persist_grid / (double)(k_last > 0 ? k_last : 1),
@@ -576,7 +561,7 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   int rc = PISO_OK;
 #define PISO_CG_RUN(CT, V, RECON) \
   rc = cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream)
-  if (sizeof(T) == 8 && !hflags[0]) {
+  if (!hflags[0]) {                                         // (fp32 state: trivially exact - the same path, so that the diagonal can be rebuilt there too)
     a.oS = oF; a.oW = oF + n; a.oE = oF + 2 * n; a.oN = oF + 3 * n;
     if (!hflags[1]) { if (vec) PISO_CG_RUN(float, VMID, true); else PISO_CG_RUN(float, 1, true); }
     else if (vec) PISO_CG_RUN(float, VMID, false);
@@ -656,7 +641,6 @@ void piso_cg_verify_stats(long long* runs_out, int* failures_out) {
   if (runs_out) *runs_out = g_verify_runs;
   if (failures_out) *failures_out = g_verify_failures;
 }
-int piso_cg_default_exchanges(void) { return kPersistDefaultExchanges; }
 
 void piso_cg_profile_read(double* ms_sum, long long* count) {
   for (int q = 0; q < 4; ++q) { ms_sum[q] = g_prof.ms[q]; count[q] = g_prof.count[q]; }

@@ -1,8 +1,10 @@
-// Persistent CG segment kernel with ONE grid-wide exchange per iteration (cg_persist.h needs two).
+// Persistent CG segment kernel: many NORMAL iterations in ONE launch with ONE grid-wide exchange per iteration, for grids whose
+// solver state fits on chip (DESIGN.md 3.1 has the measurements behind every choice below; the first persistent kernel of rounds
+// 1-2 needed two exchanges).
 //
-// Same residency as cg_persist (r, p in registers, x in LDS, float coefficient rows streamed through a circular software
-// pipeline, one workgroup of 512 threads per CU) and the same per-cell arithmetic (zrow: summation order of calcZ_v4,
-// pressure_solve_op.cu.cc:81-90).  What changes is how the two dependent reductions of a CG iteration are obtained:
+// r, p in registers, x in LDS, float coefficient rows streamed through a circular software pipeline, one workgroup of 512 threads
+// per CU; per-cell arithmetic as the two-kernel path (zrow: summation order of calcZ_v4, pressure_solve_op.cu.cc:81-90).  How the
+// two dependent reductions of a CG iteration are obtained from one exchange:
 //
 //   D(k)  p_k = r_k + beta_k p_{k-1};  z' = L p_k;  local sums  S p, p.r, p.z', r.z', z'.z', S z'
 //         the PERIMETER of z' is published (sc1 stores, ping-pong buffer k & 1)
@@ -42,7 +44,8 @@ namespace piso {
 struct NoSlab {};
 // region shape of the persistent kernels for an nx x ny grid (V cells per lane, `cus` compute units): one region of 16 rows per
 // wave has the smallest halo overhead and is taken when it keeps at least 3/4 of the waves busy (or when forced); else two
-// regions of 2 / 4 / 8 rows per wave.  R = 0: the grid cannot be tiled (two-kernel iteration).
+// regions of 2 / 4 rows per wave (two regions of 8 rows do not fit the registers: such shapes - ny a multiple of 8 but not of 16 on
+// a grid too large for 4-row regions - iterate on the two-kernel path).  R = 0: the grid cannot be tiled (two-kernel iteration).
 struct PersistShape { int R = 0, NQ = 0, nreg = 0, ntx = 0, grid = 0; };
 inline PersistShape persist_shape(int nx, int ny, int V, int cus, int force_r) {
   PersistShape s;
@@ -55,7 +58,7 @@ inline PersistShape persist_shape(int nx, int ny, int V, int cus, int force_r) {
       s.grid = (int)((nreg + kPersistWaves - 1) / kPersistWaves);
     }
   }
-  for (int R : {2, 4, 8}) {
+  for (int R : {2, 4}) {
     if (s.R) break;
     if (force_r > 0 && force_r != R) continue;
     if (ny % R != 0) continue;                              // every region has R rows
@@ -113,8 +116,16 @@ struct SlabCtl {
 constexpr int kX1Values = 8;                     // sums per exchange
 constexpr int kX1RecWords = 16;                  // 8-byte words per record: 2 per sum {32 payload bits | 32-bit epoch}
 
-// Exchange of kX1Values sums per workgroup; same protocol as grid_exchange (tagged 8-byte words, relaxed agent-scope atomics,
-// fixed summation order -> bitwise equal totals in every workgroup).  Measured: with one 128-byte record per LANE (64 cache
+// Grid-wide exchange of kX1Values partial sums per workgroup that doubles as the grid barrier (measured 4.4 us for 256 workgroups
+// against 11.3 us for "atomic counter + fence + read the partials", scripts/barrier_bench.hip):
+//   * every workgroup publishes one record: each double travels as two 8-byte words {32 payload bits | 32-bit epoch}, written and
+//     read with relaxed agent-scope atomics (single-copy atomic, coherent across the 8 XCDs' L2s);
+//   * the waves poll all records until they carry the current epoch and add them in a fixed order, so every workgroup obtains
+//     bitwise the same totals - no counter, no fence, one memory round trip;
+//   * records alternate between two arrays (epoch parity): a fast workgroup may publish epoch e+1 while a slow one still reads
+//     epoch e, and nobody can reach e+2 before everybody has published e+1.
+// DATA written before the exchange (the published perimeter rows) is stored write-through at agent scope (sc1) and drained
+// (s_waitcnt vmcnt) by every wave before the workgroup publishes; readers load it at agent scope as well.  Measured: with one 128-byte record per LANE (64 cache
 // lines per load instruction) the exchange is bound by the number of fabric transactions (11 us per exchange at 256
 // workgroups).  Here the polling is COALESCED and spread over all 8 waves: lane l reads word l % 16 of record 4 i + l / 16, so
 // one load instruction covers four whole records (512 contiguous bytes); wave w polls records 32 w .. 32 w + 31 with 8 loads

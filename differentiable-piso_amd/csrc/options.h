@@ -6,9 +6,8 @@ namespace piso {
 
 enum Opt {
   OPT_CG_PERSIST = 0,      // 0 forbid / 1 force the persistent CG kernel (default: by grid size)
-  OPT_CG_PERSIST_R,        // rows per region of the persistent kernel: 2 | 4 | 8 | 16
+  OPT_CG_PERSIST_R,        // rows per region of the persistent kernel: 2 | 4 | 16
   OPT_CG_SEGMENT,          // CG iterations per persistent launch
-  OPT_CG_EXCHANGES,        // grid-wide exchanges per persistent iteration: 1 (merged reductions) | 2 (reference recurrences)
   OPT_CG_PERSIST_TIMING,   // per-phase clocks of the persistent kernel (diagnostic builds only)
   OPT_CG_RPW,              // two-kernel path: rows per wave of K1
   OPT_CG_MAXBLOCKS,        // two-kernel path: grid cap of K1

@@ -6,7 +6,7 @@
 // (one hop, no library call between kernels) and READ locally by the consumer:
 //   * reductions travel as tagged 8-byte words {32 payload bits | 32-bit sequence tag}: single-copy atomic, so a word that
 //     carries the expected tag is complete by itself - no flag, no fence (the protocol of the persistent CG kernel's grid
-//     exchange, cg_persist.h, at system scope);
+//     exchange, cg_persist1.h, at system scope);
 //   * halo rows (64-bit payloads) are followed by a system-scope RELEASE store of their sequence number; the consumer
 //     ACQUIREs it before reading the row;
 //   * everything alternates between two slots by sequence parity; a rank can run at most one collective ahead of its slowest

@@ -32,7 +32,6 @@ lib.piso_get_option.argtypes = [C.c_char_p, _ip]
 lib.piso_get_option.restype = _i
 lib.piso_cg_persist_fallbacks.restype = _i
 lib.piso_cg_tiny_solves.restype = C.c_longlong
-lib.piso_cg_default_exchanges.restype = _i
 lib.piso_cg_verify_stats.argtypes = [C.POINTER(C.c_longlong), _ip]
 lib.piso_cg_verify_stats.restype = None
 lib.piso_csr_nnz.argtypes = [_i, _i, _i, _i, _ip, _ip]

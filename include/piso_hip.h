@@ -47,8 +47,8 @@ const char* piso_last_error_string(void);
 int piso_device_count(void);
 /* Tuning / test knobs (no counterpart in the reference).  Each knob `name` takes its default ONCE, at library load, from the
  * environment variable PISO_<NAME IN UPPER CASE>; -1 = not set (automatic).  Process-wide, not thread-safe against a
- * concurrent solve.  Names: cg_persist (0 forbid / 1 force the persistent CG kernel), cg_persist_r (2|4|8|16 rows per region),
- * cg_segment (iterations per persistent launch), cg_exchanges (1|2 grid exchanges per persistent iteration),
+ * concurrent solve.  Names: cg_persist (0 forbid / 1 force the persistent CG kernel), cg_persist_r (2|4|16 rows per region),
+ * cg_segment (iterations per persistent launch),
  * cg_persist_timing, cg_rpw, cg_maxblocks, cg_nt, cg_no_compact, cg_no_recon, cg_no_sym, cg_verify (0: skip the true-residual
  * check of persistent solves; 2: test knob, treat it as failed), cg_pad (0: never run a small wall-bounded grid that the
  * persistent kernel cannot tile on a zero-padded one). */
@@ -152,7 +152,7 @@ int piso_laplace_matrix_f32(int nx, int ny, const float* active, const float* fl
  *   laplace [N][5], divergence [N], x_out [N]; iterations_out: host int* (also the reference's `iterations` output)
  * The call returns when the solve has finished (the host must see the convergence flag, as in the reference).
  * Grids whose rows are a multiple of 128 cells (fp64; 256 for fp32) and that fit the chip run the iterations inside
- * persistent launches (csrc/cg_persist.h); a grid-wide exchange that times out fails the call with
+ * persistent launches (csrc/cg_persist1.h); a grid-wide exchange that times out fails the call with
  * PISO_ERR_HIP.  Tuning / test knobs: piso_set_option() above.
  * ------------------------------------------------------------------------------------------------------------- */
 size_t piso_cg_workspace_bytes(int nx, int ny, int elem_size);
@@ -201,8 +201,6 @@ long long piso_cg_tiny_solves(void);
  * restarts the solve on the two-kernel iteration and is counted here (and in piso_cg_persist_fallbacks).  Option "cg_verify": 0
  * skips the check, 2 treats every check as failed (test knob). */
 void piso_cg_verify_stats(long long* runs_out, int* failures_out);
-/* Grid-wide exchanges per iteration of the persistent kernel when the option cg_exchanges is not set (1 or 2). */
-int piso_cg_default_exchanges(void);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Convolutions of the CNN turbulence closure on the matrix cores (csrc/conv.hip; exact fp32 MFMA).  Replaces the

@@ -21,7 +21,7 @@ for nit in (3,):
     N.set_option("cg_persist", 0)
     xa, _ = cg_solve_native(nx, ny, True, True, L, b, 1e-30, nit, False, 1000)
     ref = arrays()
-    N.set_option("cg_persist", 1); N.set_option("cg_persist_r", 16); N.set_option("cg_exchanges", 1)
+    N.set_option("cg_persist", 1); N.set_option("cg_persist_r", 16)
     for rep in range(3):
         xb, _ = cg_solve_native(nx, ny, True, True, L, b, 1e-30, nit, False, 1000)
         got = arrays()

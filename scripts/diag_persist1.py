@@ -29,13 +29,10 @@ def main():
             for nit in (1, 2, 3, 5, 10, 40, 150):
                 N.set_option("cg_persist", 0)
                 xa, _ = cg_solve_native(nx, ny, True, True, L, b, 1e-30, nit, False, 1000)
-                res = []
-                for ex in (2, 1):
-                    N.set_option("cg_persist", 1); N.set_option("cg_persist_r", rows); N.set_option("cg_segment", seg); N.set_option("cg_exchanges", ex)
-                    xb, _ = cg_solve_native(nx, ny, True, True, L, b, 1e-30, nit, False, 1000)
-                    res.append(float((xa - xb).abs().max() / xa.abs().max()))
-                out.append("%d: %.1e/%.1e" % (nit, res[0], res[1]))
-            print("grid %dx%d R=%d seg=%d  [nit: diff 2-exchange / 1-exchange]  " % (nx, ny, rows, seg) + "  ".join(out), flush=True)
+                N.set_option("cg_persist", 1); N.set_option("cg_persist_r", rows); N.set_option("cg_segment", seg)
+                xb, _ = cg_solve_native(nx, ny, True, True, L, b, 1e-30, nit, False, 1000)
+                out.append("%d: %.1e" % (nit, float((xa - xb).abs().max() / xa.abs().max())))
+            print("grid %dx%d R=%d seg=%d  [nit: persistent vs two-kernel]  " % (nx, ny, rows, seg) + "  ".join(out), flush=True)
     print("fallbacks", N.lib.piso_cg_persist_fallbacks())
 
 if __name__ == "__main__":

@@ -18,9 +18,8 @@ def problem():
     return bench.build_problem(N, torch.device("cuda"), 1e-6, 10000, 1000)
 
 
-@pytest.mark.parametrize("exchanges", [2, 1])
 @pytest.mark.parametrize("walls", [False, True])
-def test_persistent_cg_equals_two_kernel_path_2048(walls, exchanges, piso_option):
+def test_persistent_cg_equals_two_kernel_path_2048(walls, piso_option):
     """The persistent kernel at the benchmark size (all 256 CUs, 2048 regions exchanging perimeters and partial sums across
     the 8 XCDs) against the two-kernel iteration: same arithmetic per cell, only the summation order of the dot products
     differs, so after 150 iterations the iterates agree to round-off.  One stale halo cell or one torn exchange record would
@@ -47,24 +46,22 @@ def test_persistent_cg_equals_two_kernel_path_2048(walls, exchanges, piso_option
     xa, ita = cg_solve_native(N, N, per, per, L, b, 1e-30, 150, False, 1000)
     piso_option("cg_persist", 1)
     piso_option("cg_segment", 40)
-    piso_option("cg_exchanges", exchanges)
     scale = float(xa.abs().max())
     # cg_persist1 (one exchange) obtains r.z' and sum r from one-step recurrences instead of dot products: algebraically equal,
     # round-off different -> the iterates separate slightly faster than with a mere change of summation order
-    bound = 1e-10 if exchanges == 2 else 2e-10        # measured: 4.7e-12 / 2.3e-11 (periodic), 7.6e-12 / ~3e-11 (walls)
+    bound = 2e-10        # measured: 2.3e-11 (periodic), ~3e-11 (walls)
     import diffpiso._native as Nn
     f0 = Nn.lib.piso_cg_persist_fallbacks()
     for rep in range(4):
         xb, itb = cg_solve_native(N, N, per, per, L, b, 1e-30, 150, False, 1000)
         assert ita == itb == 150
         d = float((xa - xb).abs().max()) / scale
-        print("persistent (%d exchange%s) vs two-kernel after 150 iterations: %.2e" % (exchanges, "" if exchanges == 1 else "s", d))
+        print("persistent vs two-kernel after 150 iterations: %.2e" % d)
         assert d <= bound, rep
     assert Nn.lib.piso_cg_persist_fallbacks() == f0, "a grid exchange timed out and the solve fell back to the two-kernel path"
 
 
-@pytest.mark.parametrize("exchanges", [1, 2])
-def test_persistent_cg_first_iterations_back_to_back_launches_2048(exchanges, piso_option):
+def test_persistent_cg_first_iterations_back_to_back_launches_2048(piso_option):
     """Short solves queued back to back (no host synchronisation in between, device copies in flight when the persistent kernel
     starts) against the two-kernel iteration after 3, 4 and 6 iterations: agreement to round-off (measured 2e-16 .. 5e-16).
     Regression for a buffer-store data hazard: a 16-byte perimeter store whose row offset sat in an SGPR was followed directly by
@@ -80,7 +77,6 @@ def test_persistent_cg_first_iterations_back_to_back_launches_2048(exchanges, pi
         xa, _ = cg_solve_native(N, N, True, True, L, b, 1e-30, nit, False, 1000)
         piso_option("cg_persist", 1)
         piso_option("cg_persist_r", 16)
-        piso_option("cg_exchanges", exchanges)
         outs = []
         for rep in range(6):
             xb, _ = cg_solve_native(N, N, True, True, L, b, 1e-30, nit, False, 1000)
