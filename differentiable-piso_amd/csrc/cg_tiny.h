@@ -282,16 +282,22 @@ __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __r
   const T sc_c = rank_deficient ? dsum[0] * (T)(.1 / (double)n) : (T)0;            // cg_init
   const T accuracy = (T)accuracy_f;
   // z' = L v for my cells, v in registers (phantom rows and lanes hold 0)
-  // all_rows / all_cells (wave-uniform): this wave's nine rows / its 9 x 64 cells are all real - the selects and masks that only the
-  // wave with the grid's top rows (or a grid narrower than 64) needs are branched around, not executed
-  const bool all_rows = FULL || rows == C, all_cells = FULL || (rows == C && nx == 64);
-  auto stencil_rows = [&](const T (&v)[C], T hS, T hN, auto whole) __attribute__((always_inline)) {
+  auto apply = [&](const T (&v)[C]) __attribute__((always_inline)) {
+    // my first and last rows to the waves below and above, theirs to me
+    if (rows > 0) {
+      halo[0][wave][lane] = v[0];
+#pragma unroll
+      for (int m = 0; m < C; ++m) if (m == rows - 1) halo[1][wave][lane] = v[m];
+    }
+    __syncthreads();
+    const T hS = srcS >= 0 ? halo[1][srcS][lane] : (T)0;
+    const T hN = srcN >= 0 ? halo[0][srcN][lane] : (T)0;
 #pragma unroll
     for (int mm = 0; mm < C; ++mm) {
       const int m = mm < C - 2 ? mm + 1 : (mm == C - 2 ? 0 : C - 1);     // the rows next to the halo rows last: their LDS reads are in flight
       const T vS = m == 0 ? hS : v[m - 1];
       T vN = m + 1 < C ? v[m + 1] : hN;
-      if constexpr (!decltype(whole)::value) { if (m + 1 == rows) vN = hN; }   // (the row above my last one is another wave's)
+      if (m + 1 == rows) vN = hN;                            // (wave-uniform: only the wave with the grid's top row has rows < C)
       const T vW = cols_shift<true, PERX>(v[m]), vE = cols_shift<false, PERX>(v[m]);
       T acc = 0;                                             // summation order of calcZ_v4 (:81-90): S, W, C, E, N
       acc = fma(cS[m], vS, acc);
@@ -302,22 +308,6 @@ __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __r
       z[m] = acc;
       __builtin_amdgcn_sched_barrier(0);                     // (one row at a time: the shifted copies of ALL rows at once do not fit the registers)
     }
-  };
-  auto apply = [&](const T (&v)[C]) __attribute__((always_inline)) {
-    // my first and last rows to the waves below and above, theirs to me
-    if (all_rows) {
-      halo[0][wave][lane] = v[0];
-      halo[1][wave][lane] = v[C - 1];
-    } else if (rows > 0) {
-      halo[0][wave][lane] = v[0];
-#pragma unroll
-      for (int m = 0; m < C; ++m) if (m == rows - 1) halo[1][wave][lane] = v[m];
-    }
-    __syncthreads();
-    const T hS = srcS >= 0 ? halo[1][srcS][lane] : (T)0;
-    const T hN = srcN >= 0 ? halo[0][srcN][lane] : (T)0;
-    if (all_rows) stencil_rows(v, hS, hN, std::true_type());
-    else stencil_rows(v, hS, hN, std::false_type());
   };
   CgState st = {0, 0, 0, 0};
   T pz = 1, vs = 0, rz_next = 0, sumr = 0;                  // (cg_init: SC_PZ = 1, SC_VS = 0)
@@ -406,20 +396,26 @@ __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __r
     TINY_TICK(4)                                            // test, alpha, beta
     // ---- U(k): x += alpha p; r -= alpha (z' + c sum p)
     lr = 0; lc = 0;
-    auto u_pass = [&](auto whole, auto counting) __attribute__((always_inline)) {
+    if (count_now) {             // (the count is only read by the test of iteration k + 1)
 #pragma unroll
       for (int m = 0; m < C; ++m) {
         xmine[m * 64] = fma(alpha, p[m], xmine[m * 64]);
-        if (decltype(whole)::value || (m < rows && col)) {
+        if (m < rows && col) {
           r[m] = fma(-alpha, z[m] + vs, r[m]);
           lr += r[m];
-          if constexpr (decltype(counting)::value) lc += (absval(r[m]) < accuracy) ? 0 : 1;     // NaN counts as exceeding
+          lc += (absval(r[m]) < accuracy) ? 0 : 1;          // NaN counts as exceeding
         }
       }
-    };
-    // (the count is only read by the stopping test of iteration k + 1)
-    if (all_cells) { if (count_now) u_pass(std::true_type(), std::true_type()); else u_pass(std::true_type(), std::false_type()); }
-    else { if (count_now) u_pass(std::false_type(), std::true_type()); else u_pass(std::false_type(), std::false_type()); }
+    } else {
+#pragma unroll
+      for (int m = 0; m < C; ++m) {
+        xmine[m * 64] = fma(alpha, p[m], xmine[m * 64]);
+        if (m < rows && col) {
+          r[m] = fma(-alpha, z[m] + vs, r[m]);
+          lr += r[m];
+        }
+      }
+    }
     TINY_TICK(5)                                            // U
   }
 #ifdef PISO_TINY_DIAG
