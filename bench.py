@@ -476,6 +476,10 @@ def main():
     ap.add_argument("--residual-reset", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the bicgstab / other_configs legs (profiling runs)")
+    ap.add_argument("--transport", choices=["peer", "rccl"], default=os.environ.get("PISO_BENCH_TRANSPORT", "peer"),
+                    help="what carries halo rows and dot products of the slab modes: 'peer' = mailboxes mapped across the GPUs (hipIpc; the "
+                         "persistent slab CG needs it), 'rccl' = the library's RCCL communicator (send / recv + all-reduce on the stream, "
+                         "two-kernel CG) - what 'auto' falls back to where the environment refuses hipIpc")
     ap.add_argument("--decomp", choices=["auto", "replicas", "slab", "slab-weak"], default=os.environ.get("PISO_BENCH_DECOMP", "auto"),
                     help="N > 1: 'slab-weak' = ONE grid x (grid * N) periodic box cut into y-slabs, a grid x grid slab per GPU: the "
                          "WHOLE step is sharded (assembly, glue, Laplacian on the rank's rows with halo rows through peer-mapped "
@@ -524,7 +528,7 @@ def main():
         # mailbox rows: the longest halo message is two face rows of u and three of v, five matrix values each
         comm_err = None
         try:
-            P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=26 * n + 64)
+            P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport=args.transport, row_capacity=26 * n + 64)
         except Exception as e:
             comm_err = repr(e)
         if args.sharded_child:
@@ -534,11 +538,11 @@ def main():
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             if okt.item() <= 0:
                 if rank == 0:
-                    print(json.dumps({"sharded_unavailable": comm_err or "another rank could not set up the peer transport"}), flush=True)
+                    print(json.dumps({"sharded_unavailable": comm_err or "another rank could not set up the %s transport" % args.transport}), flush=True)
                 dist.destroy_process_group()
                 sys.exit(0)
         elif comm_err:
-            raise RuntimeError("the peer transport could not be set up: " + comm_err)
+            raise RuntimeError("the %s transport could not be set up: %s" % (args.transport, comm_err))
         P["lin"].slab_comm = P["ps"].slab_comm       # the ILU(0)-BiCGStab is cut into the same slabs (dot products all-reduced)
         P["sharding"] = P["sim"].sharding = StepSharding(P["ps"].slab_comm, n, ny_grid)   # ... and so is everything else of the step
 
@@ -592,6 +596,7 @@ def main():
         loss, grad_norm = float(tot[0]), float(tot[2]) ** 0.5
         st_ = P["ps"].slab_comm.stats()
         sharded_info = {"ranks_seen": int(round(float(tot[1]))), "rows_per_rank": ny_grid // world, "halo_exchanges": P["sharding"].exchanges,
+                        "transport": st_["transport"],
                         "persistent_slab_iterations": st_["persistent_iterations"], "persistent_fallbacks": st_["persistent_fallbacks"],
                         "slab_solves_verified_against_true_residual": st_["solves_verified"], "verification_failures": st_["verification_failures"],
                         "what_is_sharded": "assembly, padding, stencil glue (forward + reverse mode), Laplacian, CSR product, ILU(0)-BiCGStab, "
@@ -728,34 +733,56 @@ def main():
         # its cross-GPU path has never met real xGMI before the driver's node, and an exception, a hang (600 s limit) or a crash
         # of the HIP runtime there must not cost the line this process is about to print.
         import subprocess
-        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 11), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"))
-        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
-        cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--decomp", "slab-weak", "--gpus", str(world), "--grid", str(n),
-               "--steps", str(args.steps), "--warmup", str(args.warmup), "--tol", repr(args.tol), "--max-iterations", str(args.max_iterations),
-               "--residual-reset", str(args.residual_reset), "--no-cpu-baseline", "--no-extras"]
-        torch.cuda.synchronize()
-        child, err = None, None
-        try:
-            cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-            if cp.returncode != 0:
-                err = {"error": "the sharded run ended with code %d" % cp.returncode, "stderr_tail": cp.stderr[-800:]}
-            elif rank == 0:
-                lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
-                child = json.loads(lines[-1]) if lines else None
-                if child is None:
-                    err = {"error": "the sharded run printed no line", "stderr_tail": cp.stderr[-800:]}
-        except subprocess.TimeoutExpired:
-            err = {"error": "the sharded run timed out after 600 s"}
-        except Exception as e:
-            err = {"error": repr(e)}
-        okt = torch.tensor([0.0 if err is not None else 1.0], device="cpu" if share_gpu else device)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        all_ok = bool(okt.item() > 0)
+
+        def sharded_attempt(transport, port_offset, limit_s):
+            """-> (child line of rank 0 or None, error or None, every rank's attempt ended well)"""
+            env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset),
+                       MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"))
+            env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+            cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--decomp", "slab-weak", "--transport", transport, "--gpus", str(world),
+                   "--grid", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup), "--tol", repr(args.tol),
+                   "--max-iterations", str(args.max_iterations), "--residual-reset", str(args.residual_reset), "--no-cpu-baseline", "--no-extras"]
+            torch.cuda.synchronize()
+            child, err = None, None
+            try:
+                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit_s)
+                if cp.returncode != 0:
+                    err = {"error": "the sharded run (%s transport) ended with code %d" % (transport, cp.returncode), "stderr_tail": cp.stderr[-800:]}
+                elif rank == 0:
+                    lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+                    child = json.loads(lines[-1]) if lines else None
+                    if child is None:
+                        err = {"error": "the sharded run (%s transport) printed no line" % transport, "stderr_tail": cp.stderr[-800:]}
+            except subprocess.TimeoutExpired:
+                err = {"error": "the sharded run (%s transport) timed out after %d s" % (transport, limit_s)}
+            except Exception as e:
+                err = {"error": repr(e)}
+            # [0]: every rank's attempt ended well; [1]: rank 0's child said the transport cannot be set up here
+            t = torch.tensor([0.0 if err is not None else 1.0, -1.0 if (child is not None and "sharded_unavailable" in child) else 0.0],
+                             device="cpu" if share_gpu else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return child, err, bool(t[0].item() > 0), bool(t[1].item() < 0)
+
+        child, err, all_ok, refused = sharded_attempt("peer", 11, 600)
+        skipped = None
+        if all_ok and refused:
+            # hipIpc handles / peer access refused by the environment: not a failure.  The RCCL transport carries the same sharded step
+            # (send / recv + all-reduce on the stream, two-kernel CG: slower) - tried once, and whatever happens to it is reported,
+            # never fatal: that path cannot be exercised with more than one rank before it meets a multi-GPU node.
+            skipped = "peer transport could not be set up here: " + str((child or {}).get("sharded_unavailable", "see the other ranks"))
+            if not share_gpu:
+                child2, err2, ok2, refused2 = sharded_attempt("rccl", 13, 420)
+                if ok2 and not refused2:
+                    child, err = child2, None
+                    skipped = None
+                else:
+                    child = None
+                    skipped += "; the RCCL transport was tried instead: " + json.dumps(err2 or {"error": "it failed on another rank or was refused as well"})
         if rank == 0:
             replicas = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak",
                         "note": "one independent %d^2 problem per GPU, no data-path collective (the run timed first)" % n}
-            if all_ok and child is not None and "sharded_unavailable" in child:
-                out["sharded_run"] = {"skipped": "peer transport could not be set up here: " + str(child["sharded_unavailable"])}
+            if all_ok and skipped is not None:
+                out["sharded_run"] = {"skipped": skipped}
                 out["replicas_only"] = True
             elif all_ok and child is not None:
                 for k in ("value", "ms_per_step", "scaling", "config", "roofline", "phases", "sharded"):

@@ -20,6 +20,7 @@
 // The iteration itself (order of updates, absolute ||r||_2 test after each half step, zero + one restart on failure,
 // NaN -> warning) is the reference's.
 #include "piso_common.h"
+#include "options.h"
 #include "slab_comm.h"
 
 namespace piso {
@@ -85,7 +86,9 @@ struct BiPeer {
   PeerView pv;
   unsigned seq;
   int* err;
-  int on;
+  int on;        // 0: one GPU.  1: peer transport - the sums cross the ranks inside the scalar kernel.  RCCL transport, two launches
+                 // around an all-reduce: 2 = write the rank's sums to `gsum` and stop, 3 = continue from the all-reduced `gsum`
+  double* gsum;  // [2 components][4 sums]
 };
 
 __device__ __forceinline__ bool is_nan(float v) { return v != v; }
@@ -504,14 +507,26 @@ __global__ __launch_bounds__(kBlock) void bi_scalar(BiArgs<T> a, int stage, BiPe
   __shared__ T smem[16];
   const int c = blockIdx.x;
   CompScalars<T> s = a.sc[c];
-  if (s.done) return;             // (the same decision on every rank: `done` follows from all-reduced sums)
+  if (s.done) {                   // (the same decision on every rank: `done` follows from all-reduced sums)
+    if (bp.on == 2 && threadIdx.x < 4) bp.gsum[c * 4 + threadIdx.x] = 0;
+    return;
+  }
   T q[4] = {0, 0, 0, 0};
+  if (bp.on == 3) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = (T)bp.gsum[c * 4 + k];
+  } else {
   for (int b = threadIdx.x; b < a.nparts; b += kBlock) {       // (four independent loads in flight per pass)
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] += a.parts[(c * 4 + k) * kBiParts + b];
   }
   block_sum<T, 4>(q, smem);
-  if (bp.on && threadIdx.x < 64) {
+  }
+  if (bp.on == 2) {
+    if (threadIdx.x < 4) bp.gsum[c * 4 + threadIdx.x] = (double)(threadIdx.x == 0 ? q[0] : (threadIdx.x == 1 ? q[1] : (threadIdx.x == 2 ? q[2] : q[3])));
+    return;
+  }
+  if (bp.on == 1 && threadIdx.x < 64) {
     // the distributed dot products: component c's four sums travel in words [8 c, 8 c + 8) of the all-reduce records
     const int lane = threadIdx.x;
     const int vq = (lane >> 1) & 3;
@@ -675,11 +690,12 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
 
   for (int c = 0; c < 2; ++c) { a.rb[c] = 0; a.re[c] = g.n[c]; a.bb[c] = 0; a.be[c] = g.nb[c]; }
   BiPeer bp;
-  bp.on = 0; bp.seq = 0; bp.err = nullptr;
+  bp.on = 0; bp.seq = 0; bp.err = nullptr; bp.gsum = nullptr;
   HaloMsg to_upper = {}, to_lower = {}, from_lower = {}, from_upper = {};
-  const bool slab = pc && pc->world > 1;
+  const bool slab = pc && (pc->world > 1 || opt(OPT_SLAB_FORCE) > 0);      // (slab_force: test knob - one rank, a ring with itself)
+  const bool rccl = pc && pc->transport == TRANSPORT_RCCL;                   // halo rows by send / recv, sums by all-reduce (slab_comm.h)
   if (pc) {
-    if (pc->transport != TRANSPORT_PEER || !pc->connected) { set_error_msg("piso_multi_bicgstab_ilu_slab: needs a connected peer communicator"); return PISO_ERR_INVALID_ARG; }
+    if (pc->transport == TRANSPORT_PEER && !pc->connected) { set_error_msg("piso_multi_bicgstab_ilu_slab: the peer communicator is not connected"); return PISO_ERR_INVALID_ARG; }
     const int world = pc->world, rank = pc->rank;
     // (a product is split into interior rows and kEdgeRows face rows at either end of the slab: thinner slabs would make the two
     // edge ranges overlap and count their rows twice in the dot products)
@@ -687,7 +703,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
       set_error_msg("piso_multi_bicgstab_ilu_slab: the slabs (ny / ranks cell rows) must be whole preconditioner bands of at least 4 rows");
       return PISO_ERR_INVALID_ARG;
     }
-    if ((size_t)(3 * nx + 1) > pc->row_cap) { set_error_msg("piso_multi_bicgstab_ilu_slab: communicator row_capacity < 3 nx + 1"); return PISO_ERR_INVALID_ARG; }
+    if (!rccl && (size_t)(3 * nx + 1) > pc->row_cap) { set_error_msg("piso_multi_bicgstab_ilu_slab: communicator row_capacity < 3 nx + 1"); return PISO_ERR_INVALID_ARG; }
     const int nyl = ny / world, jb = rank * nyl, jt = jb + nyl - 1;
     const bool last = rank == world - 1;
     a.rb[0] = jb * g.W[0]; a.re[0] = (jb + nyl) * g.W[0];
@@ -697,6 +713,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
     a.be[1] = last ? g.nb[1] : (jb + nyl) / g.R;
     bp.pv = make_view(pc, true);       // always a ring: without periodic y the wrap rows travel but no matrix entry reads them
     bp.err = pc->err; bp.on = slab ? 1 : 0;
+    if (rccl) { bp.gsum = ar.take<double>(8); if (!ar.ok()) { set_error_msg("piso_multi_bicgstab_ilu_slab: workspace too small"); return PISO_ERR_INVALID_ARG; } }
     // Edge rows of an SpMV input; they land at the same global offsets on the receiver.  Downwards go u[jb], v[jb] and v[jb + 1],
     // upwards u[jt], v[jt] - and, across the periodic seam, the duplicate row v[ny] as well: in A the row v[ny] reads v[1] and
     // v[0] reads v[ny - 1] (the wrap skips the duplicate face, central_difference_csr_op.cu.cc:259-264), in A^T it is v[1] that
@@ -709,8 +726,25 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
     from_upper = {2, {jb_up * g.W[0], g.n[0] + jb_up * g.W[1], 0}, {g.W[0], 2 * g.W[1], 0}};
   }
   auto next_seq = [&]() -> BiPeer { BiPeer b = bp; if (slab) b.seq = ++pc->seq_ar; return b; };
-  auto halo = [&](T* vec) {
-    if (slab) peer_exchange_segments<T><<<2, 256, 0, stream>>>(bp.pv, vec, to_upper, to_lower, from_lower, from_upper, ++pc->seq_ex, pc->err);
+  const HaloMsg msgs[4] = {to_upper, to_lower, from_lower, from_upper};
+  constexpr int kDtype = sizeof(T) == 8 ? 1 : 0;
+  auto exchange_on = [&](T* vec, hipStream_t st) -> int {
+    if (rccl) return comm_rccl_exchange_segments(pc, vec, kDtype, msgs, st);
+    peer_exchange_segments<T><<<2, 256, 0, st>>>(bp.pv, vec, to_upper, to_lower, from_lower, from_upper, ++pc->seq_ex, pc->err);
+    return PISO_OK;
+  };
+  auto halo = [&](T* vec) -> int { return slab ? exchange_on(vec, stream) : PISO_OK; };
+  // one stage of the scalar recurrences (peer transport / one GPU: one launch; RCCL: the ranks' sums, an all-reduce, the rest)
+  auto scalar = [&](int stage) -> int {
+    if (slab && rccl) {
+      BiPeer b = bp;
+      b.on = 2; bi_scalar<T><<<2, kBlock, 0, stream>>>(a, stage, b);
+      { const int rc = comm_rccl_allreduce_f64(pc, bp.gsum, 8, stream); if (rc != PISO_OK) return rc; }
+      b.on = 3; bi_scalar<T><<<2, kBlock, 0, stream>>>(a, stage, b);
+    } else {
+      bi_scalar<T><<<2, kBlock, 0, stream>>>(a, stage, next_seq());
+    }
+    return PISO_OK;
   };
   int dev_now = 0;
   if (slab) { PISO_HIP_CHECK(hipGetDevice(&dev_now)); if (dev_now < 0 || dev_now >= kMaxDevices) { set_error_msg("piso_multi_bicgstab_ilu_slab: device ordinal out of range"); return PISO_ERR_INVALID_ARG; } }
@@ -745,7 +779,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
     }
     PISO_HIP_CHECK(hipEventRecord(tl_side.ready, stream));                       // `in` is complete on the owned rows
     PISO_HIP_CHECK(hipStreamWaitEvent(tl_side.stream, tl_side.ready, 0));
-    peer_exchange_segments<T><<<2, 256, 0, tl_side.stream>>>(bp.pv, in, to_upper, to_lower, from_lower, from_upper, ++pc->seq_ex, pc->err);
+    { const int rc = exchange_on(in, tl_side.stream); if (rc != PISO_OK) return rc; }
     PISO_HIP_CHECK(hipEventRecord(tl_side.halo, tl_side.stream));
     if (which == 0) bi_spmv<T, 0><<<grid_vs, kBlock, 0, stream>>>(a, in, out, 1, 0);
     else bi_spmv<T, 1><<<grid_vs, kBlock, 0, stream>>>(a, in, out, 1, 0);
@@ -763,7 +797,8 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
 
   bi_init_scalars<T><<<1, 256, 0, stream>>>(a);
   bi_convert<T><<<grid_v, kBlock, 0, stream>>>(a, val, rowptr, col, x0, transpose ? 1 : 0);
-  if (slab) bi_flags_allreduce<T><<<1, 64, 0, stream>>>(a, next_seq());
+  if (slab && rccl) { const int rc = comm_rccl_allreduce_i32(pc, a.flags, 2, stream); if (rc != PISO_OK) return rc; }   // (sums: non-zero = set)
+  else if (slab) bi_flags_allreduce<T><<<1, 64, 0, stream>>>(a, next_seq());
   if (need <= 1) launch_factor<T, 1>(a, grid_b, stream);
   else if (need <= 2) launch_factor<T, 2>(a, grid_b, stream);
   else if (need <= 3) launch_factor<T, 3>(a, grid_b, stream);             // (W = nx + 1 with nx a power of two: 2^k / 256 + 1)
@@ -799,9 +834,9 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   bool pattern_checked = false;
   for (int restart = 0; restart < 2; ++restart) {
     // r = b - B x, rh = r, p = v = 0, ||r|| test, first rho / beta
-    halo(a.x);
+    { const int rc = halo(a.x); if (rc != PISO_OK) return rc; }
     bi_residual_init<T><<<grid_v, kBlock, 0, stream>>>(a);
-    bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_INIT, next_seq());
+    { const int rc = scalar(ST_INIT); if (rc != PISO_OK) return rc; }
     PISO_LAUNCH_CHECK();
     int it = 0, look = 2;
     bool all_done = false;
@@ -811,18 +846,18 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
       const int chunk = (max_it - it) < look ? (max_it - it) : look;
       if (it >= 4 && look < 16) look *= 2;
       for (int q = 0; q < chunk; ++q, ++it) {
-        if (it > 0) bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_RHO_BETA, next_seq());
+        if (it > 0) { const int rc = scalar(ST_RHO_BETA); if (rc != PISO_OK) return rc; }
         bi_update_p<T><<<grid_v, kBlock, 0, stream>>>(a);
         precond(a.p, a.ph);
         { const int rc = spmv(0, a.ph, a.v); if (rc != PISO_OK) return rc; }
-        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_ALPHA, next_seq());
+        { const int rc = scalar(ST_ALPHA); if (rc != PISO_OK) return rc; }
         bi_update_xr<T, 0><<<grid_v, kBlock, 0, stream>>>(a);
-        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_CHECK_S, next_seq());
+        { const int rc = scalar(ST_CHECK_S); if (rc != PISO_OK) return rc; }
         precond(a.r, a.sh);
         { const int rc = spmv(1, a.sh, a.t); if (rc != PISO_OK) return rc; }
-        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_OMEGA, next_seq());
+        { const int rc = scalar(ST_OMEGA); if (rc != PISO_OK) return rc; }
         bi_update_xr<T, 1><<<grid_v, kBlock, 0, stream>>>(a);
-        bi_scalar<T><<<2, kBlock, 0, stream>>>(a, ST_CHECK_R, next_seq());
+        { const int rc = scalar(ST_CHECK_R); if (rc != PISO_OK) return rc; }
       }
       PISO_LAUNCH_CHECK();
       { const int rc = fetch(); if (rc != PISO_OK) return rc; }
@@ -851,7 +886,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
     }
   }
   (void)failed_mask;
-  if (slab) {
+  if (slab && !rccl) {
     int herr = 0;
     peer_agree_on_error<><<<1, 64, 0, stream>>>(bp.pv, pc->err, ++pc->seq_ar);      // every rank returns the same status
     PISO_HIP_CHECK(hipMemcpyAsync(&herr, pc->err, sizeof(int), hipMemcpyDeviceToHost, stream));

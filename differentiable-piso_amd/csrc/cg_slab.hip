@@ -184,6 +184,32 @@ __global__ __launch_bounds__(kBlock) void peer_exchange_rows(PeerView pv, const 
   for (int i = threadIdx.x; i < nx; i += kBlock) halo[i] = __longlong_as_double((long long)peer_load(row + i));
 }
 
+int comm_rccl_exchange_segments(PisoComm* pc, void* vec, int dtype, const HaloMsg* m, hipStream_t s) {
+  if (!pc || pc->transport != TRANSPORT_RCCL || !pc->comm) { set_error_msg("comm_rccl_exchange_segments: not an RCCL communicator"); return PISO_ERR_INVALID_ARG; }
+  const int rank = pc->rank, world = pc->world;
+  const int lo = rank > 0 ? rank - 1 : world - 1, hi = rank < world - 1 ? rank + 1 : 0;          // always a ring (as the peer kernels)
+  const ncclDataType_t dt = dtype == 0 ? ncclFloat : (dtype == 1 ? ncclDouble : ncclInt32);
+  const size_t es = dtype == 1 ? 8 : 4;
+  char* base = static_cast<char*>(vec);
+  PISO_NCCL_CHECK(g_rccl.GroupStart());
+  for (int q = 0; q < m[0].count; ++q) PISO_NCCL_CHECK(g_rccl.Send(base + (size_t)m[0].off[q] * es, (size_t)m[0].len[q], dt, hi, pc->comm, s));
+  for (int q = 0; q < m[2].count; ++q) PISO_NCCL_CHECK(g_rccl.Recv(base + (size_t)m[2].off[q] * es, (size_t)m[2].len[q], dt, lo, pc->comm, s));
+  for (int q = 0; q < m[1].count; ++q) PISO_NCCL_CHECK(g_rccl.Send(base + (size_t)m[1].off[q] * es, (size_t)m[1].len[q], dt, lo, pc->comm, s));
+  for (int q = 0; q < m[3].count; ++q) PISO_NCCL_CHECK(g_rccl.Recv(base + (size_t)m[3].off[q] * es, (size_t)m[3].len[q], dt, hi, pc->comm, s));
+  PISO_NCCL_CHECK(g_rccl.GroupEnd());
+  return PISO_OK;
+}
+int comm_rccl_allreduce_f64(PisoComm* pc, double* buf, int count, hipStream_t s) {
+  if (!pc || pc->transport != TRANSPORT_RCCL || !pc->comm) { set_error_msg("comm_rccl_allreduce: not an RCCL communicator"); return PISO_ERR_INVALID_ARG; }
+  PISO_NCCL_CHECK(g_rccl.AllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, pc->comm, s));
+  return PISO_OK;
+}
+int comm_rccl_allreduce_i32(PisoComm* pc, int* buf, int count, hipStream_t s) {
+  if (!pc || pc->transport != TRANSPORT_RCCL || !pc->comm) { set_error_msg("comm_rccl_allreduce: not an RCCL communicator"); return PISO_ERR_INVALID_ARG; }
+  PISO_NCCL_CHECK(g_rccl.AllReduce(buf, buf, (size_t)count, ncclInt32, ncclSum, pc->comm, s));
+  return PISO_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ communication
 template <typename T>
 struct Comm {
@@ -687,8 +713,8 @@ int piso_comm_stats(void* comm, long long* out4) {      // (six values: see incl
 int piso_comm_exchange(void* comm, void* vec, int dtype, const int* msgs28, piso_stream_t stream_) {
   PisoComm* pc = static_cast<PisoComm*>(comm);
   if (!pc || !vec || !msgs28) { set_error_msg("piso_comm_exchange: invalid argument"); return PISO_ERR_INVALID_ARG; }
-  if (pc->world == 1) return PISO_OK;
-  if (pc->transport != TRANSPORT_PEER || !pc->connected) { set_error_msg("piso_comm_exchange: needs a connected peer communicator"); return PISO_ERR_INVALID_ARG; }
+  if (pc->world == 1 && opt(OPT_SLAB_FORCE) <= 0) return PISO_OK;        // (slab_force: test knob - a ring of one rank exchanges with itself)
+  if (pc->transport == TRANSPORT_PEER && !pc->connected) { set_error_msg("piso_comm_exchange: the peer communicator is not connected"); return PISO_ERR_INVALID_ARG; }
   HaloMsg m[4];
   for (int q = 0; q < 4; ++q) {
     m[q].count = msgs28[7 * q];
@@ -698,9 +724,11 @@ int piso_comm_exchange(void* comm, void* vec, int dtype, const int* msgs28, piso
       m[q].off[k] = msgs28[7 * q + 1 + k]; m[q].len[k] = msgs28[7 * q + 4 + k];
       if (k < m[q].count) { if (m[q].off[k] < 0 || m[q].len[k] < 0) { set_error_msg("piso_comm_exchange: negative segment"); return PISO_ERR_INVALID_ARG; } total += (size_t)m[q].len[k]; }
     }
-    if (total > pc->row_cap) { set_error_msg("piso_comm_exchange: message longer than the communicator's row_capacity"); return PISO_ERR_INVALID_ARG; }
+    if (pc->transport == TRANSPORT_PEER && total > pc->row_cap) { set_error_msg("piso_comm_exchange: message longer than the communicator's row_capacity"); return PISO_ERR_INVALID_ARG; }
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (dtype < 0 || dtype > 2) { set_error_msg("piso_comm_exchange: dtype must be 0 (float), 1 (double) or 2 (int32)"); return PISO_ERR_INVALID_ARG; }
+  if (pc->transport == TRANSPORT_RCCL) return comm_rccl_exchange_segments(pc, vec, dtype, m, stream);
   const PeerView pv = make_view(pc, true);
   const unsigned seq = ++pc->seq_ex;
   if (dtype == 0) peer_exchange_segments<float><<<2, 256, 0, stream>>>(pv, static_cast<float*>(vec), m[0], m[1], m[2], m[3], seq, pc->err);

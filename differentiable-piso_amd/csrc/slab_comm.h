@@ -24,6 +24,16 @@ struct PisoComm {
   int verify_failures = 0;            // ... and found wanting on some rank: restarted on the two-kernel iteration
 };
 
+// RCCL transport of what the peer kernels do through the mailboxes (defined in cg_slab.hip, where the RCCL entry points live):
+//   * the four halo messages of a globally indexed vector {to upper, to lower, from lower, from upper}: grouped send / recv of the
+//     segments, straight from / into the vector (no staging).  Sends and receives between one pair of ranks are matched in issue
+//     order, and with one or two ranks the lower and the upper neighbour are the same peer: every rank issues "to upper" before
+//     "to lower" and "from lower" before "from upper".  dtype: 0 float, 1 double, 2 int32;
+//   * in-place sum of `count` doubles / ints over the ranks.
+int comm_rccl_exchange_segments(PisoComm* pc, void* vec, int dtype, const HaloMsg* m4, hipStream_t stream);
+int comm_rccl_allreduce_f64(PisoComm* pc, double* buf, int count, hipStream_t stream);
+int comm_rccl_allreduce_i32(PisoComm* pc, int* buf, int count, hipStream_t stream);
+
 inline PeerView make_view(const PisoComm* pc, bool periodic_y) {
   PeerView v;
   for (int r = 0; r < kMaxRanks; ++r) v.mbox[r] = pc->mbox[r];

@@ -220,7 +220,7 @@ def gather_face_rows(comm, x, nx, ny):
 def multi_bicgstab_ilu_slab(comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn, gather=True):
     """piso_multi_bicgstab_ilu_slab_{f32,f64}: all arrays are the FULL ones on every rank; the rank solves its slab."""
     dt = values.dtype
-    assert dt in (torch.float32, torch.float64) and comm.transport == "peer"
+    assert dt in (torch.float32, torch.float64)      # (both transports: mailbox kernels, or RCCL send / recv + all-reduce)
     values, rhs, x0 = values.contiguous(), rhs.to(dt).contiguous(), x0.to(dt).contiguous()
     row_ptr, col_indices = row_ptr.contiguous(), col_indices.contiguous()
     x = torch.zeros_like(rhs)

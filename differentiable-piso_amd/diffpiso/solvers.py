@@ -84,7 +84,7 @@ class LinearSolverScipy(LinearSolver):
 
 def multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn, slab_comm=None):
     """One call of piso_multi_bicgstab_ilu_{f32,f64}. Returns (x, iterations[2]); sets warn[0] in place on NaN input.
-    slab_comm (distributed.SlabCommunicator, peer transport, more than one rank): the solve is cut into y-slabs over the ranks
+    slab_comm (distributed.SlabCommunicator, either transport, more than one rank): the solve is cut into y-slabs over the ranks
     (every rank passes the full arrays and works on its rows; dot products are all-reduced inside the scalar kernels, the edge
     rows of the SpMV inputs travel through the mailboxes) and every rank returns the full solution."""
     if slab_comm is not None and slab_comm.world > 1:
@@ -153,7 +153,7 @@ class LinearSolverCudaMultiBicgstabILU(LinearSolver):
         self.cast_to_double = cast_to_double
         self.accuracy = accuracy
         self.band_rows = band_rows
-        self.slab_comm = None        # distributed.SlabCommunicator (peer transport): cut every solve into y-slabs over the ranks
+        self.slab_comm = None        # distributed.SlabCommunicator: cut every solve into y-slabs over the ranks
         self.last_iterations = None
         self.last_adjoint_iterations = None
         self.stats = dict(solves=0, iterations=0, adjoint_solves=0, adjoint_iterations=0)   # cumulative (max over u, v per solve)

@@ -48,6 +48,7 @@ int piso_device_count(void);
 /* Tuning / test knobs (no counterpart in the reference).  Each knob `name` takes its default ONCE, at library load, from the
  * environment variable PISO_<NAME IN UPPER CASE>; -1 = not set (automatic).  Process-wide, not thread-safe against a
  * concurrent solve.  Names: cg_persist (0 forbid / 1 force the persistent CG kernel), cg_persist_r (2|4|16 rows per region),
+ * slab_force (1: a communicator of ONE rank still runs the slab code paths - a ring with itself; tests),
  * cg_segment (iterations per persistent launch),
  * cg_persist_timing, cg_rpw, cg_maxblocks, cg_nt, cg_no_compact, cg_no_recon, cg_no_sym, cg_verify (0: skip the true-residual
  * check of persistent solves; 2: test knob, treat it as failed), cg_pad (0: never run a small wall-bounded grid that the
@@ -241,7 +242,8 @@ int piso_leaky_relu_backward(const float* grad_out, const float* out, float* gra
  *  row_capacity = longest grid row (cells) the communicator will carry.  x_out_global must be NULL (gather the slabs yourself).
  *
  *  RCCL (piso_comm_unique_id / piso_comm_create): per iteration K1, a 3-double all-reduce, K2, a 3-double all-reduce and a
- *  one-row halo exchange of the residual -- stream-ordered RCCL calls, no host sync, two-kernel iteration only.  librccl is
+ *  one-row halo exchange of the residual -- stream-ordered RCCL calls, no host sync, two-kernel iteration only.  The same
+ *  communicator carries the slab BiCGStab and the halo messages of the sharded step (below).  librccl is
  *  dlopen'ed on first use; the 128-byte unique id is created on one rank and distributed by the caller.
  *
  *   laplace_local [ny_local*nx][5], divergence_local / x_out_local [ny_local*nx]: this rank's rows;
@@ -263,17 +265,21 @@ int piso_comm_stats(void* comm, long long* out6);
  * grid.  Process-wide (one process per GPU).  piso_get_row_window returns 1 if a window is set.
  * piso_comm_exchange fills halo rows: msgs28 = 4 x {count <= 3, off[3], len[3]} element segments of `vec` {sent to the upper
  * neighbour, sent to the lower, received from the lower, received from the upper} (ring neighbours); dtype 0 float, 1 double,
- * 2 int32; peer transport; a no-op on one rank.  piso_comm_check: has a wait on a peer given up (agreed over the ranks)? */
+ * 2 int32; a no-op on one rank.  Peer transport: one launch, the elements cross xGMI as 8-byte words written into the consumer's
+ * mailbox.  RCCL transport: grouped ncclSend / ncclRecv of the segments on the stream, straight from / into `vec`.
+ * piso_comm_check: has a wait on a peer given up (agreed over the ranks; peer transport - RCCL has no bounded waits)? */
 int piso_set_row_window(int row_begin, int row_end, int owns_last_face_row);
 int piso_get_row_window(int* row_begin, int* row_end, int* owns_last_face_row);
 int piso_comm_exchange(void* comm, void* vec, int dtype, const int* msgs28, piso_stream_t stream);
 int piso_comm_check(void* comm, piso_stream_t stream);
-/* Slab-decomposed ILU(0)-BiCGStab (peer transport): same arguments as piso_multi_bicgstab_ilu_*, all arrays FULL on every rank
+/* Slab-decomposed ILU(0)-BiCGStab (either transport): same arguments as piso_multi_bicgstab_ilu_*, all arrays FULL on every rank
  * (the assembly is cheap and replicated); the rank works on the face rows of its ny / world cell rows, which must be whole
  * preconditioner bands (ny / world a multiple of the band height: then the banded ILU(0) is the single-GPU one and the iterates
  * agree to summation order).  Per iteration: the five dot products are all-reduced INSIDE the one-block scalar kernels (tagged
  * words through the mailboxes), the inputs of the two SpMVs receive their neighbours' edge rows (u[j], v[j], v[j+1] downwards,
- * u[j], v[j] upwards, ring).  x_out is valid on the owned rows only.  The communicator's row_capacity must be >= 3 nx + 1. */
+ * u[j], v[j] upwards, ring).  x_out is valid on the owned rows only.  The communicator's row_capacity must be >= 3 nx + 1.
+ * RCCL transport (where the environment refuses hipIpc): every scalar stage is two launches around an 8-double ncclAllReduce, the
+ * edge rows travel by grouped ncclSend / ncclRecv on the side stream - stream-ordered, no host sync, same arithmetic. */
 int piso_multi_bicgstab_ilu_slab_f32(void* comm, const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* rhs,
                                      const float* x0, float* x_out, int nx, int ny, float tol, int max_it, int transpose,
                                      int band_rows, uint8_t* warning, int* iterations_out, void* workspace, size_t workspace_bytes,

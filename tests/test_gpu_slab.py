@@ -135,3 +135,64 @@ def test_peer_transport_one_rank_persistent_slab_kernel(n, walls, piso_option):
         assert itc == itd == 45 and float((xc - xd).abs().max()) == 0.0
     finally:
         comm.close()
+
+
+@pytest.mark.parametrize("transport", ["peer", "rccl"])
+@pytest.mark.parametrize("name", ["periodic", "xper_ywall", "spatial_ml"])
+def test_slab_bicgstab_and_halo_messages_ring_of_one(transport, name, piso_option):
+    """Both transports of the slab-decomposed ILU(0)-BiCGStab and of the sharded step's halo messages with ONE rank forced into
+    the slab code paths (option slab_force: a ring of one rank - its lower and upper neighbour are itself): the peer transport's
+    mailbox kernels, and the RCCL transport's grouped send / recv of the message segments and its scalar stages split around an
+    all-reduce (RCCL refuses two ranks on one device, so this is how that path is exercised before it meets a multi-GPU node;
+    tests/test_gpu_multiproc.py runs the peer transport over real processes)."""
+    import ctypes as C
+    from oracle import piso_ref as R
+    from tests.cases import make_case, oracle_setup
+    from diffpiso import _native as N
+    from diffpiso.distributed import SlabCommunicator, multi_bicgstab_ilu_slab
+    from diffpiso.solvers import multi_bicgstab_ilu_native
+    nx, ny = 48, 64
+    c = make_case(name, ny, nx, seed=7, variable_viscosity=(name == "spatial_ml"))
+    s = oracle_setup(c)
+    beta = float(np.prod(c["dx_yx"])) / c["dt"]
+    val, rp, col, _, _ = R.advection_matrix(s, c["vel"], beta)
+    rhs = np.random.default_rng(11).standard_normal(s.n_u + s.n_v).astype(np.float32)
+    x0 = R.flatten_staggered(c["vel"], True)
+    comm = SlabCommunicator(rank=0, world=1, transport=transport, row_capacity=3 * nx + 8)
+    try:
+        piso_option("slab_force", 1)
+        # ---- the four halo messages of a globally indexed vector: in a ring of one, what I send up comes back from below
+        for code, dt in ((0, torch.float32), (1, torch.float64), (2, torch.int32)):
+            v = torch.arange(100, device="cuda").to(dt)
+            msgs = (C.c_int * 28)(2, 10, 30, 0, 5, 2, 0,      # to upper: [10, 15) and [30, 32)
+                                  1, 20, 0, 0, 5, 0, 0,       # to lower: [20, 25)
+                                  2, 40, 60, 0, 5, 2, 0,      # from lower (= my "to upper")
+                                  1, 50, 0, 0, 5, 0, 0)       # from upper (= my "to lower")
+            N.check(N.lib.piso_comm_exchange(comm.handle, N.ptr(v), code, msgs, N.stream_ptr()), "piso_comm_exchange")
+            N.check(N.lib.piso_comm_check(comm.handle, N.stream_ptr()), "piso_comm_check")
+            ref = torch.arange(100, device="cuda").to(dt)
+            ref[40:45] = ref[10:15]; ref[60:62] = ref[30:32]; ref[50:55] = ref[20:25]
+            assert torch.equal(v, ref), (transport, dt)
+        # ---- the solver: same iteration counts and the same answer as the one-GPU driver
+        for tdt, tol, bound in ((torch.float64, 1e-9, 1e-9), (torch.float32, 1e-5, 2e-5)):
+            for transpose in (False, True):
+                args = (dev(-val, tdt), dev(rp), dev(col), dev(rhs, tdt), dev(x0, tdt), nx, ny, tol, 200, transpose, 8)
+                w1 = torch.zeros(1, dtype=torch.uint8, device="cuda")
+                w2 = torch.zeros(1, dtype=torch.uint8, device="cuda")
+                x1, it1 = multi_bicgstab_ilu_native(*args, w1)
+                x2, it2 = multi_bicgstab_ilu_slab(comm, *args, w2, gather=False)
+                assert int(w1.item()) == 0 and int(w2.item()) == 0
+                if tdt == torch.float64:
+                    assert tuple(it1) == tuple(it2), (it1, it2)
+                else:
+                    assert max(abs(a - b) for a, b in zip(it1, it2)) <= 1, (it1, it2)
+                assert float((x1 - x2).norm() / x1.norm()) <= bound, (transport, tdt, transpose)
+        # a NaN in the right-hand side raises the warning through the all-reduced flags as well
+        bad = rhs.copy()
+        bad[3] = np.nan
+        w = torch.zeros(1, dtype=torch.uint8, device="cuda")
+        multi_bicgstab_ilu_slab(comm, dev(-val, torch.float32), dev(rp), dev(col), dev(bad), dev(x0), nx, ny, 1e-5, 20, False, 8, w, gather=False)
+        assert int(w.item()) == 1
+    finally:
+        piso_option("slab_force", 0)
+        comm.close()
