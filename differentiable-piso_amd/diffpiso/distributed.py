@@ -91,11 +91,15 @@ class SlabCommunicator(object):
             mine = (C.c_ubyte * 64)()
             failure = None
             with torch.cuda.device(device):
-                status = N.lib.piso_comm_peer_create(rank, world, int(row_capacity), C.byref(handle), mine)
-                if status != 0:
-                    failure = "piso_comm_peer_create failed with status %d: %s" % (status, N.lib.piso_last_error_string().decode())
+                import os
+                if os.environ.get("PISO_TEST_REFUSE_PEER", "0") == "1" and rank == world - 1:      # test knob: ONE rank's environment says no
+                    failure = "piso_comm_peer_create: refused (PISO_TEST_REFUSE_PEER)"
                 else:
-                    self.handle = handle
+                    status = N.lib.piso_comm_peer_create(rank, world, int(row_capacity), C.byref(handle), mine)
+                    if status != 0:
+                        failure = "piso_comm_peer_create failed with status %d: %s" % (status, N.lib.piso_last_error_string().decode())
+                    else:
+                        self.handle = handle
                 everybody = all_gather_bytes(bytes(mine) + bytes([1 if failure else 0]), rank, world, device)
                 failed = [r for r in range(world) if everybody[65 * r + 64]]
                 if not failed:

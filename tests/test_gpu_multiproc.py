@@ -134,6 +134,16 @@ def _bench(env_extra, args, nproc):
     return json.loads(lines[-1])
 
 
+def test_bench_reports_a_refused_peer_transport_instead_of_failing():
+    """Where the environment refuses the peer transport (here: a test knob makes ONE rank's hipIpc set-up fail) the set-up fails as a
+    collective on every rank, the sharded child says so and leaves with code 0, and bench.py prints the replicas line with
+    `sharded_run.skipped` - exit code 0, nothing hangs.  (With one GPU per rank the RCCL transport would be tried next.)"""
+    d = _bench({"PISO_BENCH_SHARE_GPU": "1", "PISO_BENCH_SLAB_CHECK": "0", "PISO_TEST_REFUSE_PEER": "1"},
+               ["--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "256", "--no-cpu-baseline", "--no-extras", "--max-iterations", "100"], 2)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d.get("replicas_only") is True
+    assert "could not be set up on rank(s) [1]" in d["sharded_run"]["skipped"] and "sharded" not in d
+
+
 def test_decomposed_step_two_ranks_matches_one_gpu():
     """The whole benchmark step (forward PISO steps + reverse sweep) with BOTH linear solvers cut into two slabs over two
     processes -- pressure CG through the persistent slab kernel, ILU(0)-BiCGStab with all-reduced dot products, forward and
