@@ -989,9 +989,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   }
   if (kPersistDiag && c.timing && threadIdx.x == 0) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) c.timing[q * gridDim.x + blockIdx.x] += tacc[q];
+    for (int q = 0; q < 5; ++q) c.timing[q * nslots + slot] += tacc[q];            // (XCD-local mode: the group's ranks, not the launch's blocks)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) c.timing[(5 + q) * gridDim.x + blockIdx.x] += tsub[q];
+    for (int q = 0; q < 4; ++q) c.timing[(5 + q) * nslots + slot] += tsub[q];
   }
   // ---- the last U's sum r and count are only known per workgroup: one more exchange (once per segment)
   T tOut[3] = {rz_next, sumr, cnt_last};
