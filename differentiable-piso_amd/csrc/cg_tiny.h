@@ -251,7 +251,8 @@ __device__ __forceinline__ void cols_block_sum8(T (&v)[8], double* red /* [64] *
 template <typename T, bool PERX, bool FULL>
 __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __restrict__ b, T* __restrict__ x_out, int nx, int ny, int per_y,
                                            float accuracy_f, int total, int reset, int rank_deficient, CgState* state_out, int* iterations_dev,
-                                           T (*halo)[kTinyThreads / 64][64], double* red, T* bbuf, T* xbuf) {
+                                           T (*halo)[kTinyThreads / 64][64], T (*zhalo)[2][kTinyThreads / 64][64], double (*red2)[64],
+                                           T* bbuf, T* xbuf) {
   constexpr int C = kColsRows;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j0 = wave * C;
@@ -278,20 +279,21 @@ __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __r
       dsum[0] += absval(row[2]);
     }
   }
-  cols_block_sum8<T>(dsum, red);
+  int par = 0;                                              // parity of the block sums: `red2` and `zhalo` are double-buffered by it
+  cols_block_sum8<T>(dsum, red2[par]); par ^= 1;
   const T sc_c = rank_deficient ? dsum[0] * (T)(.1 / (double)n) : (T)0;            // cg_init
   const T accuracy = (T)accuracy_f;
-  // z' = L v for my cells, v in registers (phantom rows and lanes hold 0)
-  auto apply = [&](const T (&v)[C]) __attribute__((always_inline)) {
-    // my first and last rows to the waves below and above, theirs to me
-    if (rows > 0) {
-      halo[0][wave][lane] = v[0];
-#pragma unroll
-      for (int m = 0; m < C; ++m) if (m == rows - 1) halo[1][wave][lane] = v[m];
-    }
-    __syncthreads();
-    const T hS = srcS >= 0 ? halo[1][srcS][lane] : (T)0;
-    const T hN = srcN >= 0 ? halo[0][srcN][lane] : (T)0;
+  // RING COPIES (as cg_persist1.h keeps them around a region): r and p of the row below my first row and of the row above my last
+  // one live in MY registers too and are advanced with the same arithmetic as their owner advances them - p = r + beta p needs
+  // nothing from outside, r -= alpha (z' + c sum p) needs the neighbour's z' of that row, which travels through LDS in the shadow of
+  // the block reduction's barrier.  The stencil's south / north inputs of my edge rows are then registers: ONE barrier per
+  // iteration instead of two (the rows of a fresh vector - x at a residual reset - still go through `halo` with a barrier).
+  const bool hasS = srcS >= 0, hasN = srcN >= 0;            // (wave-uniform)
+  const int jS = j0 > 0 ? j0 - 1 : ny - 1, jN = j0 + rows < ny ? j0 + rows : 0;      // the ring rows' global row numbers (if they exist)
+  T rS = (hasS && col) ? bbuf[jS * 64 + lane] : (T)0, rN = (hasN && col) ? bbuf[jN * 64 + lane] : (T)0;   // r0 = b (written before the barrier above)
+  T pS = 0, pN = 0;
+  // z' = L v for my cells, v in registers (phantom rows and lanes hold 0), hS / hN: v on the rows below / above mine
+  auto stencil = [&](const T (&v)[C], T hS, T hN) __attribute__((always_inline)) {
 #pragma unroll
     for (int mm = 0; mm < C; ++mm) {
       const int m = mm < C - 2 ? mm + 1 : (mm == C - 2 ? 0 : C - 1);     // the rows next to the halo rows last: their LDS reads are in flight
@@ -307,6 +309,14 @@ __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __r
       acc = fma(cN[m], vN, acc);
       z[m] = acc;
       __builtin_amdgcn_sched_barrier(0);                     // (one row at a time: the shifted copies of ALL rows at once do not fit the registers)
+    }
+  };
+  // my first and last rows of z' for the waves below and above (read behind the next block sum's barrier)
+  auto publish_z_edges = [&]() __attribute__((always_inline)) {
+    if (rows > 0) {
+      zhalo[par][0][wave][lane] = z[0];
+#pragma unroll
+      for (int m = 0; m < C; ++m) if (m == rows - 1) zhalo[par][1][wave][lane] = z[m];
     }
   };
   CgState st = {0, 0, 0, 0};
@@ -338,8 +348,19 @@ __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __r
       T sx[8] = {0, (T)lc, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int m = 0; m < C; ++m) { p[m] = xmine[m * 64]; sx[0] += p[m]; }     // (p = r + 0 p follows)
-      apply(p);
-      cols_block_sum8<T>(sx, red);
+      {   // the rows of x next to mine through LDS (a barrier of its own: once per reset)
+        if (rows > 0) {
+          halo[0][wave][lane] = p[0];
+#pragma unroll
+          for (int m = 0; m < C; ++m) if (m == rows - 1) halo[1][wave][lane] = p[m];
+        }
+        __syncthreads();
+        const T xS = hasS ? halo[1][srcS][lane] : (T)0, xN = hasN ? halo[0][srcN][lane] : (T)0;
+        stencil(p, xS, xN);
+      }
+      publish_z_edges();                                    // (L x of the ring rows: their restarted residual)
+      const int parx = par;
+      cols_block_sum8<T>(sx, red2[par]); par ^= 1;
       if (test_now) {
         const int exceeded = sx[1] > 0;
         if (st.flag && !exceeded) { st.done = 1; st.iterations = k; }
@@ -358,13 +379,18 @@ __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __r
           lr += r[m]; lc += (absval(r[m]) < accuracy) ? 0 : 1;
         }
       }
+      rS = (hasS && col) ? bbuf[jS * 64 + lane] - (zhalo[parx][1][srcS < 0 ? 0 : srcS][lane] + vsx) : (T)0;
+      rN = (hasN && col) ? bbuf[jN * 64 + lane] - (zhalo[parx][0][srcN < 0 ? 0 : srcN][lane] + vsx) : (T)0;
     }
 #pragma unroll
     for (int m = 0; m < C; ++m) p[m] = fma(beta, p[m], r[m]);       // p = r + beta p (k = 0, resets: beta = 0; phantoms stay 0)
+    pS = is_reset ? rS : fma(beta, pS, rS);                 // (a reset: p = r - the copies held x's neighbours never, but 0 x inf is not 0)
+    pN = is_reset ? rN : fma(beta, pN, rN);
     // ---- D(k): z' = L p and the sums
     TINY_TICK(0)                                            // loop top, p update
-    apply(p);
-    TINY_TICK(1)                                            // halo exchange + stencil
+    stencil(p, pS, pN);
+    publish_z_edges();
+    TINY_TICK(1)                                            // stencil
     T sD[8] = {0, 0, 0, 0, 0, 0, lr, (T)lc};
 #pragma unroll
     for (int m = 0; m < C; ++m) {
@@ -376,7 +402,9 @@ __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __r
       sD[5] += z[m];
     }
     TINY_TICK(2)                                            // partial sums
-    cols_block_sum8<T>(sD, red);
+    const int parz = par;
+    cols_block_sum8<T>(sD, red2[par]); par ^= 1;
+    const T zS = hasS ? zhalo[parz][1][srcS][lane] : (T)0, zN = hasN ? zhalo[parz][0][srcN][lane] : (T)0;   // (consumed behind alpha)
     TINY_TICK(3)                                            // block reduction
     // ---- the stopping test of iteration k (:312-335), behind the reduction but before anything moves
     if (!tested && test_now) {
@@ -394,8 +422,10 @@ __device__ __forceinline__ void cols_solve(const T* __restrict__ L, const T* __r
     sumr = sumr - alpha * (sD[5] + ncells * vs);
     beta_next = -(rz_next + vs * sumr) / pz;                // beta of iteration k + 1: unguarded, as coded (:351-352); same divisor as alpha
     TINY_TICK(4)                                            // test, alpha, beta
-    // ---- U(k): x += alpha p; r -= alpha (z' + c sum p)
+    // ---- U(k): x += alpha p; r -= alpha (z' + c sum p) on my cells and on the ring
     lr = 0; lc = 0;
+    rS = fma(-alpha, zS + ((hasS && col) ? vs : (T)0), rS);
+    rN = fma(-alpha, zN + ((hasN && col) ? vs : (T)0), rN);
     if (count_now) {             // (the count is only read by the test of iteration k + 1)
 #pragma unroll
       for (int m = 0; m < C; ++m) {
@@ -432,16 +462,18 @@ template <typename T, bool PERX>
 __global__ __launch_bounds__(kTinyThreads) void cg_tiny_cols(const T* __restrict__ L, const T* __restrict__ b, T* __restrict__ x_out, int nx, int ny,
                                                               int per_y, float accuracy_f, int total, int reset, int rank_deficient,
                                                               CgState* state_out, int* iterations_dev) {
-  // One buffer each: a halo exchange and a block sum always alternate, and each has a barrier between its writes and its reads -
-  // whoever writes a buffer again has passed the other one's barrier, which every wave reaches only after its reads of this one.
+  // `red2` and `zhalo` are double-buffered by the parity of the block sums: ONE barrier per iteration sits between a buffer's writes
+  // and its reads, and whoever writes the same parity again has passed the NEXT barrier, which every wave reaches only after its
+  // reads of this one.  `halo` (the rows of x at a residual reset) has a barrier of its own and is used once per reset.
   __shared__ T halo[2][kTinyThreads / 64][64];              // [0]: a wave's first row, [1]: its last row
-  __shared__ double red[64];
+  __shared__ T zhalo[2][2][kTinyThreads / 64][64];          // [parity][0: first row / 1: last row][wave][lane]: z' of the waves' edge rows
+  __shared__ double red[2][64];
   __shared__ T bbuf[kColsMaxNy * 64], xbuf[kColsMaxNy * 64];
   const int wave = threadIdx.x >> 6;
   if (PISO_TINY_COLS_FULL && nx == 64 && (wave + 1) * kColsRows <= ny)
-    cols_solve<T, PERX, true>(L, b, x_out, nx, ny, per_y, accuracy_f, total, reset, rank_deficient, state_out, iterations_dev, halo, red, bbuf, xbuf);
+    cols_solve<T, PERX, true>(L, b, x_out, nx, ny, per_y, accuracy_f, total, reset, rank_deficient, state_out, iterations_dev, halo, zhalo, red, bbuf, xbuf);
   else
-    cols_solve<T, PERX, false>(L, b, x_out, nx, ny, per_y, accuracy_f, total, reset, rank_deficient, state_out, iterations_dev, halo, red, bbuf, xbuf);
+    cols_solve<T, PERX, false>(L, b, x_out, nx, ny, per_y, accuracy_f, total, reset, rank_deficient, state_out, iterations_dev, halo, zhalo, red, bbuf, xbuf);
 }
 
 
