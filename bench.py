@@ -868,6 +868,17 @@ def other_configs(device):
     """Driver-visible timings of the smaller BASELINE.json configurations (extra keys, not the headline)."""
     import torch
     res = {}
+    try:                                                                # config 1: lid-driven cavity 64 x 64, Re 400, as the reference's script steps it
+        sys.path.insert(0, os.path.join(ROOT, "examples"))
+        import lid_driven_cavity_2d as ldc
+        ldc.run(n=64, reynolds=400, dt=0.01, steps=20, out=None, verbose=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ldc.run(n=64, reynolds=400, dt=0.01, steps=100, out=None, verbose=False)
+        torch.cuda.synchronize()
+        res["config1_lid_driven_cavity_64x64_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / 100
+    except Exception as e:
+        res["config1_lid_driven_cavity_64x64_ms_per_step"] = "failed: %r" % (e,)
     P2 = build_problem(256, device, 1e-8, 10000, 1000)                  # config 2: 256^2 periodic, forward only, DNS tolerance
     with torch.no_grad():
         run_unrolled(P2, 2, backward=False)
