@@ -283,6 +283,39 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_reduce_kernel(const float* 
   if (wave == 0 && k < n) dw[k] = ((sm[threadIdx.x] + sm[64 + threadIdx.x]) + sm[128 + threadIdx.x]) + sm[192 + threadIdx.x];
 }
 
+// The same for cout % 4 == 0 (every layer but the last): a lane owns FOUR consecutive output channels of one (tap, ci) - 16-byte
+// loads, four independent sums per lane, eight bands in flight per wave; a workgroup owns 256 weights.  Same summation order per
+// weight as the scalar kernel (bands b = wave, wave + 4, ... inside a wave, then the four waves in order).
+__global__ __launch_bounds__(kBlock) void conv_wgrad_reduce4_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblocks, int taps,
+                                                                     int cinp16, int coutp, int cin, int cout) {
+  __shared__ f32x4 sm[kBlock];
+  const int n4 = taps * cin * (cout >> 2);
+  const int k4 = blockIdx.x * 64 + (threadIdx.x & 63), wave = threadIdx.x >> 6;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (k4 < n4) {
+    const int cq = cout >> 2;
+    const int co = (k4 % cq) * 4, ci = (k4 / cq) % cin, tap = k4 / (cq * cin);
+    const size_t src = ((size_t)tap * cinp16 + ci) * coutp + co, stride = (size_t)taps * cinp16 * coutp;
+    int b = wave;
+    for (; b + 28 < nblocks; b += 32) {                      // eight bands of this wave at once: the loads are independent, the sums ordered
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(part + (size_t)(b + 4 * u) * stride + src);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; b < nblocks; b += 4) s += *reinterpret_cast<const f32x4*>(part + (size_t)b * stride + src);
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (wave == 0 && k4 < n4) *reinterpret_cast<f32x4*>(dw + (size_t)k4 * 4) = ((sm[threadIdx.x] + sm[64 + threadIdx.x]) + sm[128 + threadIdx.x]) + sm[192 + threadIdx.x];
+}
+static void launch_wgrad_reduce(const float* part, float* dw, int nblocks, int taps, int cinp16, int coutp, int cin, int cout, hipStream_t stream) {
+  const int n = taps * cin * cout;
+  if (cout % 4 == 0 && coutp % 4 == 0) conv_wgrad_reduce4_kernel<<<(n / 4 + 63) / 64, kBlock, 0, stream>>>(part, dw, nblocks, taps, cinp16, coutp, cin, cout);
+  else conv_wgrad_reduce_kernel<<<(n + 63) / 64, kBlock, 0, stream>>>(part, dw, nblocks, taps, cinp16, coutp, cin, cout);
+}
+
 // row bands = partial sums per weight: what the second stage has to add (and re-read).  256: one output row per band at config 4's
 // size - with bands of two rows the 9 x 126 waves of the 64 -> 64 layer left SIMDs with two waves next to SIMDs with one
 constexpr int kWgradMaxBlocks = 256;
@@ -305,8 +338,7 @@ static int launch_wgrad(const ConvGeom& g, const float* in, const float* gout, f
   constexpr int groups = (items + 4 * IPW - 1) / (4 * IPW);
   conv_wgrad_kernel<KS, MTI, NT, IPW, PACK4><<<dim3(nblocks, groups), kBlock, 0, stream>>>(g, in, gout, part, rows_per_block);
   PISO_LAUNCH_CHECK();
-  const int n = KS * KS * g.cin * g.cout;
-  conv_wgrad_reduce_kernel<<<(n + 63) / 64, kBlock, 0, stream>>>(part, dw, nblocks, KS * KS, 16 * MTI, 16 * NT, g.cin, g.cout);
+  launch_wgrad_reduce(part, dw, nblocks, KS * KS, 16 * MTI, 16 * NT, g.cin, g.cout, stream);
   PISO_LAUNCH_CHECK();
   return PISO_OK;
 }
@@ -402,7 +434,7 @@ int piso_conv2d_wgrad(const float* in, const float* grad_out, float* dw, int H, 
     const int rows_per_block = (g.Ho + kWgradMaxBlocks - 1) / kWgradMaxBlocks, nblocks = (g.Ho + rows_per_block - 1) / rows_per_block;
     conv_wgrad64_kernel<3><<<dim3(nblocks, 3), 192, 0, stream>>>(g, in, grad_out, part, rows_per_block);
     PISO_LAUNCH_CHECK();
-    conv_wgrad_reduce_kernel<<<(ks * ks * 4096 + 63) / 64, kBlock, 0, stream>>>(part, dw, nblocks, ks * ks, 64, 64, 64, 64);
+    launch_wgrad_reduce(part, dw, nblocks, ks * ks, 64, 64, 64, 64, stream);
     PISO_LAUNCH_CHECK();
     return PISO_OK;
   }

@@ -18,6 +18,8 @@ for flag in (True, False):
         net(x).sum().backward()
         torch.cuda.synchronize()
     print("==== MFMA" if flag else "==== torch / MIOpen")
-    rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:16]
+    allrows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+    print("     GPU time of all %d kernel kinds, %d launches: %.1f us" % (len(allrows), sum(e.count for e in allrows), sum(e.device_time_total for e in allrows)))
+    rows = allrows[:16]
     for e in rows:
         print("%9.1f us  x%-3d %s" % (e.device_time_total, e.count, e.key[:110]))
