@@ -50,6 +50,25 @@ def test_deferred_iteration_count_behaves_like_an_int():
     assert len(many._pending) <= 65 and many == 400
 
 
+def test_device_constant_uploads_once_and_notices_in_place_changes():
+    """grids.device_constant: a small numpy array handed over again every step (the reference's scripts pass sim.dirichlet_values to every
+    piso_step) is converted once and found again by identity + checksum; an array modified in place is converted again."""
+    from diffpiso.grids import device_constant
+    a = np.arange(12, dtype=np.float64).reshape(1, 3, 4, 1)
+    t1 = device_constant(a, dtype=torch.float32, device="cpu")
+    t2 = device_constant(a, dtype=torch.float32, device="cpu")
+    assert t1 is t2 and t1.dtype == torch.float32 and np.array_equal(t1.numpy(), a.astype(np.float32))
+    a[0, 1, 2, 0] = -5.0
+    t3 = device_constant(a, dtype=torch.float32, device="cpu")
+    assert t3 is not t1 and float(t3[0, 1, 2, 0]) == -5.0
+    b = a.copy()
+    assert device_constant(b, dtype=torch.float32, device="cpu") is not t3          # another array object: its own entry
+    big = np.zeros(1 << 19, dtype=np.float32)                                        # 2 MiB: too large for the cache, plain conversion
+    assert device_constant(big, device="cpu") is not device_constant(big, device="cpu")
+    t = torch.ones(3)
+    assert device_constant(t, device="cpu") is t                                     # tensors pass through
+
+
 def test_workspace_queries_and_nnz_closed_form():
     assert N.lib.piso_cg_workspace_bytes(2048, 2048, 8) > 9 * 2048 * 2048 * 8
     assert N.lib.piso_bicgstab_workspace_bytes(64, 64, 4) > 18 * (65 * 64 + 64 * 65) * 4
