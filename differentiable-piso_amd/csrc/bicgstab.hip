@@ -838,13 +838,13 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
     bi_residual_init<T><<<grid_v, kBlock, 0, stream>>>(a);
     { const int rc = scalar(ST_INIT); if (rc != PISO_OK) return rc; }
     PISO_LAUNCH_CHECK();
-    int it = 0, look = 2;
+    int it = 0, look = ntot < 32768 ? 1 : 2;                 // (tiny systems - the lid-driven cavity converges in one iteration: a second one is 13 launches for nothing)
     bool all_done = false;
     while (it < max_it && !all_done) {
       // iterations between host looks: 2, 2, 4, 8, 16, 16, ... - a solve of 3 iterations (the 2048^2 benchmark) still stops at
       // once, a solve of 100 (lid-driven cavity) synchronises 9 times instead of 50; launches of a converged component return early
       const int chunk = (max_it - it) < look ? (max_it - it) : look;
-      if (it >= 4 && look < 16) look *= 2;
+      if (look < 2) look = 2; else if (it >= 4 && look < 16) look *= 2;
       for (int q = 0; q < chunk; ++q, ++it) {
         if (it > 0) { const int rc = scalar(ST_RHO_BETA); if (rc != PISO_OK) return rc; }
         bi_update_p<T><<<grid_v, kBlock, 0, stream>>>(a);
