@@ -16,6 +16,7 @@
 //                  N = co, K = pixels; every workgroup reduces a band of rows into its own partial, a second kernel adds the
 //                  partials in a fixed order (deterministic, no atomics)
 #include "piso_common.h"
+#include "options.h"
 
 namespace piso {
 
@@ -126,6 +127,106 @@ __global__ __launch_bounds__(kBlock) void conv_forward_kernel(ConvGeom g, const 
       for (int r = 0; r < 4; ++r) {
         const int x = x0 + 16 * m + ak * 4 + r;
         if (x < g.Wo && co < g.cout) {
+          float v = acc[m][n][r];
+          if (LEAKY_OUT) v = v > 0.f ? v : kLeakySlope * v;
+          out[((size_t)y * g.Wo + x) * g.cout + co] = v;
+        }
+      }
+    }
+}
+
+// The same convolution with its operands STAGED THROUGH LDS (CINP >= 16, KS >= 3).  The kernel above reads, per K-block of a wave,
+// 4 KB of A and NT KB of B from L2 for 16 MT NT MFMAs: at config 4's size that is ~10 TB/s of L2 traffic chip-wide - the 64 -> 64
+// layers ran at 53 % of the fp32 MFMA peak, bound by it.  Here the four waves of a workgroup (four consecutive tiles of 64 pixels,
+// possibly of two output rows) walk the same stages = (tap row ky, block of 16 input channels) in lock step:
+//   * B of the stage - the weights of all KS tap columns, KS NT KB - is loaded ONCE per workgroup and shared by the four waves;
+//   * A of the stage - the 64 + KS - 1 input pixels a wave's tile touches over the KS tap columns, 16 channels - is loaded ONCE per
+//     wave; the tap columns read it at pixel offsets 0 .. KS - 1 (a lane's 16-byte reads cover a contiguous KB: conflict-free).
+// L2 traffic per stage and wave: (64 + KS - 1) 64 B + KS NT KB / 4 instead of KS (4 + NT) KB (3 x 3, 64 -> 64: 7.2 instead of 24 KB).
+// Double-buffered: the next stage's operands travel from L2 into registers while the MFMAs of this stage run, are written to the
+// other LDS buffer behind them, one barrier per stage.  Same K order per output as the kernel above: the same bits.
+template <int KS, int CINP, int NT, bool LEAKY_OUT>
+__global__ __launch_bounds__(kBlock) void conv_forward_lds_kernel(ConvGeom g, const float* __restrict__ in, const float* __restrict__ w,
+                                                                   float* __restrict__ out) {
+  static_assert(CINP >= 16 && KS >= 3, "tap columns share the staged pixels; channels in blocks of 16");
+  constexpr int MT = 4, COUTP = 16 * NT, CB = CINP / 16;
+  constexpr int P = 16 * MT + KS - 1;                       // pixels of a wave's A segment
+  constexpr int NA = (P * 4 + 63) / 64;                     // 16-byte loads per lane for it
+  constexpr int BV = KS * NT * 64;                          // 16-byte words of a stage's B
+  constexpr int NB = (BV + kBlock - 1) / kBlock;            // ... per thread
+  __shared__ f32x4 As[2][kBlock / 64][P * 4];
+  __shared__ f32x4 Bs[2][BV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_x = (g.Wo + 16 * MT - 1) / (16 * MT);
+  const int tile = blockIdx.x * (kBlock / 64) + wave;
+  const bool active = tile < tiles_x * g.Ho;                // (a wave without a tile still helps with B and takes part in the barriers)
+  const int y = active ? tile / tiles_x : 0, x0 = active ? (tile - y * tiles_x) * 16 * MT : 0;
+  const int ai = lane & 15, ak = lane >> 4;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // every wave walks ALL tap rows (the weights of a stage are the same for every output row); a tap row outside the image - zero
+  // padding above / below - contributes nothing: its pixels are staged as zeros (wave-uniform: no loads are issued)
+  constexpr int nstages = KS * CB;
+  f32x4 ra[NA], rb[NB];
+  auto fetch = [&](int s) __attribute__((always_inline)) {        // stage s: global -> registers
+    const int ky = s / CB, cb = s - (s / CB) * CB;
+    const int yy = y + ky - g.pad;
+    const bool row_ok = active && yy >= 0 && yy < g.H;
+#pragma unroll
+    for (int t = 0; t < NA; ++t) {
+      const int i = lane + 64 * t, px = i >> 2, grp = i & 3;
+      const int xx = x0 + px - g.pad;
+      ra[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (row_ok && i < P * 4 && xx >= 0 && xx < g.W) ra[t] = *reinterpret_cast<const f32x4*>(in + ((size_t)yy * g.W + xx) * g.cin + 16 * cb + 4 * grp);
+    }
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int i = threadIdx.x + kBlock * t;                // [kx][ak][COUTP] 16-byte words: NT x 64 per tap column
+      const int kx = i / (NT * 64), r = i - kx * (NT * 64);
+      rb[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < BV) rb[t] = *reinterpret_cast<const f32x4*>(w + ((((size_t)(ky * KS + kx) * CB + cb) * 4) * COUTP + r) * 4);
+    }
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {      // registers -> LDS
+#pragma unroll
+    for (int t = 0; t < NA; ++t) { const int i = lane + 64 * t; if (i < P * 4) As[buf][wave][i] = ra[t]; }
+#pragma unroll
+    for (int t = 0; t < NB; ++t) { const int i = threadIdx.x + kBlock * t; if (i < BV) Bs[buf][i] = rb[t]; }
+  };
+  fetch(0); stash(0);
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nstages) fetch(s + 1);
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+      f32x4 a[MT], b[NT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = As[buf][wave][(16 * m + ai + kx) * 4 + ak];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[n] = Bs[buf][(kx * 4 + ak) * COUTP + 16 * n + ai];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][j], b[n][j], acc[m][n], 0, 0, 0);
+    }
+    if (s + 1 < nstages) stash(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int co = 16 * n + ai;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int x = x0 + 16 * m + ak * 4 + r;
+        if (active && x < g.Wo && co < g.cout) {
           float v = acc[m][n][r];
           if (LEAKY_OUT) v = v > 0.f ? v : kLeakySlope * v;
           out[((size_t)y * g.Wo + x) * g.cout + co] = v;
@@ -322,6 +423,15 @@ constexpr int kWgradMaxBlocks = 256;
 
 template <int KS, int CINP, int NT>
 static int launch_forward(const ConvGeom& g, const float* in, const float* w, float* out, int leaky, hipStream_t stream) {
+  if constexpr (CINP >= 16 && KS >= 3) {
+    if (opt(OPT_CONV_LDS) != 0) {                            // operands staged through LDS (option conv_lds 0: the direct kernel)
+      const int tiles2 = ((g.Wo + 63) / 64) * g.Ho, grid2 = (tiles2 + kBlock / 64 - 1) / (kBlock / 64);
+      if (leaky) conv_forward_lds_kernel<KS, CINP, NT, true><<<grid2, kBlock, 0, stream>>>(g, in, w, out);
+      else conv_forward_lds_kernel<KS, CINP, NT, false><<<grid2, kBlock, 0, stream>>>(g, in, w, out);
+      PISO_LAUNCH_CHECK();
+      return PISO_OK;
+    }
+  }
   const int tiles = ((g.Wo + 63) / 64) * g.Ho;
   const int grid = (tiles + kBlock / 64 - 1) / (kBlock / 64);
   if (leaky) conv_forward_kernel<KS, CINP, NT, true><<<grid, kBlock, 0, stream>>>(g, in, w, out);
