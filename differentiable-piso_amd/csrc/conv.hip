@@ -366,6 +366,85 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad64_kernel(ConvGeom g, const 
       for (int r = 0; r < 4; ++r) mine[(size_t)(4 * (ak * 4 + r) + m) * 64 + 4 * ai + n] = acc[m][n][r];
 }
 
+// The same with the operands staged through LDS: the three waves of a workgroup are the three tap COLUMNS of one tap row - they read the
+// same row of `gout` and the same row of `in`, shifted by one pixel each.  Chunks of 32 output pixels: gout[32][64] and in[34][64]
+// are loaded once per workgroup (L2 traffic / 3), double-buffered, one barrier per chunk (32 pixels: 32 MFMAs per wave).  Same pixel order
+// per weight as the kernel above: the same bits.
+template <int KS>
+__global__ __launch_bounds__(64 * KS) void conv_wgrad64_lds_kernel(ConvGeom g, const float* __restrict__ in, const float* __restrict__ gout,
+                                                                    float* __restrict__ part, int rows_per_block) {
+  constexpr int TAPS = KS * KS, CH = 32, PA = CH + KS - 1, NTH = 64 * KS;   // (chunks of 32 pixels: 33 KB of LDS, four workgroups = 12 waves per CU)
+  constexpr int NLB = (CH * 16 + NTH - 1) / NTH, NLA = (PA * 16 + NTH - 1) / NTH;       // 16-byte loads per thread: gout chunk, in chunk
+  __shared__ f32x4 Gs[2][CH * 16], Is[2][PA * 16];          // [pixel][16 groups of 4 channels]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ai = lane & 15, ak = lane >> 4;
+  const int ky = blockIdx.y, kx = wave;                      // (one workgroup = one tap row, one wave per tap column)
+  const int tap = ky * KS + kx;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int y_begin = blockIdx.x * rows_per_block, y_end = min(y_begin + rows_per_block, g.Ho);
+  const int chunks_x = (g.Wo + CH - 1) / CH;
+  f32x4 rg[NLB], ri[NLA];
+  auto fetch = [&](int y, int c) __attribute__((always_inline)) {
+    const int yy = y + ky - g.pad, x0 = c * CH;
+    const bool row_ok = yy >= 0 && yy < g.H;
+#pragma unroll
+    for (int t = 0; t < NLB; ++t) {
+      const int i = threadIdx.x + NTH * t, px = i >> 4, grp = i & 15, x = x0 + px;
+      rg[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < CH * 16 && x < g.Wo) rg[t] = *reinterpret_cast<const f32x4*>(gout + ((size_t)y * g.Wo + x) * 64 + 4 * grp);
+    }
+#pragma unroll
+    for (int t = 0; t < NLA; ++t) {
+      const int i = threadIdx.x + NTH * t, px = i >> 4, grp = i & 15, xx = x0 + px - g.pad;
+      ri[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (row_ok && i < PA * 16 && xx >= 0 && xx < g.W) ri[t] = *reinterpret_cast<const f32x4*>(in + ((size_t)yy * g.W + xx) * 64 + 4 * grp);
+    }
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NLB; ++t) { const int i = threadIdx.x + NTH * t; if (i < CH * 16) Gs[buf][i] = rg[t]; }
+#pragma unroll
+    for (int t = 0; t < NLA; ++t) { const int i = threadIdx.x + NTH * t; if (i < PA * 16) Is[buf][i] = ri[t]; }
+  };
+  const int nsteps = (y_end - y_begin) * chunks_x;
+  if (nsteps > 0) { fetch(y_begin, 0); stash(0); }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) { const int yn = y_begin + (s + 1) / chunks_x, cn = (s + 1) - ((s + 1) / chunks_x) * chunks_x; fetch(yn, cn); }
+    // (a tap row outside the image was staged as zeros: its products vanish; same as the `continue` of the direct kernel)
+#pragma unroll
+    for (int q = 0; q < CH / 16; ++q) {                     // 16 pixels = 4 x (4 pixels, one per lane group ak)
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int px = 16 * q + 4 * u + ak;
+        b[u] = Gs[buf][px * 16 + ai];
+        a[u] = Is[buf][(px + kx) * 16 + ai];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][m], b[u][n], acc[m][n], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) stash(buf ^ 1);
+    __syncthreads();
+  }
+  float* mine = part + ((size_t)blockIdx.x * TAPS + tap) * 64 * 64;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(size_t)(4 * (ak * 4 + r) + m) * 64 + 4 * ai + n] = acc[m][n][r];
+}
+
 // dW[tap][ci][co] (true sizes) = sum of the band partials in a fixed order: a workgroup owns 64 weights, its 4 waves add the
 // bands b = wave, wave + 4, ... and the four wave sums are added in wave order
 __global__ __launch_bounds__(kBlock) void conv_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nblocks, int taps,
@@ -542,7 +621,8 @@ int piso_conv2d_wgrad(const float* in, const float* grad_out, float* dw, int H, 
   if (cin == 64 && cout == 64 && ks == 3) {      // (measured: 304 us against 329 us for the generic kernel at 250 x 876; the 1 x 1
     // layer has a single tap, i.e. one busy wave per workgroup here, and stays on the generic kernel: 130 us against 219 us)
     const int rows_per_block = (g.Ho + kWgradMaxBlocks - 1) / kWgradMaxBlocks, nblocks = (g.Ho + rows_per_block - 1) / rows_per_block;
-    conv_wgrad64_kernel<3><<<dim3(nblocks, 3), 192, 0, stream>>>(g, in, grad_out, part, rows_per_block);
+    if (opt(OPT_CONV_LDS) != 0) conv_wgrad64_lds_kernel<3><<<dim3(nblocks, 3), 192, 0, stream>>>(g, in, grad_out, part, rows_per_block);
+    else conv_wgrad64_kernel<3><<<dim3(nblocks, 3), 192, 0, stream>>>(g, in, grad_out, part, rows_per_block);
     PISO_LAUNCH_CHECK();
     launch_wgrad_reduce(part, dw, nblocks, ks * ks, 64, 64, 64, 64, stream);
     PISO_LAUNCH_CHECK();
