@@ -171,7 +171,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   // ---- persistent segments (cg_persist1.h): applicable when every wave's region fits on chip
   int persist_R = 0, persist_NQ = 0, persist_grid = 0;
   PersistCtl pc;
-  pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr; pc.epoch0 = 0; pc.xcd = nullptr; pc.local_n = 0;
+  pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr; pc.epoch0 = 0; pc.xcd = nullptr; pc.local_n = 0; pc.waves = kPersistWaves;
   bool xcd_local = false;                                // the solve runs on the workgroups of one XCD (cg_persist1<..., LOCAL>)
   constexpr int kXcdCus = 32;                            // CUs of one MI355X XCD
   const int force = opt(OPT_CG_PERSIST), force_r = opt(OPT_CG_PERSIST_R);   // -1: automatic
@@ -194,6 +194,14 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     // (measured at 2048^2-class work per workgroup: regions of 4 rows to make a 64-workgroup grid fit one XCD lose more in the row
     // loops than the shorter exchange wins - 512^2: 6.2 against 4.5 us per iteration; 256^2, 16 workgroups either way: 3.8 against 4.3)
     persist_R = shape.R; persist_NQ = shape.NQ; persist_grid = shape.grid; pc.nreg = shape.nreg; pc.ntx = shape.ntx;
+    // Small regions: ONE wave with work per SIMD instead of two (waves 4-7 of a workgroup own nothing), twice the workgroups, wherever
+    // the doubled grid still fits the chip: a wave then never waits at the exchange's first barrier for the wave it shares a SIMD
+    // with (0.6 us of a ~4 us iteration).  Measured: 256^2 3.80 -> 3.47 us per iteration, 512^2 4.45 -> 4.08, 1024 x 256 4.48 -> 4.08,
+    // 512 x 256 4.07 -> 3.96 (64 workgroups chip-wide instead of 32 on one XCD), 1024 x 512 unchanged.  Option cg_persist_half 0: never.
+    if ((persist_R == 2 || persist_R == 4) && persist_NQ == 2 && 2 * persist_grid <= cus && opt(OPT_CG_PERSIST_HALF) != 0) {
+      pc.waves = kPersistWaves / 2;
+      persist_grid = (shape.nreg + pc.waves * persist_NQ - 1) / (pc.waves * persist_NQ);
+    }
     xcd_local = local_ok && (persist_R == 2 || persist_R == 4) && persist_grid <= kXcdCus;
     if (persist_R && n < 16384 && force != 1 && !a.nx_true) persist_R = 0;    // tiny grids: two-kernel path (a padded grid is here BECAUSE it is small)
   }

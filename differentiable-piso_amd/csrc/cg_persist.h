@@ -28,6 +28,7 @@ struct PersistCtl {
   // XCD-local mode of cg_persist1 (small grids: all participating workgroups on ONE XCD, exchanges through that XCD's L2):
   int* xcd;             // [0..7] arrivals per XCD, [8] 1 + the XCD that runs the solve (0: not decided yet); zeroed before every launch
   int local_n;          // workgroups that take part (the launch has 8 x local_n: some XCD is dealt at least local_n of them)
+  int waves;            // waves of a workgroup that own regions: 8, or 4 (one per SIMD: nobody waits for a SIMD's other wave; small grids)
 };
 #ifdef PISO_PERSIST_DIAG
 constexpr bool kPersistDiag = true;     // per-phase clocks of wave 0 (PISO_CG_PERSIST_TIMING=1); costs a few registers

@@ -463,8 +463,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   bool has[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int reg = (wg * kPersistWaves + wave) * NQ + q;
-    has[q] = reg < c.nreg;
+    const int reg = (wg * c.waves + wave) * NQ + q;
+    has[q] = wave < c.waves && reg < c.nreg;
     const int ty = has[q] ? reg / c.ntx : 0;
     tx0[q] = has[q] ? reg - ty * c.ntx : 0;
     j0[q] = ty * R;

@@ -353,7 +353,7 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
   // cg_persist1<..., SLAB>; every rank takes the same decision (same shape, same options, failures are all-reduced)
   PersistShape shape;
   PersistCtl pc;
-  pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr; pc.epoch0 = 0;
+  pc.rec = nullptr; pc.err = nullptr; pc.nreg = 0; pc.ntx = 0; pc.timing = nullptr; pc.epoch0 = 0; pc.xcd = nullptr; pc.local_n = 0; pc.waves = kPersistWaves;
   SlabCtl sl;
   constexpr bool kCanSym = RECON && sizeof(CT) == 4;
   if (sizeof(T) == 8 && V == 16 / (int)sizeof(T) && allow_persist && comm.peer() && nloc == 1 && opt(OPT_CG_PERSIST) != 0 &&
