@@ -316,6 +316,110 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(ConvGeom g, const fl
   }
 }
 
+// The generic weight gradient with its operands staged through LDS (cin, cout multiples of 4).  The kernel above issues one 4-byte
+// load with its own bounds checks per operand element - U (IPW + NT) load instructions and ~8 VALU instructions each per 4 U IPW NT
+// MFMAs: the address arithmetic costs as much as the matrix cores.  Here the four waves of a workgroup - the items (tap, 16-channel
+// tile of ci) of one group - share a staged chunk of 32 output pixels: gout[32][COUTP] and in[KS rows][32 + KS - 1][CINP16], zero where
+// the image ends, loaded with 16-byte accesses once per workgroup, double-buffered, one barrier per chunk.  The inner loop reads
+// LDS at addresses that need no checks.  Same pixel order per weight: the same bits.
+template <int KS, int MTI, int NT, int IPW>
+__global__ __launch_bounds__(kBlock) void conv_wgrad_lds_kernel(ConvGeom g, const float* __restrict__ in, const float* __restrict__ gout,
+                                                                 float* __restrict__ part, int rows_per_block) {
+  constexpr int TAPS = KS * KS, ITEMS = TAPS * MTI, CH = 32, PA = CH + KS - 1;
+  constexpr int CINP16 = 16 * MTI, COUTP = 16 * NT;
+  constexpr int GV = CH * COUTP / 4, IV = KS * PA * CINP16 / 4;            // 16-byte words of a staged chunk
+  constexpr int NG = (GV + kBlock - 1) / kBlock, NI = (IV + kBlock - 1) / kBlock;
+  __shared__ f32x4 Gs[2][GV], Is[2][IV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ai = lane & 15, ak = lane >> 4;
+  const int item0 = (blockIdx.y * 4 + wave) * IPW;
+  f32x4 acc[IPW][NT];
+#pragma unroll
+  for (int t = 0; t < IPW; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int aoff[IPW];                                            // float offset of (ky, kx, ci tile) inside a staged `in` chunk, + my ci
+#pragma unroll
+  for (int t = 0; t < IPW; ++t) {
+    const int item = item0 + t < ITEMS ? item0 + t : ITEMS - 1;     // (a duplicate of the last item: computed, never stored)
+    const int tap = item / MTI, ky = tap / KS, kx = tap - ky * KS;
+    aoff[t] = (ky * PA + kx) * CINP16 + 16 * (item - tap * MTI) + ai;
+  }
+  const int y_begin = blockIdx.x * rows_per_block, y_end = min(y_begin + rows_per_block, g.Ho);
+  const int chunks_x = (g.Wo + CH - 1) / CH, nsteps = (y_end - y_begin) * chunks_x;
+  f32x4 rg[NG], ri[NI];
+  auto fetch = [&](int s) __attribute__((always_inline)) {
+    const int y = y_begin + s / chunks_x, x0 = (s - (s / chunks_x) * chunks_x) * CH;
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+      const int i = threadIdx.x + kBlock * t, px = i / (COUTP / 4), c4 = (i - px * (COUTP / 4)) * 4, x = x0 + px;
+      rg[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < GV && x < g.Wo && c4 < g.cout) rg[t] = *reinterpret_cast<const f32x4*>(gout + ((size_t)y * g.Wo + x) * g.cout + c4);
+    }
+#pragma unroll
+    for (int t = 0; t < NI; ++t) {
+      const int i = threadIdx.x + kBlock * t;
+      const int c4 = (i % (CINP16 / 4)) * 4, rest = i / (CINP16 / 4), px = rest % PA, ky = rest / PA;
+      const int yy = y + ky - g.pad, xx = x0 + px - g.pad;
+      ri[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // (a pixel of `in` beyond the output row's last pixel + KS - 1 is never paired with a non-zero gout: the chunk's own bound suffices)
+      if (i < IV && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W && c4 < g.cin) ri[t] = *reinterpret_cast<const f32x4*>(in + ((size_t)yy * g.W + xx) * g.cin + c4);
+    }
+  };
+  auto stash = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < NG; ++t) { const int i = threadIdx.x + kBlock * t; if (i < GV) Gs[buf][i] = rg[t]; }
+#pragma unroll
+    for (int t = 0; t < NI; ++t) { const int i = threadIdx.x + kBlock * t; if (i < IV) Is[buf][i] = ri[t]; }
+  };
+  if (nsteps > 0) { fetch(0); stash(0); }
+  __syncthreads();
+  const bool working = item0 < ITEMS;                       // (a wave without items still loads its share and takes part in the barriers)
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) fetch(s + 1);
+    if (working) {
+      const float* gs = reinterpret_cast<const float*>(Gs[buf]);
+      const float* is = reinterpret_cast<const float*>(Is[buf]);
+#pragma unroll
+      for (int q = 0; q < CH / 16; ++q) {
+        float a[4][IPW], b[4][NT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int px = 16 * q + 4 * u + ak;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b[u][n] = gs[px * COUTP + 16 * n + ai];
+#pragma unroll
+          for (int t = 0; t < IPW; ++t) a[u][t] = is[px * CINP16 + aoff[t]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < IPW; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], b[u][n], acc[t][n], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nsteps) stash(buf ^ 1);
+    __syncthreads();
+  }
+  if (!working) return;
+  float* mine = part + (size_t)blockIdx.x * TAPS * CINP16 * COUTP;
+#pragma unroll
+  for (int t = 0; t < IPW; ++t) {
+    const int item = item0 + t;
+    if (item >= ITEMS) break;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ak * 4 + r, co = 16 * n + ai;
+        const int tap = item / MTI, m = item - tap * MTI;
+        mine[((size_t)tap * CINP16 + 16 * m + row) * COUTP + co] = acc[t][n][r];
+      }
+  }
+}
+
 // Weight gradient of the 64 -> 64 channel layers: M and N are PERMUTED (tile m, row i <-> channel 4 i + m; tile n, column j <->
 // channel 4 j + n) so that a lane's operand for all four tiles is ONE float4 of its pixel (channels [4 (lane & 15), +4)):
 // one 16-byte load of `in`, one of `gout` per 4 pixels and 16 MFMAs.  A wave owns one tap and all 4 x 4 tiles.
@@ -525,7 +629,14 @@ static int launch_wgrad(const ConvGeom& g, const float* in, const float* gout, f
   const int nblocks = (g.Ho + rows_per_block - 1) / rows_per_block;
   constexpr int items = PACK4 ? KS * ((KS + 3) / 4) : KS * KS * MTI;
   constexpr int groups = (items + 4 * IPW - 1) / (4 * IPW);
-  conv_wgrad_kernel<KS, MTI, NT, IPW, PACK4><<<dim3(nblocks, groups), kBlock, 0, stream>>>(g, in, gout, part, rows_per_block);
+  bool staged = false;
+  if constexpr (!PACK4) {
+    if (opt(OPT_CONV_LDS) != 0 && g.cin % 4 == 0 && g.cout % 4 == 0) {
+      conv_wgrad_lds_kernel<KS, MTI, NT, IPW><<<dim3(nblocks, groups), kBlock, 0, stream>>>(g, in, gout, part, rows_per_block);
+      staged = true;
+    }
+  }
+  if (!staged) conv_wgrad_kernel<KS, MTI, NT, IPW, PACK4><<<dim3(nblocks, groups), kBlock, 0, stream>>>(g, in, gout, part, rows_per_block);
   PISO_LAUNCH_CHECK();
   launch_wgrad_reduce(part, dw, nblocks, KS * KS, 16 * MTI, 16 * NT, g.cin, g.cout, stream);
   PISO_LAUNCH_CHECK();
