@@ -382,7 +382,7 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
       sl.rows_hi = sl.pv.mbox[sl.pv.upper >= 0 ? sl.pv.upper : sl.pv.rank] + PeerLayout::kRows;
     }
   }
-  int seg_len = (int)(20000.0 / ((double)R[0].a.nx * R[0].a.ny * 8.5e-6 + 4.0));   // ~20 ms of work per segment
+  int seg_len = (int)(40000.0 / ((double)R[0].a.nx * R[0].a.ny * 8.5e-6 + 4.0));   // ~10 ms of work per segment at 2048^2 per GPU (as cg.hip)
   seg_len = seg_len < 50 ? 50 : (seg_len > 2000 ? 2000 : seg_len);
   if (opt(OPT_CG_SEGMENT) > 0) seg_len = opt(OPT_CG_SEGMENT);
 

@@ -127,6 +127,16 @@ def _bench(env_extra, args, nproc):
     else:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
+    if p.returncode != 0 and nproc > 1 and "piso_comm_peer" not in p.stderr:
+        # one retry on a fresh port: eight processes on one GPU right behind another multi-process test have failed in the launcher once
+        # (seen once in ~20 runs of the suite); a failure of the code under test fails again
+        print("first attempt failed (code %d), stderr tail:\n%s" % (p.returncode, p.stderr[-1500:]))
+        s2 = socket.socket()
+        s2.bind(("127.0.0.1", 0))
+        port2 = s2.getsockname()[1]
+        s2.close()
+        cmd = [str(port2) if c == str(port) else c for c in cmd]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     if p.returncode != 0 and ("piso_comm_peer_create" in p.stderr or "piso_comm_peer_connect" in p.stderr):
         pytest.skip("peer transport unavailable here")
