@@ -329,7 +329,11 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
           return cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out,
                                          kernel_ms_out, stream, false);
         }
-        if (prof) { float t = 0; PISO_HIP_CHECK(hipEventElapsedTime(&t, seg_ev[0], seg_ev[1])); seg_ms += t; seg_iters += ke - k; ++seg_launches; }
+        if (prof) {
+          // (a solve that converges inside the launch leaves it there: the iterations it RAN count, not the segment's length)
+          const int ran = tl_poll.pinned[0].done ? (tl_poll.pinned[0].iterations - k > 0 ? tl_poll.pinned[0].iterations - k : 0) : ke - k;
+          float t = 0; PISO_HIP_CHECK(hipEventElapsedTime(&t, seg_ev[0], seg_ev[1])); seg_ms += t; seg_iters += ran < ke - k ? ran : ke - k; ++seg_launches;
+        }
         if (tl_poll.pinned[0].done) { finished = true; stop_it = tl_poll.pinned[0].iterations; }
         ++segments_run;
         k_last = ke - 1;
