@@ -3,14 +3,15 @@
 // a block reduction, and the residual resets of the reference's default residual_reset = 10 happen in the same launch.
 //
 // Why: on such a grid an iteration of the chip-wide paths is nothing but latency - two dependent launches (~13 us) or one grid
-// exchange (~3.6 us even with all workgroups on one XCD) for 4 160 cells of arithmetic; here it is ~1 us.
+// exchange (~3.5 us even with all workgroups on one XCD) for 4 160 cells of arithmetic; here it is ~2 us
+// (cg_tiny_cols below, the lid-driven cavity's shape) to ~4 us (cg_tiny, any shape).
 //
 // Same iteration and the same control flow as cg_k1 / cg_k2 driven by cg_run (cg_kernels.h, cg.hip), i.e. as
 // pressure_solve_op.cu.cc:257-357: x0 = 0, r0 = b, the rank-1 shift c sum(p) with c = 0.1 mean|diag| (:161-190, :277-286), the
 // stopping test of iteration k - 1 evaluated at the top of iteration k for k % 5 == 0 with the device-flag semantics (:312-335),
 // beta unguarded (:351-352), alpha guarded (:301-302), restart r = b - (L x + c sum x), p = r when (k + 1) % reset == 0 (:260-274).
-// The matrix is taken as given ([N][5] = -y, -x, diag, +x, +y, any values): the coefficients of a thread's cells live in its
-// registers, r and x too, the direction in LDS (the stencil reads its neighbours there).  Summation order inside a cell as calcZ_v4
+// The matrix is taken as given ([N][5] = -y, -x, diag, +x, +y, any values): the coefficients of a thread's cells, its part of the
+// direction and z' live in its registers; r, x, b and the direction (the stencil reads its neighbours there) in LDS.  Summation order inside a cell as calcZ_v4
 // (:81-90): S, W, C, E, N with explicit fma.
 #pragma once
 #include "cg_kernels.h"
@@ -201,11 +202,11 @@ __global__ __launch_bounds__(kTinyThreads) void cg_tiny(const T* __restrict__ L,
 }
 
 // ---- the same solve with a COLUMN layout: lane = x (nx <= 64), wave w owns the rows [9 w, 9 w + 9) (ny <= 72: the lid-driven
-// cavity is 64 x 65).  p, r, x, b, z' and the five coefficients of a thread's nine vertically adjacent cells all live in
-// registers; the south / north neighbours of the direction are the thread's own registers (the rows next to another wave's rows
-// travel through LDS: two rows per wave and iteration), west / east come from the neighbouring lanes through the DPP wavefront
-// shifts.  LDS traffic per iteration: 2 row writes + 2 row reads per wave and one line of wave sums (cg_tiny: ~90 accesses per
-// thread).  The block reduction is the exchange of cg_persist1.h in small: reduce-scatter butterfly of the eight partial sums
+// cavity is 64 x 65).  p, r, z' and the five coefficients of a thread's nine vertically adjacent cells live in registers (x and b in
+// LDS, off the dependent chain); the south / north neighbours of the direction are the thread's own registers - for a wave's edge
+// rows: RING COPIES of the neighbouring wave's row, advanced with the owner's arithmetic (see cols_solve) - west / east come from
+// the neighbouring lanes through the DPP wavefront shifts.  LDS traffic per iteration: x read + write, 2 z' row writes + 2 reads
+// per wave and one line of wave sums (cg_tiny: ~90 accesses per thread); ONE barrier per iteration.  The block reduction is the exchange of cg_persist1.h in small: reduce-scatter butterfly of the eight partial sums
 // inside a wave (lane l ends with value l & 7), one LDS line [8 values][8 waves], ONE barrier, one LDS read per lane and a
 // three-step tree over the waves - every wave computes the same bits.
 // PERX (periodic x) needs nx == 64: the wavefront ROTATES are the wrap-around.
