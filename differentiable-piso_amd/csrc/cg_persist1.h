@@ -26,6 +26,7 @@
 // summation orders); converged answers and the stopping cadence are the reference's.  A segment starts from and ends in the
 // global-memory state of the two-kernel path, exactly like cg_persist.
 #pragma once
+#include <cstddef>
 #include <type_traits>
 
 #include "cg_persist.h"
@@ -42,6 +43,15 @@ namespace piso {
 //     GPUs' records in rank order (bitwise the same totals on every GPU, so every GPU takes the same decisions);
 //   * N of the slab's last row comes from the N array (its S twin lives on the neighbour), sums of the previous K2 from a.gB.
 struct NoSlab {};
+#ifndef PISO_X1
+#define PISO_X1 0
+#endif
+#ifndef PISO_X2
+#define PISO_X2 0
+#endif
+#ifndef PISO_X3
+#define PISO_X3 0
+#endif
 // region shape of the persistent kernels for an nx x ny grid (V cells per lane, `cus` compute units): one region of 16 rows per
 // wave has the smallest halo overhead and is taken when it keeps at least 3/4 of the waves busy (or when forced); else two
 // regions of 2 / 4 rows per wave (two regions of 8 rows do not fit the registers: such shapes - ny a multiple of 8 but not of 16 on
@@ -75,6 +85,21 @@ struct SlabCtl {
   double ncells;           // cells of the GLOBAL grid
   char *rows_own, *rows_lo, *rows_hi;   // the row areas (PeerLayout::kRows) of my mailbox and of the lower / upper neighbour's
 };
+// A kernel argument read AGAIN from the kernarg segment (scalar loads through a pointer the optimiser cannot see through).  The
+// row loops of the persistent kernels are bound by VALU issue and short of scalar registers: whatever only the rare paths need -
+// the mailbox addresses of the two edge waves of a slab, the pointers of the exit block - is fetched where it is used instead of
+// living in SGPRs across the loop (a spilled SGPR comes back through v_readlane, a VALU slot; an s_load costs none).
+// Persist1Kargs mirrors the argument list of cg_persist1 (arguments are laid out like the members of a struct); the slab kernel
+// compares one reloaded field with the argument itself at entry and fails the launch if the layouts ever disagree.
+template <typename T, typename SL>
+struct Persist1Kargs { CgArgs<T> a; PersistCtl c; int k_begin, k_end, sv, pend; SL sl; };
+template <typename F>
+__device__ __forceinline__ F karg(unsigned off) {
+  typedef __attribute__((address_space(4))) const char kchar;
+  kchar* kp = (kchar*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  return *(const __attribute__((address_space(4))) F*)(kp + off);
+}
 
 // coefficient rows in flight per wave (A/B builds: -DPISO_PERSIST1_DEPTH=n + scripts/build_variant.py / scripts/ab.sh).  Round 3, 16-row
 // regions at 2048^2, with the back-and-forth row order (kZigZag): 3 rows 12.5 us, 4 rows 11.8 us, 5 rows 11.5 us per iteration,
@@ -99,10 +124,16 @@ struct SlabCtl {
 #define PISO_PERSIST1_ASMCNT_SLAB 1
 #endif
 #ifndef PISO_PERSIST1_LEAN_SLAB
-#define PISO_PERSIST1_LEAN_SLAB 0
+#define PISO_PERSIST1_LEAN_SLAB 1
 #endif
 #ifndef PISO_PERSIST1_ZIGZAG_SLAB
-#define PISO_PERSIST1_ZIGZAG_SLAB 0          // (the slab variant has no registers for the rows held across the turn: 17.2 vs 18.1 us)
+#define PISO_PERSIST1_ZIGZAG_SLAB 1          // (round 3: off - the slab variant had no registers for the rows held across the turn)
+#endif
+#ifndef PISO_PERSIST1_RING_SLAB
+#define PISO_PERSIST1_RING_SLAB 1            // ring values through LDS broadcast reads in the slab variant as well
+#endif
+#ifndef PISO_PERSIST1_DEEP_SLAB
+#define PISO_PERSIST1_DEEP_SLAB 1            // the five-row coefficient pipeline in the slab variant as well
 #endif
 #ifndef PISO_PERSIST1_PREFETCH_BEHIND_DRAIN
 #define PISO_PERSIST1_PREFETCH_BEHIND_DRAIN 0    // (measured: no gain - the first barrier of the exchange waits for the slowest wave, not for the drain)
@@ -289,30 +320,40 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
 // before they published their local records, and workgroup 0 saw all of those before it wrote this one.
 constexpr int kX1SmX = 16;                        // LDS words of the second level: 8 totals, 1 flag
 template <typename T>
-__device__ __forceinline__ bool xgpu_exchange8(const PeerView& pv, T (&v)[kX1Values], unsigned epoch, T* smx2) {
+__device__ __forceinline__ bool xgpu_exchange8(unsigned sl_off, T (&v)[kX1Values], unsigned epoch, T* smx2) {
+  // (sl_off: where the SlabCtl sits in the kernarg segment - mailbox addresses, rank and world are fetched here, by wave 0 only,
+  // instead of occupying ~24 SGPRs across the row loops of every wave)
   T* smx = smx2 + (epoch & 1) * kX1SmX;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bool good = true;
   if (wave == 0) {
+    constexpr unsigned pv_off = (unsigned)offsetof(SlabCtl, pv);
+    const int world = karg<int>(sl_off + pv_off + (unsigned)offsetof(PeerView, world));
+    const int rank = karg<int>(sl_off + pv_off + (unsigned)offsetof(PeerView, rank));
     if (blockIdx.x == 0 && lane < kPeerRecWords) {
       double mine = 0;
+      int sel = lane >> 1;
+      asm volatile("" : "+v"(sel));                           // (opaque: the eight lane masks are not hoisted out of the iteration loop into SGPRs)
 #pragma unroll
-      for (int q = 0; q < kX1Values; ++q) mine = ((lane >> 1) == q) ? (double)v[q] : mine;
+      for (int q = 0; q < kX1Values; ++q) mine = (sel == q) ? (double)v[q] : mine;
       const peer_u64 word = peer_tagged(mine, lane & 1, epoch);
-      for (int p = 0; p < pv.world; ++p)
-        peer_store(reinterpret_cast<peer_u64*>(pv.mbox[p] + PeerLayout::x_rec(epoch & 1, pv.rank)) + lane, word);
+      for (int p = 0; p < world; ++p) {
+        char* mb = karg<char*>(sl_off + pv_off + (unsigned)offsetof(PeerView, mbox) + 8u * (unsigned)p);
+        peer_store(reinterpret_cast<peer_u64*>(mb + PeerLayout::x_rec(epoch & 1, rank)) + lane, word);
+      }
     }
+    const char* own = karg<char*>(sl_off + (unsigned)offsetof(SlabCtl, rows_own)) - PeerLayout::kRows;
     const int wd = lane & 15, sub = lane >> 4;
     peer_u64 w[2] = {0, 0};
     bool okl[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) okl[i] = (i * 4 + sub) >= pv.world;     // absent ranks count as arrived (payload 0)
+    for (int i = 0; i < 2; ++i) okl[i] = (i * 4 + sub) >= world;     // absent ranks count as arrived (payload 0)
     unsigned spins = 0;
     while (true) {
       bool ok = true;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        if (!okl[i]) w[i] = peer_load(reinterpret_cast<const peer_u64*>(pv.mbox[pv.rank] + PeerLayout::x_rec(epoch & 1, i * 4 + sub)) + wd);
+        if (!okl[i]) w[i] = peer_load(reinterpret_cast<const peer_u64*>(own + PeerLayout::x_rec(epoch & 1, i * 4 + sub)) + wd);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (!okl[i]) okl[i] = (unsigned)(w[i] & 0xffffffffull) == epoch;
@@ -420,7 +461,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // half and side (5 VALU instructions per row and pass in a loop that is bound by VALU issue), through the LDS it is one
   // broadcast read per row and pass that every lane receives (ring_issue) and no VALU slot at all.
   // (the slab variant and the fp64-coefficient fallback have no registers for the values in flight: they keep the DPP shifts)
-  constexpr bool kRingLds = !SLAB && sizeof(CT) == 4 && (NQ == 1 || PISO_PERSIST1_RING_SMALL != 0);
+  constexpr bool kRingLds = (!SLAB || PISO_PERSIST1_RING_SLAB != 0) && sizeof(CT) == 4 && (NQ == 1 || PISO_PERSIST1_RING_SMALL != 0);
   // kLean: the round-3 forms of the end-cell store (range-checked, all lanes) and of the coefficient offset (kept in a VGPR)
   constexpr bool kLean = !SLAB || PISO_PERSIST1_LEAN_SLAB != 0;
   constexpr int kRingBytes = 64 * (int)sizeof(T) + 64 * (int)sizeof(CT);
@@ -472,22 +513,41 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   const unsigned nbytesT = (unsigned)((size_t)nx * ny * sizeof(T)), nbytesC = (unsigned)((size_t)nx * ny * sizeof(CT));
   const unsigned rowT = (unsigned)(nx * sizeof(T)), rowC = (unsigned)(nx * sizeof(CT));
   // SLAB: does region q touch the lower / upper edge of the slab, and is there a GPU beyond it (else: a wall of the global grid)?
-  bool bot[NQ], top[NQ];
+  // ONE scalar of edge bits per region, opaque to the optimiser (it would expand them into flags that live in SGPRs across the
+  // loop): bit 0 first row = the slab's first row AND a GPU lies below, bit 1 last row = the slab's last row AND a GPU lies above,
+  // bit 2 / 3 first / last row = the slab's first / last row.  Everything else the two edge waves of a slab need - mailbox
+  // addresses, the row capacity - is fetched from the kernarg segment where it is used (karg): it used to occupy ~30 SGPRs in
+  // EVERY wave, which came back as v_readlane reloads in a loop that is bound by VALU issue (113 spilled SGPRs, 17-19 us per
+  // iteration against 11 for the single-GPU kernel).
+  typedef Persist1Kargs<T, SlabCtl> KArgs;
+  constexpr unsigned sl_off = (unsigned)offsetof(KArgs, sl);
+  constexpr unsigned pv_off = sl_off + (unsigned)offsetof(SlabCtl, pv);
+  unsigned ef[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) { bot[q] = SLAB && has[q] && j0[q] == 0; top[q] = SLAB && has[q] && j0[q] + R == ny; }
-  bool nb_lo = false, nb_hi = false;
-  // (mailbox resources are built from the kernel arguments where they are used - only the edge waves touch them, and 12 SGPRs
-  // held across the loop come back as v_readlane reloads in every wave)
-  const unsigned nbytesH = nbytesT + 2 * rowT;              // r / p[] including their halo rows (resources built where they are used)
-  unsigned mbz = 0;                                         // the eight rows of a mailbox (host-level exchange + z' halos)
-  if constexpr (SLAB) {
-    nb_lo = sl.pv.lower >= 0; nb_hi = sl.pv.upper >= 0;
-    mbz = (unsigned)(8 * sl.pv.row_cap * 8);
+  for (int q = 0; q < NQ; ++q) {
+    ef[q] = 0;
+    if constexpr (SLAB) {
+      const bool bot = has[q] && j0[q] == 0, top = has[q] && j0[q] + R == ny;
+      ef[q] = (bot && sl.pv.lower >= 0 ? 1u : 0u) | (top && sl.pv.upper >= 0 ? 2u : 0u) | (bot ? 4u : 0u) | (top ? 8u : 0u);
+      ef[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)ef[q]);
+      asm volatile("" : "+s"(ef[q]));
+    }
   }
-  // byte offset of z' halo row (parity, side) inside the rows of a mailbox
-  auto zrow_off = [&](int parity, int side) __attribute__((always_inline)) -> unsigned {
-    if constexpr (SLAB) return (unsigned)((4 + parity * 2 + side) * sl.pv.row_cap * 8);
-    else return 0u;
+  if constexpr (SLAB) {                                     // the mirror of the argument list is the argument list
+    if (karg<char*>(sl_off + (unsigned)offsetof(SlabCtl, rows_own)) != sl.rows_own || karg<size_t>(pv_off + (unsigned)offsetof(PeerView, row_cap)) != sl.pv.row_cap) {
+      if (threadIdx.x == 0) *c.err = 1;
+      return;
+    }
+  }
+  const unsigned nbytesH = nbytesT + 2 * rowT;              // r / p[] including their halo rows (resources built where they are used)
+  // resource of the eight rows of a mailbox (host-level exchange + z' halos) and the byte offset of z' halo row (parity, side)
+  // inside them: built by the edge waves where they use them
+  // (on = false: a resource of no bytes - every access through it is dropped by the range check: the edge rows' mailbox stores
+  // sit in the row loop without a branch; control flow in the middle of the unrolled loop cost the allocator 95 spilled VGPRs)
+  auto mailbox_rows = [&](unsigned field_off, int parity, int side, unsigned& zoff, bool on = true) __attribute__((always_inline)) -> rsrc_t {
+    const unsigned cap8 = (unsigned)karg<size_t>(pv_off + (unsigned)offsetof(PeerView, row_cap)) * 8u;
+    zoff = (unsigned)(4 + parity * 2 + side) * cap8;
+    return make_rsrc(karg<char*>(sl_off + field_off), on ? 8u * cap8 : 0u);
   };
   const rsrc_t RoS = make_rsrc(a.oS, nbytesC), RoW = make_rsrc(a.oW, nbytesC), RoE = make_rsrc(a.oE, nbytesC), RoN = make_rsrc(a.oN, nbytesC);
   const rsrc_t RcC = make_rsrc(a.cC, nbytesT);
@@ -538,7 +598,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       // (lane l < R: left neighbour of row l, lane R + l: right neighbour; other lanes and walls read 0)
       const int jb = row_wrap(j0[q] - 1, vb[q]), ja = row_wrap(j0[q] + R, va[q]);
       if constexpr (SLAB) {                                  // no wrap inside a slab: beyond its edges lies a neighbour's row (or a wall)
-        vb[q] = !bot[q] || nb_lo; va[q] = !top[q] || nb_hi;
+        vb[q] = !(ef[q] & 4u) || (ef[q] & 1u); va[q] = !(ef[q] & 8u) || (ef[q] & 2u);
         const unsigned hb = (has[q] && vb[q]) ? vT[q] : 0xffffffffu, ha = (has[q] && va[q]) ? vT[q] : 0xffffffffu;
         const rsrc_t RrH = make_rsrc(a.r - nx, nbytesH), RpH = make_rsrc(a.p[k_begin & 1] - nx, nbytesH);
         rhb[q] = bld<T, V>(RrH, hb, (unsigned)j0[q] * rowT);            // (the halo-based resources start one row lower)
@@ -620,7 +680,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   constexpr int NT = NQ * R;
   // (the deep pipeline pays where the loop has registers to spare: the slab variant and the four-array / fp64-coefficient variants
   // keep the round-2 depth, they spill otherwise)
-  constexpr bool kDeep = NQ == 1 && NT == 16 && SYM && RECON && !SLAB && sizeof(T) == 8;
+  constexpr bool kDeep = NQ == 1 && NT == 16 && SYM && RECON && (!SLAB || PISO_PERSIST1_DEEP_SLAB != 0) && sizeof(T) == 8;
   constexpr int depth_max = kDeep ? PISO_PERSIST1_DEPTH : ((NQ == 1) ? 3 : kPersistMaxDepth);
   constexpr int budget = kDeep ? 4 * PISO_PERSIST1_DEPTH : ((NQ == 1 || NT < 16) ? 16 : 8);
   constexpr int Dw = budget / coef_regs < 2 ? 2 : (budget / coef_regs > depth_max ? depth_max : budget / coef_regs);
@@ -688,7 +748,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         *(lds_CT*)(unsigned long)(ring_a + (unsigned)(q * kRingBytes + 64 * (int)sizeof(T)) + (unsigned)lane * (unsigned)sizeof(CT)) = eW[q];
       bool valid;
       const int jw = row_wrap(j0[q] + R, valid);
-      if (SLAB && top[q]) cSh[q] = bld<CT, V>(RoN, has[q] ? coef_offset(q) : 0xffffffffu, (unsigned)(ny - 1) * rowC);   // N of my last row
+      if (SLAB && (ef[q] & 8u)) cSh[q] = bld<CT, V>(RoN, has[q] ? coef_offset(q) : 0xffffffffu, (unsigned)(ny - 1) * rowC);   // N of my last row
       else
       cSh[q] = bld<CT, V>(RoS, (has[q] && valid) ? coef_offset(q) : 0xffffffffu, (unsigned)jw * rowC);
     }
@@ -749,16 +809,24 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     }
     return z;
   };
-  unsigned zoff_lo = 0, zoff_hi = 0, zoff_b = 0, zoff_a = 0;   // SLAB: this iteration's rows in the neighbours' / my mailbox
+  int k = k_begin;                                           // the iteration (SLAB: its parity picks the mailbox rows)
   // perimeter of row jj of region q (what neighbouring regions read): the whole first / last row, else the two end cells
   auto publish = [&](rsrc_t Rd, int q, int jj, const Vec<T, V>& val) __attribute__((always_inline)) {
     const unsigned sT = row_base(q, jj, rowT);
     if (jj == 0 || jj == R - 1) {
       bst<T, V, kPub>(Rd, vT[q], sT, val);
-      if constexpr (SLAB) {
+      if constexpr (SLAB && !PISO_X3) {
         // my first row is the row ABOVE the lower neighbour's slab (its side 1), my last row the row BELOW the upper one's (side 0)
-        if (jj == 0 && bot[q] && nb_lo) bst<T, V, kSystem>(make_rsrc(sl.rows_lo, mbz), vT[q], zoff_lo, val);
-        if (jj == R - 1 && top[q] && nb_hi) bst<T, V, kSystem>(make_rsrc(sl.rows_hi, mbz), vT[q], zoff_hi, val);
+        if (jj == 0) {
+          unsigned zoff;
+          const rsrc_t Rm = mailbox_rows((unsigned)offsetof(SlabCtl, rows_lo), k & 1, 1, zoff, (ef[q] & 1u) != 0);
+          bst<T, V, kSystem>(Rm, vT[q], zoff, val);
+        }
+        if (jj == R - 1) {
+          unsigned zoff;
+          const rsrc_t Rm = mailbox_rows((unsigned)offsetof(SlabCtl, rows_hi), k & 1, 0, zoff, (ef[q] & 2u) != 0);
+          bst<T, V, kSystem>(Rm, vT[q], zoff, val);
+        }
       }
     } else {
       // the two end cells of the row: lanes 0 and 63 store their cells of the row (16 bytes each; a lane's inner cell is written
@@ -792,13 +860,25 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       bool vbq, vaq;
       const int jb = row_wrap(j0[q] - 1, vbq), ja = row_wrap(j0[q] + R, vaq);
       const unsigned hb = vbq ? vT[q] : 0xffffffffu, ha = vaq ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
-      if constexpr (SLAB) {                                  // (wave-uniform branches: no per-lane offset registers to keep)
+      if constexpr (SLAB && !PISO_X2) {                                  // (wave-uniform branches: no per-lane offset registers to keep)
+        if (!(ef[q] & 4u)) hbZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] - 1) * rowT);
+        else if (ef[q] & 1u) {
+          unsigned zoff;
+          const rsrc_t Rm = mailbox_rows((unsigned)offsetof(SlabCtl, rows_own), k & 1, 0, zoff);
+          hbZ[q] = bld<T, V, kSystem>(Rm, vT[q], zoff);
+        } else {
 #pragma unroll
-        for (int e = 0; e < V; ++e) { hbZ[q].v[e] = 0; haZ[q].v[e] = 0; }
-        if (!bot[q]) hbZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] - 1) * rowT);
-        else if (nb_lo) hbZ[q] = bld<T, V, kSystem>(make_rsrc(sl.rows_own, mbz), vT[q], zoff_b);
-        if (!top[q]) haZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] + R) * rowT);
-        else if (nb_hi) haZ[q] = bld<T, V, kSystem>(make_rsrc(sl.rows_own, mbz), vT[q], zoff_a);
+          for (int e = 0; e < V; ++e) hbZ[q].v[e] = 0;
+        }
+        if (!(ef[q] & 8u)) haZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] + R) * rowT);
+        else if (ef[q] & 2u) {
+          unsigned zoff;
+          const rsrc_t Rm = mailbox_rows((unsigned)offsetof(SlabCtl, rows_own), k & 1, 1, zoff);
+          haZ[q] = bld<T, V, kSystem>(Rm, vT[q], zoff);
+        } else {
+#pragma unroll
+          for (int e = 0; e < V; ++e) haZ[q].v[e] = 0;
+        }
       } else {
       hbZ[q] = bld<T, V, kAgent>(Rz, hb, (unsigned)jb * rowT);
       haZ[q] = bld<T, V, kAgent>(Rz, ha, (unsigned)ja * rowT);
@@ -814,7 +894,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
 
   unsigned epoch = c.epoch0;
   bool healthy = true, first = true;
-  int k = k_begin;
   unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tsub[4] = {0, 0, 0, 0}, tlast = (kPersistDiag && c.timing) ? wall_clock64() : 0;
   auto tick = [&](int slot) __attribute__((always_inline)) {     // diagnostic builds only (-DPISO_PERSIST_DIAG): D / exchange / U clocks
     if (kPersistDiag && c.timing) { const unsigned long long t = wall_clock64(); tacc[slot] += t - tlast; tlast = t; }
@@ -832,7 +911,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     // consecutive iterations alternate buffers: a neighbour's loads of z'_k are consumed before it publishes its record k + 1,
     // which everybody needs before writing the same buffer again in iteration k + 2
     const rsrc_t Rz = (k & 1) ? Rz1 : Rz0;
-    if constexpr (SLAB) { zoff_lo = zrow_off(k & 1, 1); zoff_hi = zrow_off(k & 1, 0); zoff_b = zrow_off(k & 1, 0); zoff_a = zrow_off(k & 1, 1); }
     const T beta = uniform(-(rz_next + vs * sumr) / pz);     // (:351-352), unguarded as coded
     // ---- D(k): p = r + beta p on my cells and on the ring; z' = L p; sums; the perimeter of z' goes out
     T sD[kX1Values] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -896,7 +974,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       }
     };
     healthy = grid_exchange8<T, LOCAL>(c, sD, epoch, smem, slot, nslots, prefetch_u, (kPersistDiag && c.timing) ? tsub : nullptr);
-    if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl.pv, sD, epoch, smem + 2 * kX1Sm); }
+    if constexpr (SLAB && !PISO_X1) { if (healthy) healthy = xgpu_exchange8<T>(sl_off, sD, epoch, smem + 2 * kX1Sm); }
     tick(1);
     if (!healthy) break;
     // ---- the stopping test of iteration k, one exchange late but before anything moves (x = x_k): (:312-335)
@@ -999,7 +1077,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     T sX[kX1Values] = {0, 0, 0, 0, 0, 0, lU[0], lU[1]};
     ++epoch;
     healthy = grid_exchange8<T, LOCAL>(c, sX, epoch, smem, slot, nslots);
-    if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl.pv, sX, epoch, smem + 2 * kX1Sm); }
+    if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl_off, sX, epoch, smem + 2 * kX1Sm); }
     tOut[1] = sX[6]; tOut[2] = sX[7];
   }
 
@@ -1021,8 +1099,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           const rsrc_t RrH = make_rsrc(a.r - nx, nbytesH), RpH = make_rsrc(a.p[k & 1] - nx, nbytesH);
           T* hs = halo_s + (kParkHalos ? (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V : 0);
           if constexpr (kParkHalos) { pnb[q] = ldv<T, V>(hs); pna[q] = ldv<T, V>(hs + 64 * V); }
-          if (bot[q] && nb_lo) { bst<T, V>(RrH, vT[q], 0u, rhb[q]); bst<T, V>(RpH, vT[q], 0u, pnb[q]); }
-          if (top[q] && nb_hi) { bst<T, V>(RrH, vT[q], (unsigned)(ny + 1) * rowT, rha[q]); bst<T, V>(RpH, vT[q], (unsigned)(ny + 1) * rowT, pna[q]); }
+          if (ef[q] & 1u) { bst<T, V>(RrH, vT[q], 0u, rhb[q]); bst<T, V>(RpH, vT[q], 0u, pnb[q]); }
+          if (ef[q] & 2u) { bst<T, V>(RrH, vT[q], (unsigned)(ny + 1) * rowT, rha[q]); bst<T, V>(RpH, vT[q], (unsigned)(ny + 1) * rowT, pna[q]); }
         }
       }
   }

@@ -1,0 +1,89 @@
+"""Static look at a kernel's compiled loop (no GPU needed): registers, spills, scratch and the instruction mix of its largest loop.
+Usage: python scripts/isa_loop.py <csrc file, e.g. cg_slab.hip> <substring of the mangled kernel name> [extra hipcc flags ...]
+e.g.   python scripts/isa_loop.py cg_slab.hip cg_persist1IdfLi16ELi1ELb1ELb1ELb1
+The iteration loop of the persistent kernels is bound by VALU issue: every v_* instruction (v_readlane reloads of spilled SGPRs
+included) costs the same ~4.5 SIMD cycles, so `valu`, `readlane`, `scratch` of the loop are the numbers to watch."""
+import collections, os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "differentiable-piso_amd", "csrc")
+
+
+def compile_to_asm(src, flags):
+    d = tempfile.mkdtemp(prefix="isa_")
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-int-to-pointer-cast",
+           "-c", os.path.join(CSRC, src), "-o", os.path.join(d, "o.o"), "-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"] + flags
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    if p.returncode != 0:
+        sys.stderr.write(p.stderr[-4000:])
+        raise SystemExit(1)
+    asm = [f for f in os.listdir(d) if f.endswith("gfx950.s")]
+    return os.path.join(d, asm[0]), p.stderr
+
+
+def resources(remarks, key):
+    out, cur = {}, None
+    for l in remarks.split("\n"):
+        m = re.search(r"Function Name: (\S+)", l)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.search(r"remark: [^:]*:\d+:\d+:\s+(.*?): (\d+)", l) or re.search(r"\s+(TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", l)
+        if m and cur and key in cur:
+            out.setdefault(cur, {})[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+def loops(lines):
+    labels = {}
+    for n, l in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = n
+    best = None
+    for n, l in enumerate(lines):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < n:
+            a = labels[m.group(1)]
+            if best is None or n - a > best[1] - best[0]:
+                best = (a, n)
+    return best
+
+
+def mix(body):
+    c = collections.Counter()
+    for l in body:
+        l = l.strip()
+        if not l or l[0] in ";." or l.endswith(":"):
+            continue
+        c[l.split()[0]] += 1
+    return c
+
+
+def main():
+    src, key, flags = sys.argv[1], sys.argv[2], sys.argv[3:]
+    asm, remarks = compile_to_asm(src, flags)
+    res = resources(remarks, key)
+    text = open(asm).read()
+    for name in sorted(res):
+        i = text.index("\n" + name + ":")
+        j = text.index(".Lfunc_end", i)
+        lines = text[i:j].split("\n")
+        r = res[name]
+        print(name[:110])
+        print("   VGPRs %s  SGPR spills %s  VGPR spills %s  scratch %s B/lane  LDS %s B" % (
+            r.get("VGPRs"), r.get("SGPRs Spill"), r.get("VGPRs Spill"), r.get("ScratchSize [bytes/lane]"), r.get("LDS Size [bytes/block]")))
+        lp = loops(lines)
+        if lp:
+            c = mix(lines[lp[0]:lp[1]])
+            valu = sum(v for k, v in c.items() if k.startswith("v_"))
+            print("   largest loop: %d instructions, valu %d, readlane %d, writelane %d, scratch %d, fp64 %d, cvt %d, dpp %d, s_load %d, vmem %d, ds %d" % (
+                sum(c.values()), valu, c["v_readlane_b32"], c["v_writelane_b32"], sum(v for k, v in c.items() if k.startswith("scratch_")),
+                sum(v for k, v in c.items() if k.endswith("_f64") or k.endswith("_f64_e32") or k.endswith("_f64_e64")),
+                sum(v for k, v in c.items() if k.startswith("v_cvt")), c["v_mov_b32_dpp"], sum(v for k, v in c.items() if k.startswith("s_load")),
+                sum(v for k, v in c.items() if k.startswith("buffer_") or k.startswith("global_")), sum(v for k, v in c.items() if k.startswith("ds_"))))
+    print("asm:", asm)
+
+
+if __name__ == "__main__":
+    main()
