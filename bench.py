@@ -29,6 +29,9 @@ One JSON line on stdout (rank 0) with, besides the contract's keys:
                 (VALU issue + one grid exchange; `bound` stays the contract's "hbm" = the peak frac is priced against) and `floors_us_per_iteration` / `frac_of_binding_floor` price it
   bicgstab      fixed-work run of the ILU(0)-BiCGStab (both components, every launch does work), 296 B per row and iteration
   phases        forward / adjoint ms per step, CG iterations per step, CG share of the step
+  slab_kernel_loopback   (N = 1) us per iteration of the SLAB instance of the persistent CG kernel in a ring of one rank (edge rows
+                and totals through the rank's own peer mailbox) next to the plain kernel on the same system: the kernel-level
+                weak-scaling efficiency of the sharded N > 1 headline before any xGMI hop
   other_configs ms per step of BASELINE.json's config 2 (256^2 forward) and config 3 (512x256 fwd + adjoint, 4 steps)
   cpu_baseline  the C oracle (a port of the reference's algorithm) on all host cores, bounded sample (rank 0, N = 1 only)
 """
@@ -217,6 +220,51 @@ def bicgstab_fixed_work(P, n, iters=10, reps=3):
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
             "ms_per_solve": best, "us_per_iteration": 1e3 * best / max(total_its, 1), "rows": rows,
             "algorithmic_bytes_per_solve": nbytes, "bytes_per_row_iteration": BICG_BYTES_PER_ROW_ITER}
+
+
+def slab_kernel_loopback(n, device, iters=3000):
+    """N = 1 only, after the timed region: the SLAB instance of the persistent CG kernel (cg_persist1<..., SLAB>, the kernel of
+    the sharded N > 1 headline) in a ring of ONE rank - the edge rows of z' and the GPU's totals go through the rank's own
+    peer mailbox, so every slab-specific instruction runs, only the xGMI hop is local - next to the plain kernel on the same
+    system, same box, same fixed iteration count.  The ratio is the weak-scaling efficiency of the kernel before any hop."""
+    import torch
+    from diffpiso.distributed import SlabCommunicator, cg_solve_slab
+    from diffpiso.solvers import cg_solve_native, laplace_matrix_native
+    g = torch.Generator(device="cpu")
+    g.manual_seed(11)
+    a0 = 0.5 + torch.rand(n * (n + 1) + (n + 1) * n, generator=g)
+    av, au = a0[:n * (n + 1)].view(n + 1, n), a0[n * (n + 1):].view(n, n + 1)
+    av[n] = av[0]
+    au[:, n] = au[:, 0]
+    ones = torch.ones((n + 2) * (n + 2), device=device)
+    L = laplace_matrix_native(n, n, ones, ones, a0.to(device), torch.float64)
+    b = torch.randn(n * n, generator=g, dtype=torch.float64).to(device)
+    b -= b.mean()
+    comm = SlabCommunicator(rank=0, world=1, device=device, transport="peer", row_capacity=n)
+    try:
+        res = {}
+        for key, fn in (("plain", lambda k: cg_solve_native(n, n, True, True, L, b, 1e-30, k, False, 1 << 30)),
+                        ("slab", lambda k: cg_solve_slab(comm, n, n, True, True, L, b, 1e-30, k, False, 1 << 30))):
+            x, _ = fn(100)
+            res[key + "_x"] = x
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn(iters)
+                torch.cuda.synchronize()
+                us = 1e6 * (time.perf_counter() - t0) / iters
+                best = us if best is None else min(best, us)
+            res[key] = best
+        st = comm.stats()
+        diff = float((res["slab_x"] - res["plain_x"]).abs().max() / res["plain_x"].abs().max())
+        return {"grid": [n, n], "iterations_timed": iters, "us_per_iteration_slab_kernel_ring_of_one": res["slab"],
+                "us_per_iteration_plain_kernel": res["plain"], "ratio_plain_over_slab": res["plain"] / res["slab"],
+                "max_rel_diff_after_100_iterations": diff, "persistent_slab_iterations": st["persistent_iterations"],
+                "persistent_fallbacks": st["persistent_fallbacks"], "verification_failures": st["verification_failures"],
+                "note": "whole solves (set-up, first iteration and the true-residual check included); the hop to the mailbox is local"}
+    finally:
+        comm.close()
 
 
 def cpu_baseline(P, n, tol, cg_iters_per_step, bicg_solves_per_step=2, sample_iters=240):
@@ -716,6 +764,10 @@ def main():
                 out["bicgstab"] = bicgstab_fixed_work(P, n)
             except Exception as e:
                 out["bicgstab"] = {"error": repr(e)}
+            try:
+                out["slab_kernel_loopback"] = slab_kernel_loopback(n, device)
+            except Exception as e:
+                out["slab_kernel_loopback"] = {"error": repr(e)}
             try:
                 out["other_configs"] = other_configs(device)
             except Exception as e:

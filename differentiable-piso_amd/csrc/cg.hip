@@ -19,7 +19,7 @@ struct CgProfile {
   long long count[4] = {0, 0, 0, 0};    // launches of K1, K2; ITERATIONS executed inside persistent segments; segment LAUNCHES
 };
 static CgProfile g_prof;
-constexpr size_t kPersistWsWords = (size_t)2 * kPersistMaxGrid * 32 + 64;   // records (2 x grid x 128 B) + error flag
+constexpr size_t kPersistWsWords = kPersistWsWordsAll;   // exchange records + control words (cg_persist.h)
 
 struct HostPoll {
   CgState* pinned = nullptr;   // [2]
@@ -230,7 +230,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     pc.rec = reinterpret_cast<unsigned long long*>(persist_ws);
     pc.err = reinterpret_cast<int*>(persist_ws + kPersistWsWords - 16);
     PISO_HIP_CHECK(hipMemsetAsync(persist_ws, 0, kPersistWsWords * sizeof(unsigned), stream));
-    pc.xcd = reinterpret_cast<int*>(persist_ws + (size_t)2 * kPersistMaxGrid * 32);   // 9 words behind the records, before the error flag
+    pc.xcd = reinterpret_cast<int*>(persist_ws + kPersistRecWords);   // 10 words behind the records, before the error flag
     pc.local_n = xcd_local ? persist_grid : 0;
     if (launch_grid > kPersistMaxGrid) persist_R = 0;
     if (kPersistDiag && opt_on(OPT_CG_PERSIST_TIMING)) {   // diagnostic builds only: per-phase clocks of every workgroup
@@ -243,7 +243,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     // record left by an earlier launch - in memory or in some XCD's L2 - can never pass for one of this launch.  The records are
     // zeroed as well, which covers the counter's wrap.
     pc.epoch0 = (g_persist_launches.fetch_add(1, std::memory_order_relaxed) & 0xffffu) << 16;
-    PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 128 + 16 * sizeof(int), stream));   // records + XCD arrivals
+    PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, kPersistZeroBytes, stream));   // records (both levels) + XCD arrivals
     constexpr bool kCanSym = RECON && sizeof(CT) == 4;     // the symmetric variant exists for the compact coefficient path
     if constexpr (kCanSym && sizeof(T) == 8) {
       if (xcd_local) {                                       // (symmetric, one exchange, regions of 2 / 4 rows: checked above)
@@ -429,6 +429,13 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     const char* names[9] = {"D (p update, stencil, sums, publish)", "exchange", "U (stencil, x / r update, ring)", "-", "-",
                              "  exchange: wave sums + drain of the perimeter stores", "  exchange: first barrier", "  exchange: publish + polling",
                              "  exchange: record sums + second barrier"};
+    if (opt(OPT_CG_PERSIST_TIMING) >= 2) {                  // the whole table: one line per workgroup (us per iteration)
+      const double f = 0.01 / (double)(k_last > 0 ? k_last : 1);
+      for (int b = 0; b < persist_grid; ++b)
+        fprintf(stderr, "cg_persist_wg %3d xcd %d band %3d  D %.2f  exchange %.2f  U %.2f  | drain %.2f  barrier1 %.2f  publish+poll %.2f  sums %.2f\n", b, (int)h[9 * persist_grid + b], (int)h[10 * persist_grid + b],
+                f * (double)h[0 * persist_grid + b], f * (double)h[1 * persist_grid + b], f * (double)h[2 * persist_grid + b],
+                f * (double)h[5 * persist_grid + b], f * (double)h[6 * persist_grid + b], f * (double)h[7 * persist_grid + b], f * (double)h[8 * persist_grid + b]);
+    }
     for (int q = 0; q < 9; ++q) {
       double s = 0, mn = 1e300, mx = 0;
       for (int b = 0; b < persist_grid; ++b) { const double v = (double)h[q * persist_grid + b]; s += v; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
@@ -578,6 +585,15 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   rc = cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream)
   if (!hflags[0]) {                                         // (fp32 state: trivially exact - the same path, so that the diagonal can be rebuilt there too)
     a.oS = oF; a.oW = oF + n; a.oE = oF + 2 * n; a.oN = oF + 3 * n;
+#ifdef PISO_EXP_SKEW      // experiment: the W array at another offset from the S array than a power of two (channel / bank conflicts?)
+    {
+      static float* skew = nullptr;
+      static size_t skew_n = 0;
+      if (skew_n < n) { if (skew) (void)hipFree(skew); PISO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&skew), (n + (1u << 20)) * sizeof(float))); skew_n = n; }
+      PISO_HIP_CHECK(hipMemcpyAsync(skew + PISO_EXP_SKEW, oF + n, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      a.oW = skew + PISO_EXP_SKEW;
+    }
+#endif
     if (!hflags[1]) { if (vec) PISO_CG_RUN(float, VMID, true); else PISO_CG_RUN(float, 1, true); }
     else if (vec) PISO_CG_RUN(float, VMID, false);
     else PISO_CG_RUN(float, 1, false);

@@ -96,9 +96,18 @@ struct Persist1Kargs { CgArgs<T> a; PersistCtl c; int k_begin, k_end, sv, pend; 
 template <typename F>
 __device__ __forceinline__ F karg(unsigned off) {
   typedef __attribute__((address_space(4))) const char kchar;
+  typedef __attribute__((address_space(4))) const unsigned kword;
   kchar* kp = (kchar*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(kp));
-  return *(const __attribute__((address_space(4))) F*)(kp + off);
+  static_assert(sizeof(F) % 4 == 0, "whole dwords");
+  constexpr int NW = (int)(sizeof(F) / 4);
+  unsigned w[NW];
+  kword* src = (kword*)(kp + off);
+#pragma unroll
+  for (int i = 0; i < NW; ++i) w[i] = src[i];              // (merged into s_load_dwordx2 / x4 / x8 / x16)
+  F out;
+  __builtin_memcpy(&out, w, sizeof(F));
+  return out;
 }
 
 // coefficient rows in flight per wave (A/B builds: -DPISO_PERSIST1_DEPTH=n + scripts/build_variant.py / scripts/ab.sh).  Round 3, 16-row
@@ -135,11 +144,29 @@ __device__ __forceinline__ F karg(unsigned off) {
 #ifndef PISO_PERSIST1_DEEP_SLAB
 #define PISO_PERSIST1_DEEP_SLAB 1            // the five-row coefficient pipeline in the slab variant as well
 #endif
+#ifndef PISO_PERSIST1_EXIT_KARGS
+#define PISO_PERSIST1_EXIT_KARGS 1            // the exit block reads its pointers again from the kernarg segment
+#endif
 #ifndef PISO_PERSIST1_PREFETCH_BEHIND_DRAIN
 #define PISO_PERSIST1_PREFETCH_BEHIND_DRAIN 0    // (measured: no gain - the first barrier of the exchange waits for the slowest wave, not for the drain)
 #endif
 #ifndef PISO_PERSIST1_POLL_DELAY
 #define PISO_PERSIST1_POLL_DELAY 24             // s_sleep units (64 cycles) between publishing a record and the first polling pass
+#endif
+#ifndef PISO_PERSIST1_HIER
+#define PISO_PERSIST1_HIER 1                    // chip-wide launches exchange through the tree workgroup -> XCD leader -> everybody (grid_exchange8_hier)
+#endif
+#ifndef PISO_PERSIST1_AHEAD
+#define PISO_PERSIST1_AHEAD 0                   // rows of z' = L p that the U pass finds precomputed (see kAhead)
+#endif
+#ifndef PISO_PERSIST1_PACK
+#define PISO_PERSIST1_PACK 1                    // end cells of a region's rows published as one packed block per region (see kPack)
+#endif
+#ifndef PISO_PERSIST1_HALO_AT
+#define PISO_PERSIST1_HALO_AT 0                 // 16-row regions: the U row step in front of which the neighbours' z' rows are requested (0: behind the exchange)
+#endif
+#ifndef PISO_PERSIST1_POLL_DELAY2
+#define PISO_PERSIST1_POLL_DELAY2 0             // s_sleep units in front of the first polling pass of the tree's second level
 #endif
 #ifndef PISO_PERSIST1_POLL_SLEEP
 #define PISO_PERSIST1_POLL_SLEEP 1              // s_sleep units (64 cycles) between two polling passes
@@ -313,6 +340,161 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
   return good;
 }
 
+// ---- The same exchange as a TREE that follows the hardware (chip-wide launches; round 4): workgroup -> XCD leader -> everybody.
+//   level 1  every workgroup stores its record WITHOUT sc1 into the records of ITS XCD (slot = 32 xcd + arrival rank on that XCD;
+//            the store stays in that XCD's L2); wave 0 of the XCD's leader (arrival rank 0) polls the XCD's records with sc1 loads
+//            (L1 bypassed, served by the L2 both share) and adds them in rank order;
+//   level 2  the leader publishes the XCD's sums as one record through the fabric (sc1 store); EVERY wave of every workgroup polls
+//            the eight XCD records itself (two coalesced loads per lane) and adds them in XCD order - bitwise the same totals in
+//            every wave of the chip, no second barrier, no LDS round trip behind the polling.
+// Measured (scripts/barrier_bench.hip, 256 workgroups, 3 sums): 2.40 us per exchange against 3.7-5.3 us for the flat all-to-all
+// variants (every workgroup polling 256 records through the fabric: 8 MB of polling reads per pass; here 4 KB per XCD at level 1
+// and 2 MB at level 2).  hx packs what a workgroup learnt at entry (hier_enter): bits 0-2 XCD, 3-8 arrival rank, 9-14 workgroups
+// on my XCD, 15-22 XCDs that hold workgroups.  A wave whose polling gives up sets the workgroup's LDS flag and the launch's
+// error word; all waves of the workgroup read the flag behind the next barrier and leave the loop together.
+__device__ __forceinline__ unsigned long long* hier_level2(const PersistCtl& c) {
+  return c.rec + (size_t)2 * kPersistMaxGrid * kX1RecWords;                 // right behind the level-1 records (kPersistRecWords)
+}
+// entry of a chip-wide launch: which XCD am I on, which arrival there, how many workgroups does every XCD hold?  One returning
+// atomic per workgroup, then everybody waits for everybody ONCE per launch (c.xcd[0..7] arrivals per XCD, [9] arrivals in all;
+// zeroed by the host before the launch).
+__device__ __forceinline__ unsigned hier_enter(const PersistCtl& c, int* lds2) {      // lds2: [0] hx, [1] launch cannot run, [2] sticky flag of the exchanges
+  if (threadIdx.x == 0) {
+    const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);       // HW_REG_XCC_ID[3:0]
+    const int rank = __hip_atomic_fetch_add(c.xcd + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(c.xcd + 9, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    bool ok = rank < 32;
+    while (ok && __hip_atomic_load(c.xcd + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
+      if (++spins > (1u << 22)) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    unsigned present = 0, mine = 0;
+    for (int x = 0; x < kXcds; ++x) {
+      const int n = __hip_atomic_load(c.xcd + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n > 0) present |= 1u << x;
+      if (n > 32) ok = false;
+      if (x == xcc) mine = (unsigned)n;
+    }
+    if (!ok) *c.err = 1;
+    lds2[0] = (int)((unsigned)xcc | ((unsigned)(rank & 63) << 3) | ((mine & 63u) << 9) | (present << 15));
+    lds2[1] = ok ? 0 : 1;
+    lds2[2] = 0;
+  }
+  __syncthreads();
+  return (unsigned)__builtin_amdgcn_readfirstlane(lds2[0]);
+}
+template <typename T, typename F = NoPrefetch>
+__device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[kX1Values], unsigned epoch, T* smem, unsigned hx, int* flag,
+                                                    F while_records_travel = F(), unsigned long long* tsub = nullptr) {
+  unsigned long long t0 = (kPersistDiag && tsub) ? wall_clock64() : 0;
+  auto tsplit = [&](int q) __attribute__((always_inline)) {
+    if (kPersistDiag && tsub) { const unsigned long long t = wall_clock64(); tsub[q] += t - t0; t0 = t; }
+  };
+  typedef unsigned long long u64;
+  constexpr int NV = kX1Values;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  T* sm = smem + (epoch & 1) * kX1Sm;                       // parity double buffer (one barrier per exchange separates writers and readers)
+  {
+    double vd[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) vd[q] = (double)v[q];
+    const double mine = wave_reduce_scatter8(vd);              // lane l: value l & 7, summed over this wave
+    if (lane < NV) sm[lane * kPersistWaves + wave] = (T)mine;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every perimeter store of this wave has completed (see grid_exchange8)
+  tsplit(0);
+  __syncthreads();
+  tsplit(1);
+  const bool good = __builtin_amdgcn_readfirstlane(*flag) == 0;   // (a polling pass of an EARLIER exchange gave up somewhere in this workgroup)
+  const int xcc = (int)(hx & 7u), rank = (int)((hx >> 3) & 63u), nmine = (int)((hx >> 9) & 63u);
+  const unsigned present = (hx >> 15) & 0xffu;
+  u64* rec1 = c.rec + (size_t)(epoch & 1) * kPersistMaxGrid * kX1RecWords + (size_t)xcc * 32 * kX1RecWords;
+  u64* rec2 = hier_level2(c) + (size_t)(epoch & 1) * kXcds * kX1RecWords;
+  // lane l polls word l % 16 of record 4 i + l / 16, i.e. 8-byte word 64 i + l of the record array: ONE per-lane offset, made opaque
+  // so that nothing derived from it is hoisted out of the iteration loop into vector registers that live across the row loops
+  int lw = lane;
+  asm volatile("" : "+v"(lw));
+  bool mygood = true;
+  if (wave == 0) {
+    {
+      // lane l < 16 publishes word l: sum l / 2, low half (even l) or high half (odd l) - one store instruction, one cache line
+      const int vq = (lane >> 1) & (NV - 1);
+      T s = 0;
+      for (int w = 0; w < kPersistWaves; ++w) s += sm[vq * kPersistWaves + w];
+      const u64 bits = (u64)__double_as_longlong((double)s);
+      const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+      if (lane < kX1RecWords) __hip_atomic_store(rec1 + (size_t)rank * kX1RecWords + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (rank == 0) {                                          // the XCD's leader: the records of my XCD (through its L2), in rank order
+      // (branch-free passes: all eight loads every time, records beyond the XCD's count masked by one compare against a scalar -
+      // per-record arrival flags are eight lane masks = sixteen SGPRs the row loops then spill)
+      u64 w[8];
+      const int lim = nmine * kX1RecWords;                    // words of the XCD's block that belong to records in play
+      unsigned spins = 0;
+      while (true) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(rec1 + lw + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bad |= (lw < lim - i * 64) ? ((unsigned)(w[i] & 0xffffffffull) ^ epoch) : 0u;
+        if (__all(bad == 0)) break;
+        if (++spins > (1u << 22)) { mygood = false; break; }
+      }
+      double acc = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned hi_other = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(w[i] >> 32), 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+        const double val = __longlong_as_double((long long)((w[i] >> 32) | ((u64)hi_other << 32)));   // (odd lanes: garbage that nobody reads)
+        acc += (lw < lim - i * 64) ? val : 0.0;
+      }
+      acc += lanes_xor16(acc);
+      acc += lanes_xor32(acc);                                // even lane 2 q (of every group of 16): the XCD's sum of value q
+      const double other = dpp_move<0xB1>(acc);              // odd lanes: the even neighbour's sum
+      const u64 bits = (u64)__double_as_longlong((lane & 1) ? other : acc);
+      const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+      if (lane < kX1RecWords) __hip_atomic_store(rec2 + (size_t)xcc * kX1RecWords + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // the records need a microsecond or two to make their way: work that does not depend on the sums goes here (the row loops
+  // are bound by VALU issue, and the SIMDs idle while the exchange is in flight)
+  while_records_travel();
+  {
+    // every wave: the eight XCD records (lane l: word l % 16 of record 4 i + l / 16), added in XCD order
+    u64 w[2];
+    unsigned spins = 0;
+    if (PISO_PERSIST1_POLL_DELAY2 > 0) __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_DELAY2);
+    while (true) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) w[i] = __hip_atomic_load(rec2 + lw + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned bad = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)                            // (XCDs without workgroups: nothing to wait for, payload 0)
+        bad |= (((present >> (i * 4)) >> (lw >> 4)) & 1u) ? ((unsigned)(w[i] & 0xffffffffull) ^ epoch) : 0u;
+      if (__all(bad == 0)) break;
+      if (++spins > (1u << 22)) { mygood = false; break; }
+      __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_SLEEP);
+    }
+    tsplit(2);
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned hi_other = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(w[i] >> 32), 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+      const double val = __longlong_as_double((long long)((w[i] >> 32) | ((u64)hi_other << 32)));
+      acc += (((present >> (i * 4)) >> (lw >> 4)) & 1u) ? val : 0.0;
+    }
+    acc += lanes_xor16(acc);
+    acc += lanes_xor32(acc);                                  // lane 2 q: the total of value q - the same bits in every wave of the chip
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = (T)read_lane_c(acc, 2 * q);
+  }
+  if (!mygood) {                                              // (wave-uniform)
+    if (lane == 0) { *flag = 1; *c.err = 1; }
+  }
+  tsplit(3);
+  return good && mygood;
+}
+
 // Second level of the exchange (SLAB): the GPU's totals (bitwise the same in all of its workgroups after grid_exchange8) go to
 // every peer's mailbox as one tagged record, written by workgroup 0; wave 0 of EVERY workgroup polls the `world` records of its
 // own mailbox (lane l: word l % 16 of rank l / 16 [+ 4]) and adds them in a fixed order.  A record that carries the tag also says
@@ -471,6 +653,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar branches, SGPRs
   int wg = blockIdx.x;                                     // XCD-contiguous bands (block b is observed on XCD b % 8)
   if (gridDim.x % kXcds == 0) wg = (blockIdx.x % kXcds) * (gridDim.x / kXcds) + blockIdx.x / kXcds;
+#ifdef PISO_EXP_ROT       // experiment: the bands of regions rotated against the XCDs (does a slow band follow its addresses or its XCD?)
+  wg = (wg + PISO_EXP_ROT) % (int)gridDim.x;
+#endif
   int nslots = (int)gridDim.x;                             // workgroups that take part in the exchanges
   if constexpr (LOCAL) {
     __shared__ int local_rank_s;
@@ -500,6 +685,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     nslots = c.local_n;
   }
   const int slot = LOCAL ? wg : (int)blockIdx.x;           // my exchange record
+  // chip-wide launches: the exchange is a tree over the XCDs (grid_exchange8_hier); where am I in it?
+  constexpr bool kHier = !LOCAL && PISO_PERSIST1_HIER != 0;
+  unsigned hx = 0;
+  __shared__ int hier_s[kHier ? 4 : 1];
+  if constexpr (kHier) {
+    hx = hier_enter(c, hier_s);
+    if (hier_s[1]) return;                                 // (every workgroup of the launch fails this the same way)
+  }
   int j0[NQ], tx0[NQ];
   bool has[NQ];
 #pragma unroll
@@ -519,7 +712,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // addresses, the row capacity - is fetched from the kernarg segment where it is used (karg): it used to occupy ~30 SGPRs in
   // EVERY wave, which came back as v_readlane reloads in a loop that is bound by VALU issue (113 spilled SGPRs, 17-19 us per
   // iteration against 11 for the single-GPU kernel).
-  typedef Persist1Kargs<T, SlabCtl> KArgs;
+  typedef Persist1Kargs<T, std::conditional_t<SLAB, SlabCtl, NoSlab>> KArgs;
   constexpr unsigned sl_off = (unsigned)offsetof(KArgs, sl);
   constexpr unsigned pv_off = sl_off + (unsigned)offsetof(SlabCtl, pv);
   unsigned ef[NQ];
@@ -567,7 +760,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // ---- the state of the two-kernel path: r and the direction p_{k-1} of my regions into registers, x into LDS
   const T alpha0 = pend ? uniform(a.scal[SC_ALPHA]) : (T)0;   // pend: x still lacks alpha p of the iteration before k_begin
   Vec<T, V> rr[NQ][R], pp[NQ][R];
-  unsigned vT[NQ], vEnd[NQ];                               // vEnd: vT in lanes 0 and 63, beyond any buffer (also + a row offset) elsewhere
+  // kPack (regions of more than two rows): the END CELLS of a region's rows - what the strips to the left and right read - are
+  // published as one packed block per region instead of in place: entry (side, row) = the 16 bytes of lane 0 (side 0) or lane 63
+  // (side 1), 2 x R x 16 bytes at the start of the region's SECOND row of the z' buffer (interior rows of that buffer are
+  // otherwise unused).  In place every end cell dirtied a cache line of its own in the writer's L2 and was fetched as a line of
+  // its own by the reader: 28 + 28 lines per region and iteration against 4 + 4 - and ~1 MB per XCD of L2 capacity that the
+  // coefficient rows (4.19 MB per XCD at 2048^2 on a 4 MB L2) were missing.
+  constexpr bool kPack = PISO_PERSIST1_PACK != 0 && R > 2 && V == 2;
+  unsigned vT[NQ], vEnd[NQ];                               // vEnd: where lanes 0 and 63 publish their end cells, beyond any buffer elsewhere
   // copies of r (registers) and of the direction (LDS / registers, `edge`) on the ring around my regions
   Vec<T, V> rhb[NQ], rha[NQ], pnb[NQ], pna[NQ];
   T eR[NQ], edge[NQ];
@@ -579,6 +779,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       const int cq = (tx0[q] * 64 + lane) * V;
       vT[q] = (unsigned)(cq * sizeof(T));
       vEnd[q] = (!kLean || lane == 0 || lane == 63) ? vT[q] : 0x80000000u;
+      if constexpr (kPack) vEnd[q] = lane == 0 ? (unsigned)(tx0[q] * 64 * V * sizeof(T)) : (lane == 63 ? (unsigned)(tx0[q] * 64 * V * sizeof(T)) + (unsigned)(R * 16) : 0x80000000u);
       T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
 #pragma unroll
       for (int jj = 0; jj < R; ++jj) {
@@ -640,6 +841,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   T ncells = (T)((double)nx * (double)ny);
   if constexpr (SLAB) ncells = (T)sl.ncells;
   if constexpr (RAGGED) ncells = (T)a.ncells;
+  ncells = uniform(ncells);                                 // (in scalar registers, not in a vector register pair held across the loop)
   // RAGGED: are my columns / the columns next to my strip / the rows around my regions cells of the true system?
   bool col_ok[NQ], lcol_ok[NQ], rcol_ok[NQ];
 #pragma unroll
@@ -693,9 +895,12 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // byte offset of row j0[q] + jj: recomputed at every use (two scalar instructions) from a value the optimiser cannot see
   // through - hoisted out of the unrolled row loops the 2 x 16 products live in SGPRs that spill, and a spilled SGPR comes back
   // through v_readlane, a VALU slot of a loop that is bound by VALU issue
-  auto row_base = [&](int q, int jj, unsigned row_bytes) __attribute__((always_inline)) -> unsigned {
+  auto row_base = [&](int q, int jj, unsigned row_bytes, bool coef = false) __attribute__((always_inline)) -> unsigned {
     unsigned j = (unsigned)j0[q];
     asm volatile("" : "+s"(j));
+#ifdef PISO_EXP_ONEROW    // experiment (wrong results): every row of a region reads [1: and publishes to] the region's first row - all loads hit cache
+    if (PISO_EXP_ONEROW == 1 || coef) return j * row_bytes;
+#endif
     return (j + (unsigned)jj) * row_bytes;
   };
   auto coef_offset = [&](int q) __attribute__((always_inline)) -> unsigned {
@@ -714,12 +919,18 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // fabric, ~6 TB/s of coefficient rows, not at the speed of their arithmetic.)
   constexpr bool kZigZag = PISO_PERSIST1_ZIGZAG != 0 && (!SLAB || PISO_PERSIST1_ZIGZAG_SLAB != 0) && (NQ == 1 || PISO_PERSIST1_ZIGZAG_SMALL != 0);
   constexpr bool kPrefetchBehindDrain = PISO_PERSIST1_PREFETCH_BEHIND_DRAIN != 0 && !kZigZag;
+  // kAhead: z' = L p of the first rows of the U pass does not depend on alpha - it is computed WHILE the exchange's records travel
+  // (behind the publish, in front of the polling: the SIMDs have nothing else to do for a microsecond or two) and kept in
+  // registers; U then skips the stencil of those rows.  With the back-and-forth order these are the rows D ended with: their
+  // coefficients are still in registers.  Same instructions on the same registers as D's z': bitwise the same values.
+  constexpr int kAhead = (kHier && kZigZag && NQ == 1 && NT == 16 && SYM && RECON && sizeof(T) == 8 && sizeof(CT) == 4) ? PISO_PERSIST1_AHEAD : 0;
+  static_assert(kAhead <= Dw || kAhead == 0, "the rows computed ahead are rows whose coefficients D left in registers");
   constexpr int kRes = (NQ == 1 && NT == 16 && SYM && RECON) ? PISO_PERSIST1_RESIDENT : 0;
   auto issue_coef = [&](int t) __attribute__((always_inline)) {
     if (t < kRes && !first_fill) return;
     const int q = t / R, jj = t - q * R;
     const unsigned vCq = coef_offset(q);
-    const unsigned sT = row_base(q, jj, rowT), sC = row_base(q, jj, rowC);
+    const unsigned sT = row_base(q, jj, rowT, true), sC = row_base(q, jj, rowC, true);
     cS[t] = bld<CT, V>(RoS, vCq, sC); cW[t] = bld<CT, V>(RoW, vCq, sC);
     if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vCq, sC); cN[t] = bld<CT, V>(RoN, vCq, sC); }
     if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
@@ -815,6 +1026,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     const unsigned sT = row_base(q, jj, rowT);
     if (jj == 0 || jj == R - 1) {
       bst<T, V, kPub>(Rd, vT[q], sT, val);
+      if constexpr (kPack) bst<T, V, kPub>(Rd, vEnd[q], row_base(q, 1, rowT) + (unsigned)(jj * 16), val);    // (its end cells into the packed block as well)
       if constexpr (SLAB && !PISO_X3) {
         // my first row is the row ABOVE the lower neighbour's slab (its side 1), my last row the row BELOW the upper one's (side 0)
         if (jj == 0) {
@@ -832,7 +1044,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       // the two end cells of the row: lanes 0 and 63 store their cells of the row (16 bytes each; a lane's inner cell is written
       // too and never read), every other lane carries an offset beyond the buffer and its store is dropped by the range check -
       // no exec mask to build, no data to select (2 compares + 2 selects per row in a loop that is bound by VALU issue)
-      if constexpr (kLean) {
+      if constexpr (kPack) {
+        bst<T, V, kPub>(Rd, vEnd[q], row_base(q, 1, rowT) + (unsigned)(jj * 16), val);
+      } else if constexpr (kLean) {
         bst<T, V, kPub>(Rd, vEnd[q], sT, val);
       } else {
         const bool last = lane == 63;
@@ -850,16 +1064,22 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       int side, er, lane_now = lane;
-      if constexpr (SLAB) asm volatile("" : "+v"(lane_now));
+      asm volatile("" : "+v"(lane_now));                    // (the ring offset is recomputed here: hoisted, it is one more register across the row loops - spilled)
       ring_lane(lane_now, R, side, er);
       int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
       if (cc < 0) cc = a.per_x ? nx - 1 : -1;
       else if (cc >= nx) cc = a.per_x ? 0 : -1;
-      const unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
+      unsigned vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
+      if constexpr (kPack) {
+        // the neighbouring strip's packed block: its side-1 entry (its lane 63, whose last cell is my left neighbour) or its side-0
+        // entry (its lane 0, first cell), row `er`
+        const int strip = (cc >= 0) ? cc / (64 * V) : 0;
+        const unsigned ent = (side == 0) ? (unsigned)(R * 16 + er * 16 + (V - 1) * (int)sizeof(T)) : (unsigned)(er * 16);
+        vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + 1) * rowT + (unsigned)(strip * 64 * V * (int)sizeof(T)) + ent : 0xffffffffu;
+      }
       eZ[q] = bld1<T, kAgent>(Rz, vo, 0);
       bool vbq, vaq;
       const int jb = row_wrap(j0[q] - 1, vbq), ja = row_wrap(j0[q] + R, vaq);
-      const unsigned hb = vbq ? vT[q] : 0xffffffffu, ha = vaq ? vT[q] : 0xffffffffu;   // beyond a wall: out of range -> 0
       if constexpr (SLAB && !PISO_X2) {                                  // (wave-uniform branches: no per-lane offset registers to keep)
         if (!(ef[q] & 4u)) hbZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] - 1) * rowT);
         else if (ef[q] & 1u) {
@@ -880,8 +1100,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           for (int e = 0; e < V; ++e) haZ[q].v[e] = 0;
         }
       } else {
-      hbZ[q] = bld<T, V, kAgent>(Rz, hb, (unsigned)jb * rowT);
-      haZ[q] = bld<T, V, kAgent>(Rz, ha, (unsigned)ja * rowT);
+      // (beyond a wall: a resource of no bytes - the load is dropped by the range check and returns 0; a per-lane offset that says
+      // the same is one more vector register across the row loops)
+      hbZ[q] = bld<T, V, kAgent>(make_rsrc(a.zp[k & 1], vbq ? nbytesT : 0u), vT[q], (unsigned)jb * rowT);
+      haZ[q] = bld<T, V, kAgent>(make_rsrc(a.zp[k & 1], vaq ? nbytesT : 0u), vT[q], (unsigned)ja * rowT);
       }
     }
   };
@@ -973,7 +1195,21 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         }
       }
     };
-    healthy = grid_exchange8<T, LOCAL>(c, sD, epoch, smem, slot, nslots, prefetch_u, (kPersistDiag && c.timing) ? tsub : nullptr);
+    Vec<T, V> zs[kAhead > 0 ? kAhead : 1];
+    auto z_ahead = [&]() __attribute__((always_inline)) {
+      if constexpr (kAhead > 0) {
+        if (has[0]) {
+          ring_issue(NT - 1);
+#pragma unroll
+          for (int tt = 0; tt < kAhead; ++tt) {
+            if (tt + 1 < kAhead) ring_issue(NT - 2 - tt);
+            zs[tt] = zrow(NT - 1 - tt);
+          }
+        }
+      }
+    };
+    if constexpr (kHier) healthy = grid_exchange8_hier<T>(c, sD, epoch, smem, hx, hier_s + 2, z_ahead, (kPersistDiag && c.timing) ? tsub : nullptr);
+    else healthy = grid_exchange8<T, LOCAL>(c, sD, epoch, smem, slot, nslots, prefetch_u, (kPersistDiag && c.timing) ? tsub : nullptr);
     if constexpr (SLAB && !PISO_X1) { if (healthy) healthy = xgpu_exchange8<T>(sl_off, sD, epoch, smem + 2 * kX1Sm); }
     tick(1);
     if (!healthy) break;
@@ -998,16 +1234,18 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     lU[0] = 0; lU[1] = 0;
     int cnt_wave = 0;                                        // #{|r_{k+1}| >= accuracy} of the whole wave, counted on the scalar unit
     if (has[0]) {
-      issue_halos(Rz);
-      ring_issue(kZigZag ? NT - 1 : 0);
+      constexpr int kHaloAt = (NT == 16) ? PISO_PERSIST1_HALO_AT : 0;     // the row step of U in front of which the neighbours' z' is requested
+      if constexpr (kHaloAt == 0) issue_halos(Rz);
+      if constexpr (kAhead < NT) ring_issue(kZigZag ? NT - 1 - kAhead : 0);
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
         const int t = kZigZag ? NT - 1 - tt : tt;
         const int q = t / R, jj = t - q * R;
-        if (tt + 1 < NT) ring_issue(kZigZag ? t - 1 : t + 1);
+        if constexpr (kHaloAt > 0) { if (tt == kHaloAt) issue_halos(Rz); }
+        if (tt + 1 < NT && tt + 1 >= kAhead) ring_issue(kZigZag ? t - 1 : t + 1);
         T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V + jj * 64 * V;
         Vec<T, V> xv = ldv<T, V>(xl);                        // x += alpha p (:303); the LDS latency hides under the stencil
-        const Vec<T, V> z = zrow(t);
+        const Vec<T, V> z = (tt < kAhead) ? zs[tt < kAhead ? tt : 0] : zrow(t);
 #pragma unroll
         for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha, pp[q][jj].v[e], xv.v[e]);
         stv<T, V>(xl, xv);
@@ -1070,20 +1308,42 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     for (int q = 0; q < 5; ++q) c.timing[q * nslots + slot] += tacc[q];            // (XCD-local mode: the group's ranks, not the launch's blocks)
 #pragma unroll
     for (int q = 0; q < 4; ++q) c.timing[(5 + q) * nslots + slot] += tsub[q];
+    c.timing[9 * nslots + slot] = (unsigned long long)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);   // the XCD I ran on
+    c.timing[10 * nslots + slot] = (unsigned long long)wg;                                                              // the band of regions I own
   }
   // ---- the last U's sum r and count are only known per workgroup: one more exchange (once per segment)
   T tOut[3] = {rz_next, sumr, cnt_last};
   if (!first && healthy && !st.done) {
     T sX[kX1Values] = {0, 0, 0, 0, 0, 0, lU[0], lU[1]};
     ++epoch;
-    healthy = grid_exchange8<T, LOCAL>(c, sX, epoch, smem, slot, nslots);
+    if constexpr (kHier) healthy = grid_exchange8_hier<T>(c, sX, epoch, smem, hx, hier_s + 2);     // (nothing to compute ahead)
+    else healthy = grid_exchange8<T, LOCAL>(c, sX, epoch, smem, slot, nslots);
     if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl_off, sX, epoch, smem + 2 * kX1Sm); }
     tOut[1] = sX[6]; tOut[2] = sX[7];
   }
 
   // ---- back to the global-memory state of the two-kernel path (iteration k reads its direction from p[k & 1])
+  // (the pointers of the exit are read again from the kernarg segment: held in SGPRs across the loop they are spilled, and the
+  // reloads of OTHER spilled values land in the row loops)
+#if PISO_PERSIST1_EXIT_KARGS
+  struct { T *r, *x, *pk, *partsB, *scal; const T* gB; CgState* state; int nB; } ax;       // (pk: p[k & 1])
+  struct { int* err; } cx;
   {
-    const rsrc_t Rr = make_rsrc(a.r, nbytesT), Rx = make_rsrc(a.x, nbytesT), Rp = make_rsrc(a.p[k & 1], nbytesT);
+    typedef CgArgs<T> A;
+    constexpr unsigned ao = (unsigned)offsetof(KArgs, a), co = (unsigned)offsetof(KArgs, c);
+    ax.r = karg<T*>(ao + (unsigned)offsetof(A, r)); ax.x = karg<T*>(ao + (unsigned)offsetof(A, x));
+    ax.pk = karg<T*>(ao + (unsigned)offsetof(A, p) + 8u * (unsigned)(k & 1));
+    ax.partsB = karg<T*>(ao + (unsigned)offsetof(A, partsB)); ax.scal = karg<T*>(ao + (unsigned)offsetof(A, scal));
+    ax.gB = karg<const T*>(ao + (unsigned)offsetof(A, gB)); ax.state = karg<CgState*>(ao + (unsigned)offsetof(A, state));
+    ax.nB = karg<int>(ao + (unsigned)offsetof(A, nB));
+    cx.err = karg<int*>(co + (unsigned)offsetof(PersistCtl, err));
+  }
+#else
+  struct { T *r, *x, *pk, *partsB, *scal; const T* gB; CgState* state; int nB; } ax = {a.r, a.x, a.p[k & 1], a.partsB, a.scal, a.gB, a.state, a.nB};
+  const PersistCtl& cx = c;
+#endif
+  {
+    const rsrc_t Rr = make_rsrc(ax.r, nbytesT), Rx = make_rsrc(ax.x, nbytesT), Rp = make_rsrc(ax.pk, nbytesT);
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
       if (has[q]) {
@@ -1096,7 +1356,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           bst<T, V>(Rx, vT[q], sT, ldv<T, V>(xl + jj * 64 * V));
         }
         if constexpr (SLAB) {                               // the two-kernel slab path continues from the halo rows of r and p
-          const rsrc_t RrH = make_rsrc(a.r - nx, nbytesH), RpH = make_rsrc(a.p[k & 1] - nx, nbytesH);
+          const rsrc_t RrH = make_rsrc(ax.r - nx, nbytesH), RpH = make_rsrc(ax.pk - nx, nbytesH);
           T* hs = halo_s + (kParkHalos ? (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V : 0);
           if constexpr (kParkHalos) { pnb[q] = ldv<T, V>(hs); pna[q] = ldv<T, V>(hs + 64 * V); }
           if (ef[q] & 1u) { bst<T, V>(RrH, vT[q], 0u, rhb[q]); bst<T, V>(RpH, vT[q], 0u, pnb[q]); }
@@ -1106,17 +1366,17 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   }
   if (wg == 0) {                                           // (= blockIdx.x 0, or the first arrival of the XCD-local group)
     // the next launch (cg_k1 with do_check, or another segment) finds the last K2-totals in record 0 of partsB
-    for (int b = threadIdx.x; b < a.nB; b += kPersistThreads) {
+    for (int b = threadIdx.x; b < ax.nB; b += kPersistThreads) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a.partsB[q * kMaxPartials + b] = (b == 0) ? tOut[q] : (T)0;
+      for (int q = 0; q < 3; ++q) ax.partsB[q * kMaxPartials + b] = (b == 0) ? tOut[q] : (T)0;
     }
     if constexpr (SLAB) {
-      if (threadIdx.x == 0) { T* g = const_cast<T*>(a.gB); g[0] = tOut[0]; g[1] = tOut[1]; g[2] = tOut[2]; }   // (already summed over all GPUs)
+      if (threadIdx.x == 0) { T* g = const_cast<T*>(ax.gB); g[0] = tOut[0]; g[1] = tOut[1]; g[2] = tOut[2]; }   // (already summed over all GPUs)
     }
     if (threadIdx.x == 0) {
-      a.scal[SC_PZ] = pz; a.scal[SC_VS] = vs; a.scal[SC_ALPHA] = alpha;
-      a.state[0] = st; a.state[1] = st;
-      if (!healthy) *c.err = 1;
+      ax.scal[SC_PZ] = pz; ax.scal[SC_VS] = vs; ax.scal[SC_ALPHA] = alpha;
+      ax.state[0] = st; ax.state[1] = st;
+      if (!healthy) *cx.err = 1;
     }
   }
 }

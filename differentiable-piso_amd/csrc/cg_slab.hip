@@ -118,7 +118,7 @@ __global__ void slab_gap_to_sum(const unsigned* out2, T* out, int force) {
     out[0] = (T)(((gap > 1e-5f * scale && gap > 1e-30f) || force) ? 1 : 0);
   }
 }
-constexpr size_t kSlabPersistWsWords = (size_t)2 * kPersistMaxGrid * 32 + 64;   // exchange records (2 x grid x 128 B) + error flag
+constexpr size_t kSlabPersistWsWords = kPersistWsWordsAll;   // exchange records + control words (cg_persist.h)
 // loopback all-reduce: bufs of the G virtual ranks live `stride` apart; sum in rank order, write to all
 template <typename T>
 __global__ void loop_allreduce(T* base, int G, size_t stride, int count) {
@@ -374,6 +374,7 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
       pc.rec = reinterpret_cast<unsigned long long*>(persist_ws);
       pc.err = reinterpret_cast<int*>(persist_ws + kSlabPersistWsWords - 16);
       pc.nreg = shape.nreg; pc.ntx = shape.ntx;
+      pc.xcd = reinterpret_cast<int*>(persist_ws + kPersistRecWords);
       PISO_HIP_CHECK(hipMemsetAsync(persist_ws, 0, kSlabPersistWsWords * sizeof(unsigned), stream));
       sl.pv = make_view(comm.rccl, comm.periodic_y);
       sl.ncells = global_cells;
@@ -421,7 +422,7 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
           if (rc != PISO_OK) return rc;
         }
         pc.epoch0 = (c->launches++ & 0xffffu) << 16;
-        PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, (size_t)2 * kPersistMaxGrid * 128, stream));
+        PISO_HIP_CHECK(hipMemsetAsync(pc.rec, 0, kPersistZeroBytes, stream));   // records (both levels) + XCD arrivals
         bool launched = false;
         if constexpr (kCanSym) {
           if (symmetric) { launch_slab_segment<T, CT, RECON, true>(shape.R, shape.grid, R[0].a, pc, k, ke, sv, pending ? 1 : 0, sl, stream); launched = true; }

@@ -27,6 +27,7 @@ struct Ctl {
   u64* grp;                           // V2: [G/16][8]
   u64* loc;                           // V3: XCC-local
   int* xcc;                           // out: XCC id per block
+  int* xcnt;                          // V30: arrivals per XCD
 };
 
 // ---------------- V0: counter + fence + partials (the first version of cg_persist.h; kept as the baseline of the comparison)
@@ -526,6 +527,74 @@ __device__ void exch_v2(const Ctl& c, double (&v)[3], unsigned epoch, double* sm
   wg_broadcast(v, smem, epoch);
 }
 
+
+// ---------------- V30: two levels that follow the hardware: level 1 inside an XCD through that XCD's L2 (records stored without
+// sc1 - they stay in the L2 - and polled with sc1 loads, which bypass the L1 and are served by the L2), level 2 = the eight XCD
+// records through the fabric (sc1 stores, sc1 loads), published by the first arrival of every XCD.  xcd / rank: the XCC id of the
+// workgroup and its arrival rank there (one atomic per launch).  AoS records of 8 words, coalesced cooperative polls as V7.
+template <bool LEADER_ONLY>   // V31: only the first arrival of an XCD reads the level-1 records (a tree: 256 -> 8 leaders -> everybody)
+__device__ void exch_v30(const Ctl& c, double (&v)[3], unsigned epoch, double* smem, int xcd, int rank, int per_xcd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* sm = smem + (epoch & 1) * 32;
+  for (int q = 0; q < 3; ++q) v[q] = wave_sum(v[q]);
+  if (lane == 0) for (int q = 0; q < 3; ++q) sm[q * kWaves + wave] = v[q];
+  __syncthreads();
+  if (wave == 0) {
+    const int wq = lane & 7, grp = lane >> 3;
+    u64* loc = c.loc + (size_t)(epoch & 1) * kMaxG * 8 + (size_t)xcd * 32 * 8;
+    if (lane < 6) {
+      double s = 0;
+      for (int w = 0; w < kWaves; ++w) s += sm[(lane >> 1) * kWaves + w];
+      const u64 bits = __double_as_longlong(s);
+      const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+      __hip_atomic_store(loc + (size_t)rank * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    u64 w[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { w[i] = 0; ok[i] = !(wq < 6 && (i * 8 + grp) < per_xcd) || (LEADER_ONLY && rank != 0); }
+    unsigned spins = 0;
+    while (true) {
+      bool all = true;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (!ok[i]) w[i] = __hip_atomic_load(loc + (size_t)i * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!ok[i]) ok[i] = ((unsigned)(w[i] & 0xffffffffull) == epoch);
+        all = all && ok[i];
+      }
+      if (__all(all) || ++spins > (1u << 20)) break;
+    }
+    double acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u64 nxt = __shfl_down(w[i], 1, 64);
+      const bool act = wq < 6 && !(wq & 1) && (i * 8 + grp) < per_xcd;
+      acc += act ? __longlong_as_double((w[i] >> 32) | (nxt & 0xffffffff00000000ull)) : 0.0;
+    }
+    acc += __shfl_xor(acc, 8, 64); acc += __shfl_xor(acc, 16, 64); acc += __shfl_xor(acc, 32, 64);   // lane 2 q: XCD total of value q
+    u64* grpr = c.grp + (size_t)(epoch & 1) * 64;
+    if (rank == 0 && lane < 6) {
+      const double s = __shfl(acc, lane & 6, 64);
+      const u64 bits = __double_as_longlong(s);
+      const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
+      __hip_atomic_store(grpr + (size_t)xcd * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    u64 g = 0;
+    const bool need = wq < 6;
+    while (true) {
+      g = __hip_atomic_load(grpr + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__all(!need || (unsigned)(g & 0xffffffffull) == epoch) || ++spins > (1u << 21)) break;
+    }
+    const u64 nxt = __shfl_down(g, 1, 64);
+    double t = (wq < 6 && !(wq & 1)) ? __longlong_as_double((g >> 32) | (nxt & 0xffffffff00000000ull)) : 0.0;
+    t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+    for (int q = 0; q < 3; ++q) v[q] = __shfl(t, 2 * q, 64);
+  }
+  wg_broadcast(v, smem, epoch);
+}
+
 template <int VAR>
 __global__ __launch_bounds__(kThreads) void bench(Ctl c, int iters, double* out, u64* ticks) {
   __shared__ double smem[96];
@@ -535,6 +604,17 @@ __global__ __launch_bounds__(kThreads) void bench(Ctl c, int iters, double* out,
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
     c.xcc[blockIdx.x] = (int)(x & 0xf);
   }
+  __shared__ int xr[2];
+  if (VAR == 30 || VAR == 31) {
+    if (threadIdx.x == 0) {
+      unsigned x;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+      xr[0] = (int)(x & 7);
+      xr[1] = __hip_atomic_fetch_add(c.xcnt + (x & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
+  const int my_xcd = VAR >= 30 ? xr[0] : 0, my_rank = VAR >= 30 ? xr[1] : 0;
   const u64 t0 = wall_clock64();
   for (int it = 1; it <= iters; ++it) {
     double v[3] = {1.0, (double)(threadIdx.x & 3), (double)it * 1e-3};
@@ -561,6 +641,8 @@ __global__ __launch_bounds__(kThreads) void bench(Ctl c, int iters, double* out,
     if (VAR == 13) exch_v10<4, false>(c, v, (unsigned)it, smem);
     if (VAR == 14) exch_v10<12, false>(c, v, (unsigned)it, smem);
     if (VAR == 9) exch_v8<1>(c, v, (unsigned)it, smem);
+    if (VAR == 30) exch_v30<false>(c, v, (unsigned)it, smem, my_xcd, my_rank, (int)gridDim.x / 8);
+    if (VAR == 31) exch_v30<true>(c, v, (unsigned)it, smem, my_xcd, my_rank, (int)gridDim.x / 8);
     acc += v[0] + v[1] + v[2];
   }
   const u64 t1 = wall_clock64();
@@ -571,14 +653,16 @@ int main(int argc, char** argv) {
   const int G = argc > 1 ? atoi(argv[1]) : 256, iters = argc > 2 ? atoi(argv[2]) : 2000;
   Ctl c;
   CK(hipMalloc((void**)&c.bar, 256)); CK(hipMalloc((void**)&c.parts, 3 * kMaxG * 8));
-  CK(hipMalloc((void**)&c.rec, kMaxG * 64)); CK(hipMalloc((void**)&c.grp, 16 * 64)); CK(hipMalloc((void**)&c.loc, kMaxG * 64));
-  CK(hipMalloc((void**)&c.xcc, kMaxG * 4));
+  CK(hipMalloc((void**)&c.rec, kMaxG * 64)); CK(hipMalloc((void**)&c.grp, 16 * 64)); CK(hipMalloc((void**)&c.loc, 2 * kMaxG * 64));
+  CK(hipMalloc((void**)&c.xcc, kMaxG * 4)); CK(hipMalloc((void**)&c.xcnt, 64));
   double* out; u64* ticks;
   CK(hipMalloc((void**)&out, kMaxG * 8)); CK(hipMalloc((void**)&ticks, kMaxG * 8));
   const double expect = (double)G * kThreads * 1.0 + (double)G * (kThreads / 4) * 6.0;
-  for (int var = 0; var < 23; ++var) {
+  for (int var = 0; var < 32; ++var) {
+    if (var > 22 && var < 30) continue;
+    if (var >= 30 && G % 8 != 0) continue;
     for (int rep = 0; rep < 2; ++rep) {
-      CK(hipMemset(c.bar, 0, 256)); CK(hipMemset(c.rec, 0, kMaxG * 64)); CK(hipMemset(c.grp, 0, 16 * 64));
+      CK(hipMemset(c.bar, 0, 256)); CK(hipMemset(c.rec, 0, kMaxG * 64)); CK(hipMemset(c.grp, 0, 16 * 64)); CK(hipMemset(c.loc, 0, 2 * kMaxG * 64)); CK(hipMemset(c.xcnt, 0, 64));
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       CK(hipEventRecord(e0));
       if (var == 0) bench<0><<<G, kThreads>>>(c, iters, out, ticks);
@@ -603,6 +687,8 @@ int main(int argc, char** argv) {
       if (var == 12) bench<12><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 13) bench<13><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 14) bench<14><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 30) bench<30><<<G, kThreads>>>(c, iters, out, ticks);
+      if (var == 31) bench<31><<<G, kThreads>>>(c, iters, out, ticks);
       if (var == 9 && G <= 64) bench<9><<<G, kThreads>>>(c, iters, out, ticks);
       CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));

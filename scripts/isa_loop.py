@@ -35,19 +35,30 @@ def resources(remarks, key):
 
 
 def loops(lines):
-    labels = {}
+    """lines of the largest loop: the blocks the assembler's comments attribute to one loop header ("in Loop: Header=BBn_m" /
+    "Parent Loop BBn_m"), header block included - block placement may put unrelated blocks between them."""
+    blocks, cur, name = {}, None, None
     for n, l in enumerate(lines):
         m = re.match(r"^(\.LBB\d+_\d+):", l)
         if m:
-            labels[m.group(1)] = n
-    best = None
-    for n, l in enumerate(lines):
-        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
-        if m and m.group(1) in labels and labels[m.group(1)] < n:
-            a = labels[m.group(1)]
-            if best is None or n - a > best[1] - best[0]:
-                best = (a, n)
-    return best
+            name, cur = m.group(1)[2:], None
+            hdr = None
+            for k in range(n, min(n + 4, len(lines))):
+                mm = re.search(r"(?:in Loop: Header=|Parent Loop |Loop Header: Depth=1)(BB\d+_\d+)?", lines[k])
+                if mm:
+                    hdr = mm.group(1) or name
+                    break
+                if k > n and not lines[k].lstrip().startswith(";"):
+                    break
+            cur = hdr
+        elif re.match(r"^; %bb\.\d+:", l.strip()):
+            mm = re.search(r"in Loop: Header=(BB\d+_\d+)", " ".join(lines[n:n + 2]))
+            cur = mm.group(1) if mm else None
+        if cur:
+            blocks.setdefault(cur, []).append(l)
+    if not blocks:
+        return None
+    return max(blocks.values(), key=len)
 
 
 def mix(body):
@@ -75,7 +86,7 @@ def main():
             r.get("VGPRs"), r.get("SGPRs Spill"), r.get("VGPRs Spill"), r.get("ScratchSize [bytes/lane]"), r.get("LDS Size [bytes/block]")))
         lp = loops(lines)
         if lp:
-            c = mix(lines[lp[0]:lp[1]])
+            c = mix(lp)
             valu = sum(v for k, v in c.items() if k.startswith("v_"))
             print("   largest loop: %d instructions, valu %d, readlane %d, writelane %d, scratch %d, fp64 %d, cvt %d, dpp %d, s_load %d, vmem %d, ds %d" % (
                 sum(c.values()), valu, c["v_readlane_b32"], c["v_writelane_b32"], sum(v for k, v in c.items() if k.startswith("scratch_")),
