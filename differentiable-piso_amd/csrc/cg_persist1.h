@@ -162,11 +162,17 @@ __device__ __forceinline__ F karg(unsigned off) {
 #ifndef PISO_PERSIST1_PACK
 #define PISO_PERSIST1_PACK 1                    // end cells of a region's rows published as one packed block per region (see kPack)
 #endif
+#ifndef PISO_PERSIST1_NT_PUB
+#define PISO_PERSIST1_NT_PUB 0
+#endif
+#ifndef PISO_PERSIST1_NT_HALO
+#define PISO_PERSIST1_NT_HALO 0
+#endif
 #ifndef PISO_PERSIST1_HALO_AT
 #define PISO_PERSIST1_HALO_AT 0                 // 16-row regions: the U row step in front of which the neighbours' z' rows are requested (0: behind the exchange)
 #endif
 #ifndef PISO_PERSIST1_POLL_DELAY2
-#define PISO_PERSIST1_POLL_DELAY2 0             // s_sleep units in front of the first polling pass of the tree's second level
+#define PISO_PERSIST1_POLL_DELAY2 24            // s_sleep units in front of the first polling pass of the tree's second level
 #endif
 #ifndef PISO_PERSIST1_POLL_SLEEP
 #define PISO_PERSIST1_POLL_SLEEP 1              // s_sleep units (64 cycles) between two polling passes
@@ -628,7 +634,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
                                                                std::conditional_t<SLAB, SlabCtl, NoSlab> sl = {}) {
   static_assert(!(SLAB && RAGGED), "a slab is never padded");
   static_assert(!(SLAB && LOCAL), "a slab's neighbours are other GPUs");
-  constexpr int kPub = LOCAL ? kPlain : kAgent;            // cache policy of what other workgroups read inside the launch
+  // cache policy of what other workgroups read inside the launch; PISO_PERSIST1_NT_PUB / _NT_HALO add the non-temporal hint (aux
+  // bit 1): a published row is never read again by its writer and read once by its reader - it need not stay in either L2
+  constexpr int kPub = (LOCAL ? kPlain : kAgent) | (PISO_PERSIST1_NT_PUB != 0 && !LOCAL ? 2 : 0);
+  constexpr int kHalo = kAgent | (PISO_PERSIST1_NT_HALO != 0 && !LOCAL ? 2 : 0);
   constexpr int V = 16 / sizeof(T);                        // 16-byte lane accesses
   static_assert(R * NQ <= 16 && 2 * R <= 64, "at most 16 rows per wave; the edge columns of a region fit one wave-wide load");
   static_assert(!SLAB || sizeof(T) == 8, "mailbox rows hold 8-byte elements");
@@ -1077,11 +1086,11 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         const unsigned ent = (side == 0) ? (unsigned)(R * 16 + er * 16 + (V - 1) * (int)sizeof(T)) : (unsigned)(er * 16);
         vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + 1) * rowT + (unsigned)(strip * 64 * V * (int)sizeof(T)) + ent : 0xffffffffu;
       }
-      eZ[q] = bld1<T, kAgent>(Rz, vo, 0);
+      eZ[q] = bld1<T, kHalo>(Rz, vo, 0);
       bool vbq, vaq;
       const int jb = row_wrap(j0[q] - 1, vbq), ja = row_wrap(j0[q] + R, vaq);
       if constexpr (SLAB && !PISO_X2) {                                  // (wave-uniform branches: no per-lane offset registers to keep)
-        if (!(ef[q] & 4u)) hbZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] - 1) * rowT);
+        if (!(ef[q] & 4u)) hbZ[q] = bld<T, V, kHalo>(Rz, vT[q], (unsigned)(j0[q] - 1) * rowT);
         else if (ef[q] & 1u) {
           unsigned zoff;
           const rsrc_t Rm = mailbox_rows((unsigned)offsetof(SlabCtl, rows_own), k & 1, 0, zoff);
@@ -1090,7 +1099,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
 #pragma unroll
           for (int e = 0; e < V; ++e) hbZ[q].v[e] = 0;
         }
-        if (!(ef[q] & 8u)) haZ[q] = bld<T, V, kAgent>(Rz, vT[q], (unsigned)(j0[q] + R) * rowT);
+        if (!(ef[q] & 8u)) haZ[q] = bld<T, V, kHalo>(Rz, vT[q], (unsigned)(j0[q] + R) * rowT);
         else if (ef[q] & 2u) {
           unsigned zoff;
           const rsrc_t Rm = mailbox_rows((unsigned)offsetof(SlabCtl, rows_own), k & 1, 1, zoff);
@@ -1102,8 +1111,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       } else {
       // (beyond a wall: a resource of no bytes - the load is dropped by the range check and returns 0; a per-lane offset that says
       // the same is one more vector register across the row loops)
-      hbZ[q] = bld<T, V, kAgent>(make_rsrc(a.zp[k & 1], vbq ? nbytesT : 0u), vT[q], (unsigned)jb * rowT);
-      haZ[q] = bld<T, V, kAgent>(make_rsrc(a.zp[k & 1], vaq ? nbytesT : 0u), vT[q], (unsigned)ja * rowT);
+      hbZ[q] = bld<T, V, kHalo>(make_rsrc(a.zp[k & 1], vbq ? nbytesT : 0u), vT[q], (unsigned)jb * rowT);
+      haZ[q] = bld<T, V, kHalo>(make_rsrc(a.zp[k & 1], vaq ? nbytesT : 0u), vT[q], (unsigned)ja * rowT);
       }
     }
   };
