@@ -152,7 +152,7 @@ def build_mixing_layer(ny, nx, device, tol, max_it, reset):
                 dt=dt, lin=lin, ps=ps)
 
 
-def run_unrolled(P, steps, backward=True, clock=None):
+def run_unrolled(P, steps, backward=True, clock=None, keep=None):
     """K steps forward through the reference-signature run_piso_steps, then the reverse sweep of L = 1/2 |u_K|^2.
     clock (optional dict): 'fwd_s' / 'bwd_s' accumulate wall time with a device synchronisation between the two sweeps."""
     import torch
@@ -181,6 +181,8 @@ def run_unrolled(P, steps, backward=True, clock=None):
         if clock is not None:
             torch.cuda.synchronize()
             clock["bwd_s"] = clock.get("bwd_s", 0.0) + time.perf_counter() - t1
+    if keep is not None:          # (--dump-fields: the fields behind the loss, for the field-level parity tests of the sharded step)
+        keep.update(u=vn.staggered_tensor().detach(), p=out[4].data.detach(), du=vel_t.grad, dp=p_t.grad)
     return vel_t.grad, float(loss.detach()), warn
 
 
@@ -537,6 +539,15 @@ def main():
                          "child process per rank whose result becomes the headline (replicas beside it) - if the sharded run fails on "
                          "a node it has never met, the replicas line survives and the exit code says so")
     ap.add_argument("--grid-ny", type=int, default=0, help="rows of the grid if different from --grid (a taller periodic box)")
+    ap.add_argument("--lin-tol", type=float, default=0.0, help="tolerance of the advection solves if different from --tol (fixed-iteration "
+                    "pressure solves: --tol 1e-30 --max-iterations K --lin-tol 1e-6)")
+    ap.add_argument("--cg-persist", type=int, default=-1, choices=[-1, 0, 1], help="library option cg_persist: 0 forbids the persistent CG "
+                    "kernel (two-kernel iteration), 1 forces it, -1 by grid size")
+    ap.add_argument("--unshifted", action="store_true", help="pressure CG without the reference's rank-1 shift (laplace_rank_deficient = False): "
+                    "fixed-iteration runs of two summation orders stay comparable (DESIGN.md 4)")
+    ap.add_argument("--dump-fields", default="", help="directory: every rank writes ITS rows of u_K, p_K, dL/du_0, dL/dp_0 of the timed run to "
+                    "rank<r>.npz (tests/test_gpu_sharded_fields.py)")
+    ap.add_argument("--perturb-input", type=float, default=0.0, help=argparse.SUPPRESS)    # (diagnostics: relative white noise on the initial velocity)
     ap.add_argument("--self-check-child", action="store_true", help=argparse.SUPPRESS)      # (internal: one rank of the N > 1 self-check)
     ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)         # (internal: one rank of the 'auto' mode's slab-weak run)
     ap.add_argument("--replica-steps-per-s", type=float, default=0.0, help=argparse.SUPPRESS)
@@ -570,6 +581,13 @@ def main():
     ny_grid = n * world if slab_weak else (args.grid_ny if args.grid_ny > 0 else n)
     P = build_problem(n, device, args.tol, args.max_iterations, args.residual_reset, ny=ny_grid)
     slab = world > 1 and decomp in ("slab", "slab-weak")
+    if args.perturb_input > 0:
+        gen_ = torch.Generator(device="cpu").manual_seed(99)
+        P["vel_t"] = P["vel_t"] * (1.0 + args.perturb_input * torch.randn(P["vel_t"].shape, generator=gen_).to(device))
+    if args.unshifted:
+        P["ps"].laplace_rank_deficient = False
+    if args.lin_tol > 0:
+        P["lin"].accuracy = args.lin_tol
     if slab:
         from diffpiso.distributed import SlabCommunicator
         from diffpiso.sharding import StepSharding
@@ -602,6 +620,8 @@ def main():
 
     if share_gpu:
         N.set_option("cg_persist", 0)      # (two replicas' persistent kernels do not fit one GPU side by side)
+    elif args.cg_persist >= 0:
+        N.set_option("cg_persist", args.cg_persist)
     torch.cuda.reset_peak_memory_stats(device)
     for _ in range(args.warmup):
         run_unrolled(P, 1)
@@ -624,9 +644,19 @@ def main():
     clock = {}
     barrier()
     t0 = time.perf_counter()
-    grad, loss, warn = run_unrolled(P, args.steps, clock=clock)
+    keep = {} if args.dump_fields else None
+    grad, loss, warn = run_unrolled(P, args.steps, clock=clock, keep=keep)
     barrier()
     elapsed = time.perf_counter() - t0
+    if keep:
+        sh_ = P.get("sharding")
+        j0, j1, last = (sh_.j0, sh_.j1, 1 if sh_.last else 0) if sh_ is not None else (0, ny_grid, 1)
+        os.makedirs(args.dump_fields, exist_ok=True)
+        np.savez(os.path.join(args.dump_fields, "rank%d.npz" % rank), j0=j0, j1=j1, last=last,
+                 u_v=keep["u"][0, j0:j1 + last, :, 0].cpu().numpy(), u_u=keep["u"][0, j0:j1, :, 1].cpu().numpy(), p=keep["p"][0, j0:j1, :, 0].cpu().numpy(),
+                 du_v=keep["du"][0, j0:j1 + last, :, 0].cpu().numpy(), du_u=keep["du"][0, j0:j1, :, 1].cpu().numpy(),
+                 dp=keep["dp"][0, j0:j1, :, 0].cpu().numpy())
+        del keep
     ms_sum = (C.c_double * 4)()
     cnt = (C.c_longlong * 4)()
     N.lib.piso_cg_profile_read(ms_sum, cnt)
@@ -644,6 +674,7 @@ def main():
         loss, grad_norm = float(tot[0]), float(tot[2]) ** 0.5
         st_ = P["ps"].slab_comm.stats()
         sharded_info = {"ranks_seen": int(round(float(tot[1]))), "rows_per_rank": ny_grid // world, "halo_exchanges": P["sharding"].exchanges,
+                        "max_memory_allocated_bytes_rank0": int(torch.cuda.max_memory_allocated(device)),
                         "transport": st_["transport"],
                         "persistent_slab_iterations": st_["persistent_iterations"], "persistent_fallbacks": st_["persistent_fallbacks"],
                         "slab_solves_verified_against_true_residual": st_["solves_verified"], "verification_failures": st_["verification_failures"],
@@ -784,7 +815,14 @@ def main():
         # child process per rank (own process group on another port), with the contract's barrier / max-over-ranks timing inside:
         # its cross-GPU path has never met real xGMI before the driver's node, and an exception, a hang (600 s limit) or a crash
         # of the HIP runtime there must not cost the line this process is about to print.
+        import gc
         import subprocess
+        # The children run on the SAME GPUs: hand back what this process holds first - the replicas problem, its gradient, the K-step
+        # tape and the allocator blocks primed for it (the sharded step keeps globally indexed arrays, N times the one-GPU size per array)
+        P.clear()
+        grad = warn = None
+        gc.collect()
+        torch.cuda.empty_cache()
 
         def sharded_attempt(transport, port_offset, limit_s):
             """-> (child line of rank 0 or None, error or None, every rank's attempt ended well)"""

@@ -15,8 +15,8 @@ from .grids import (AABox, CLOSED, NO_SLIP, NO_STICK, OPEN, PERIODIC, SLIPPERY, 
                     StaggeredGrid, as_tensor, box, default_device, placeholder, stack_staggered_components,
                     unstack_staggered_tensor)
 from .piso import Physics, SimulationParameters, advection_matrix_cuda, explicit_H_csr, piso_step, pressure_extrapolation
-from .solvers import (LinearSolver, LinearSolverCudaMultiBicgstabILU, LinearSolverHipMultiBicgstabILU, LinearSolverScipy,
-                      PisoPressureSolverCudaCustom, PisoPressureSolverHip, PoissonSolver)
+from .solvers import (LinearSolver, LinearSolverCudaBicgstabILU, LinearSolverCudaMultiBicgstabILU, LinearSolverHipMultiBicgstabILU,
+                      LinearSolverScipy, PisoPressureSolverCudaCustom, PisoPressureSolverHip, PoissonSolver, mat_vec_mul_csr, print_residual)
 from .stencils import (arrange_rhs_term_tf, calculate_centered_shape, calculate_staggered_shape, convert_to_scipy_csr,
                        custom_padded, finite_volume_divergence, finite_volume_gradient_tensor, flatten_staggered_data,
                        padded_velocity_flat, stagger_flattened_data, vorticity)

@@ -141,6 +141,21 @@ def get_option(name):
     return v.value
 
 
+_window = (-1, -1, 0)
+
+
+def use_window(sharding):
+    """The row window of the library's element-wise / gather kernels (include/piso_hip.h: piso_set_row_window) is state of the
+    process; the package treats it as an attribute of every CALL: each kernel wrapper names the sharding (sharding.StepSharding) it
+    works for - None: the whole grid - right before it launches, so that two simulations in one process (a sharded training run next
+    to an un-sharded validation run, bench.py's other configurations) can never see each other's window."""
+    global _window
+    w = (-1, -1, 0) if sharding is None else (int(sharding.j0), int(sharding.j1), int(sharding.last))
+    if w != _window:
+        check(lib.piso_set_row_window(*w), "piso_set_row_window")
+        _window = w
+
+
 def cg_verify_stats():
     """(solves whose result was checked against the true residual, checks that failed) -- include/piso_hip.h."""
     runs, fails = C.c_longlong(0), C.c_int(0)

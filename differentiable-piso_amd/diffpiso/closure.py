@@ -4,8 +4,9 @@ Mirror of diffpiso/networks.py (fullyconv_network / initialise_fullyconv_network
 diffpiso/combined_training_integrated.py:399-411, 443-454: network input = cell-centred velocity (+ central pressure gradient),
 network output (2 channels at cell centres) resampled to the faces as the forcing term of piso_step.
 On the GPU the convolutions run on hand-written MFMA kernels (csrc/conv.hip: exact fp32 v_mfma_f32_16x16x4_f32, NHWC, fused
-leaky ReLU, forward / input gradient / weight gradient) behind `conv2d_leaky`; host tensors (the oracle chain of the
-tests) go through torch's conv2d.
+leaky ReLU, forward / input gradient / weight gradient) behind `conv2d_leaky`: a device tensor the kernels cannot serve raises
+- nothing on the GPU ever goes to another convolution library.  HOST tensors (the CPU tests of the network's shape logic, the
+oracle chain of the GPU tests, the offline fixture generator) go through torch's CPU conv2d.
 The field-algebra pieces (at_centers, gradient, centre -> face resampling) are pinned by tests/golden (PhiFlow numpy backend).
 """
 import numpy as np
@@ -15,7 +16,6 @@ import torch.nn.functional as F
 from .grids import CenteredGrid, StaggeredGrid, axis_extrapolation, stack_staggered_components
 from .stencils import pad_axis, pad_axis_sides
 
-USE_MFMA_CONV = True      # device tensors: csrc/conv.hip; False: torch.nn.functional.conv2d (MIOpen)
 
 
 def _laid_out(w_hwio):
@@ -102,8 +102,13 @@ class _Conv2dLeaky(torch.autograd.Function):
 
 
 def conv2d_leaky(x_nhwc, w_oihw, pad, leaky):
-    """NHWC convolution (+ leaky ReLU 0.2) of the closure: MFMA kernels for float32 device tensors of batch 1, torch otherwise."""
-    if USE_MFMA_CONV and x_nhwc.is_cuda and x_nhwc.dtype == torch.float32 and x_nhwc.shape[0] == 1 and w_oihw.dtype == torch.float32:
+    """NHWC convolution (+ leaky ReLU 0.2) of the closure.  Device tensors: the MFMA kernels (float32, batch 1 - what the
+    reference's training feeds, one simulation per step) or an error; host tensors: torch's CPU convolution (tests / fixtures)."""
+    if x_nhwc.is_cuda or w_oihw.is_cuda:
+        if not (x_nhwc.is_cuda and w_oihw.is_cuda and x_nhwc.dtype == torch.float32 and w_oihw.dtype == torch.float32 and x_nhwc.shape[0] == 1):
+            from ._native import PisoNativeError
+            raise PisoNativeError("conv2d_leaky: the MFMA convolution kernels take float32 NHWC device tensors of batch 1 (got %s %s, weights %s on %s); "
+                                  "there is no other convolution path on the GPU" % (tuple(x_nhwc.shape), x_nhwc.dtype, w_oihw.dtype, w_oihw.device))
         return _Conv2dLeaky.apply(x_nhwc, w_oihw, int(pad), bool(leaky))
     y = F.conv2d(x_nhwc.permute(0, 3, 1, 2), w_oihw, padding=int(pad))
     if leaky:

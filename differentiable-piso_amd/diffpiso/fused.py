@@ -49,6 +49,10 @@ class Geometry(object):
     def f(self, v):
         return C.c_float(np.float32(v))
 
+    def activate(self):
+        """Every wrapper calls this before it launches: the kernels walk this geometry's rows (N.use_window)."""
+        N.use_window(self.sh)
+
     def new_like(self, t):
         """Output buffer of a kernel: a windowed launch (slab-decomposed step) fills this rank's rows, the rest must be zero."""
         return torch.zeros_like(t) if self.sh is not None else torch.empty_like(t)
@@ -72,6 +76,7 @@ def faces_to_grid(flat, geom, box, extrapolation):
 
 
 def pad_velocity(vel_flat, geom, per_x, per_y):
+    geom.activate()
     out = geom.new((geom.ny + 2) * (geom.nx + 3) + (geom.ny + 3) * (geom.nx + 2), vel_flat.device)
     N.check(N.lib.piso_pad_velocity(N.ptr(vel_flat), N.ptr(out), geom.nx, geom.ny, int(per_x), int(per_y), N.stream_ptr()),
             "piso_pad_velocity")
@@ -79,6 +84,7 @@ def pad_velocity(vel_flat, geom, per_x, per_y):
 
 
 def a0_vfirst(a_flat, geom, dx_factor):
+    geom.activate()
     out = geom.new_like(a_flat)
     N.check(N.lib.piso_a0_vfirst(N.ptr(a_flat), N.ptr(out), geom.nx, geom.ny, geom.f(geom.beta), geom.f(dx_factor), N.stream_ptr()),
             "piso_a0_vfirst")
@@ -97,6 +103,7 @@ class _FaceOp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mode, geom, p, in0, in1, in2, a_flat, dmask):
         p, in0, in1, in2 = _c(p), _c(in0), _c(in1), _c(in2)
+        geom.activate()
         if geom.sh is not None:
             geom.sh.halo_cells(p)                            # G(p) on the slab's edge faces reads the neighbours' cell rows
         out0 = geom.new_like(in0)
@@ -116,6 +123,7 @@ class _FaceOp(torch.autograd.Function):
         mode, geom = ctx.mode, ctx.geom
         d0 = _c(d0)
         d1 = _c(d1) if mode == FACE_CORR1 else None
+        geom.activate()
         if geom.sh is not None:                              # d p gathers the face cotangents around every cell of the slab
             d0 = geom.sh.halo_faces(d0.clone())
             d1 = geom.sh.halo_faces(d1.clone()) if d1 is not None else None
@@ -135,6 +143,7 @@ class _Divergence(torch.autograd.Function):
     @staticmethod
     def forward(ctx, faces, geom, per_x, per_y):
         faces = _c(faces)
+        geom.activate()
         if geom.sh is not None:
             geom.sh.halo_faces(faces)                        # the slab's last cell row reads the face row above it
         div = geom.new(geom.nx * geom.ny, faces.device)
@@ -147,6 +156,7 @@ class _Divergence(torch.autograd.Function):
     def backward(ctx, dc):
         geom, per_x, per_y = ctx.meta
         dc = _c(dc)
+        geom.activate()
         if geom.sh is not None:
             dc = geom.sh.halo_cells(dc.clone())
         out = geom.new(geom.n_u + geom.n_v, dc.device)
@@ -161,6 +171,7 @@ class _HContribution(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m_delta, delta, a_flat, geom):
         m_delta, delta = _c(m_delta), _c(delta)
+        geom.activate()
         h, hb = geom.new_like(delta), geom.new_like(delta)
         N.check(N.lib.piso_h_contribution(N.ptr(m_delta), N.ptr(delta), N.ptr(a_flat), geom.f(geom.beta), N.ptr(h), N.ptr(hb), geom.nx,
                                           geom.ny, N.stream_ptr()), "piso_h_contribution")
@@ -171,6 +182,7 @@ class _HContribution(torch.autograd.Function):
     def backward(ctx, dh, dhb):
         geom = ctx.geom
         dh, dhb = _c(dh), _c(dhb)
+        geom.activate()
         d_md, d_delta = geom.new_like(dhb), geom.new_like(dhb)
         N.check(N.lib.piso_h_contribution_adjoint(N.ptr(dh), N.ptr(dhb), N.ptr(ctx.a_flat), geom.f(geom.beta), N.ptr(d_md),
                                                   N.ptr(d_delta), geom.nx, geom.ny, N.stream_ptr()), "piso_h_contribution_adjoint")
@@ -194,6 +206,11 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
     sh = getattr(sim, "sharding", None)                                            # sharding.StepSharding: this rank's y-slab only
     if sh is not None and (sh.nx, sh.ny) != (nx, ny):
         raise ValueError("the step sharding was built for a %d x %d grid" % (sh.nx, sh.ny))
+    for solver in (sim.linear_solver, sim.pressure_solver):
+        comm = getattr(solver, "slab_comm", None)
+        if (comm is not None and getattr(comm, "sharded", False)) != (sh is not None):
+            raise ValueError("piso_step: the simulation's `sharding` and its solvers' slab communicators disagree - a sharded step needs both "
+                             "solvers cut into the same slabs (solver.slab_comm), an un-sharded step none that is marked `sharded`")
     geom = Geometry(nx, ny, velocity.dx, beta, pressure.extrapolation, acc, sh)
     staggered_shape = (1, ny + 1, nx + 1, 2)
     if warn is None:
@@ -207,7 +224,6 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
         if sh is not None:
             sh.halo_faces(vel_flat)                                                # the padding / assembly of the slab's edge rows
             if sh.pattern is None:                                                 # col / rowptr of the whole grid, once
-                N.check(N.lib.piso_set_row_window(-1, -1, 0), "piso_set_row_window")
                 geom.sh = None
                 try:
                     pad0 = pad_velocity(torch.zeros_like(vel_flat), geom, per_x, per_y)
@@ -215,12 +231,11 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
                                                                  viscosity, sim.no_slip_flat(dev, ny, nx), beta)
                 finally:
                     geom.sh = sh
-                    N.check(N.lib.piso_set_row_window(sh.j0, sh.j1, int(sh.last)), "piso_set_row_window")
                 sh.set_pattern(col0, rp0, int(nnz0[0]))
         vel_pad = pad_velocity(vel_flat.detach(), geom, per_x, per_y)
         matrix_values, row_pointers, column_indices, Aflat, matrix_nnz = assemble_from_padded(
             vel_pad, nx, ny, velocity.dx, per_x, per_y, dmask, sim.active_mask_tensor(dev), viscosity, sim.no_slip_flat(dev, ny, nx), beta,
-            pattern=sh.pattern if sh is not None else None)
+            pattern=sh.pattern if sh is not None else None, sharding=sh)
         if sh is not None:                                                         # the solvers' transposes, the H product and A0 read
             sh.halo_csr_values(matrix_values)                                      # the matrix rows / diagonal of the neighbouring face rows
             sh.halo_faces(Aflat)

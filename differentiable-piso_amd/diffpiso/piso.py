@@ -90,12 +90,15 @@ _scalar_constants = {}
 
 
 def assemble_from_padded(vel_pad, nx, ny, dx_yx, per_x, per_y, dirichlet_mask_flat, active_mask, viscosity, no_slip_wall_mask, beta,
-                         pattern=None):
+                         pattern=None, sharding=None):
     """The CentralDifferenceMatrixCsr call of advection_matrix_cuda (piso_tf.py:95-123) on an already padded, flattened
     velocity.  Returns (matrix_values, row_pointers, column_indices, A_flat, matrix_nnz).
     pattern = (col_indices, row_pointers) of the whole grid (slab-decomposed step, sharding.py): the launch assembles this
     rank's rows only, rewrites their part of the pattern with the same numbers, and values / diagonal elsewhere are zero."""
     dev = vel_pad.device
+    if (pattern is None) != (sharding is None):
+        raise ValueError("assemble_from_padded: a slab-decomposed assembly needs both the grid's pattern and the sharding")
+    N.use_window(sharding)
     dx = dx_yx
     grid_spacing = np.array([dx[1], dx[0]], dtype=np.float32)               # :96
     cell_area = (np.prod(dx) / np.array([dx[1], dx[0]], dtype=np.float32)).astype(np.float32)   # :97
@@ -162,6 +165,7 @@ class _CsrMatVec(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_flat, values, row_ptr, col_indices, nx, ny, sharding=None):
         x_flat = x_flat.contiguous()
+        N.use_window(sharding)
         if sharding is not None:
             sharding.halo_faces(x_flat)                      # the product gathers x from the face rows around the slab
         y = (torch.zeros_like if sharding is not None else torch.empty_like)(x_flat)
@@ -176,6 +180,7 @@ class _CsrMatVec(torch.autograd.Function):
         values, row_ptr, col_indices = ctx.saved_tensors
         nx, ny, sharding = ctx.meta
         dy = dy.contiguous()
+        N.use_window(sharding)
         if sharding is not None:
             dy = sharding.halo_faces(dy.clone())
         dx = (torch.zeros_like if sharding is not None else torch.empty_like)(dy)
@@ -193,83 +198,17 @@ def explicit_H_csr(matrix_values, row_pointers, column_indices, velocity, stagge
     return stagger_flattened_data(prod, staggered_shape, coord_flip=True) - (A - beta) * velocity.staggered_tensor()
 
 
-FUSED_GLUE = True     # piso_step runs its stencil glue on the fused HIP kernels of csrc/glue.hip (fused.py); False: torch ops
-
-
 def piso_step(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_physics, dirichlet_values,
               viscosity_field=None, forcing_term=None, unrolling_step=0, warn=None, full_output=False, **kwargs):
-    """diffpiso/piso_tf.py:11-81.  Two implementations of the same statements: `_piso_step_reference` below (torch ops, one per
-    TensorFlow / PhiFlow op of the reference: the readable transcription, pinned by the golden vectors of the reference's own
-    helpers) and `fused.piso_step_fused` (one HIP launch per statement; tests hold it to the transcription)."""
+    """diffpiso/piso_tf.py:11-81 on the fused HIP glue kernels (`fused.piso_step_fused`: one launch per statement of the reference's
+    step, forward and reverse mode with the reference's custom gradients).  There is no other implementation in the package: the
+    statement-by-statement torch transcription that the tests hold the fused path to lives in tests/piso_step_transcription.py."""
     from . import stencils
-    if FUSED_GLUE and stencils.REFERENCE_ADJOINTS and velocity.data[0].data.is_cuda:
-        from .fused import piso_step_fused
-        return piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_physics, dirichlet_values,
-                               viscosity_field, forcing_term, unrolling_step, warn, full_output)
-    return _piso_step_reference(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_physics, dirichlet_values,
-                                viscosity_field, forcing_term, unrolling_step, warn, full_output)
-
-
-def _piso_step_reference(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_physics, dirichlet_values,
-                         viscosity_field=None, forcing_term=None, unrolling_step=0, warn=None, full_output=False):
-    """diffpiso/piso_tf.py:11-81, statement by statement."""
-    staggered_shape = tuple(velocity.staggered_tensor().shape)
-    sim = simulation_physics
-    vel_tensor = velocity.staggered_tensor()
-    dev = vel_tensor.device
-    ny, nx = staggered_shape[1] - 1, staggered_shape[2] - 1
-    if warn is None:
-        warn = torch.zeros(1, dtype=torch.uint8, device=dev)
-
-    def pressure_solve(field, A_0, guess, unrolling_step):
-        res, _, L = sim.pressure_solver.solve(A_0, field, guess, False, sim, unrolling_step=unrolling_step)
-        return res, L
-
-    viscosity = sim.viscosity if viscosity_field is None else viscosity_field      # :21-24
-    dxdy = float(np.prod(velocity.dx))
-    beta = dxdy / dt                                                               # :26
-
-    # ADVECTION MATRICES (:29-33)
-    matrix_values, row_pointers, column_indices, A, matrix_nnz, Aflat = advection_matrix_cuda(
-        velocity, sim.dirichlet_mask_flat(dev), viscosity, beta=beta, no_slip_wall_mask=sim.no_slip_flat(dev, ny, nx),
-        bool_periodic=sim.bool_periodic, active_mask=sim.active_mask_tensor(dev),
-        accessible_mask=sim.accessible_mask_tensor(dev), unrolling_step=unrolling_step)
-
-    # Predictor step (:36-47)
-    implicit_rhs = vel_tensor * beta - finite_volume_gradient_tensor(pressure, sim)
-    if forcing_term is not None:
-        implicit_rhs = implicit_rhs + device_constant(forcing_term, device=dev) * dxdy
-    implicit_rhs = arrange_rhs_term_tf(implicit_rhs, sim.dirichlet_mask, dirichlet_values, beta, coord_flip=True)
-    sol = sim.linear_solver.solve(-matrix_values, row_pointers, column_indices, implicit_rhs, staggered_shape,
-                                  flatten_staggered_data(velocity, True), offset=1, transpose=False,
-                                  unrolling_step=unrolling_step, warn=warn)
-    warn = sol[1]
-    sol = stagger_flattened_data(sol[0], staggered_shape, coord_flip=True)
-    velocity_star = StaggeredGrid(sol, box=velocity.box, extrapolation=velocity.extrapolation)
-
-    # Corrector step 1 (:49-58); implicitly assumes dx == dy like the reference
-    v1div = finite_volume_divergence(velocity_star)
-    dx_factor = dxdy / (float(velocity.dx[0]) ** 2)
-    bmA = beta - A
-    A_0 = 1 / bmA * dx_factor
-    pressure_inc_data, Lap1 = pressure_solve(v1div, A_0, guess=pressure_inc1.data, unrolling_step=unrolling_step)
-    pressure_inc1 = CenteredGrid(pressure_inc_data, box=pressure_inc1.box, extrapolation=pressure_inc1.extrapolation)
-    star_tensor = velocity_star.staggered_tensor()
-    velocity_s2 = star_tensor - finite_volume_gradient_tensor(pressure_inc1, sim_physics=sim) / bmA / dxdy
-
-    # Corrector step 2 (:60-73)
-    H_contribution = explicit_H_csr(matrix_values, row_pointers, column_indices, StaggeredGrid(velocity_s2 - star_tensor),
-                                    staggered_shape, A, beta)
-    H_div = finite_volume_divergence(StaggeredGrid(H_contribution / bmA, box=velocity.box,
-                                                   extrapolation=velocity.extrapolation))
-    pressure_inc2_data, Lap2 = pressure_solve(H_div, A_0, guess=pressure_inc2.data, unrolling_step=1000 + unrolling_step)
-    pressure_inc2 = CenteredGrid(pressure_inc2_data, box=pressure_inc2.box, extrapolation=pressure_inc2.extrapolation)
-    velocity_s3_data = velocity_s2 + (H_contribution - finite_volume_gradient_tensor(pressure_inc2, sim_physics=sim) / dxdy) / bmA
-    velocity_s3 = StaggeredGrid(velocity_s3_data, box=velocity.box, extrapolation=velocity.extrapolation)
-
-    pressure = pressure + pressure_inc1 + pressure_inc2                             # :75
-
-    if full_output:
-        return velocity_s3, pressure, pressure_inc1, pressure_inc2, matrix_values, column_indices, row_pointers, \
-            star_tensor, velocity_s2, Aflat, implicit_rhs, sol, velocity_s3_data, v1div, Lap1, Lap2, warn
-    return velocity_s3, pressure, warn
+    if not velocity.data[0].data.is_cuda:
+        raise N.PisoNativeError("piso_step: the fields must live on the GPU (the PISO path has no CPU implementation)")
+    if not stencils.REFERENCE_ADJOINTS:
+        raise ValueError("piso_step implements the reference's custom gradients (stencils.REFERENCE_ADJOINTS = True); the exact "
+                         "transposes are available through the stencil functions only")
+    from .fused import piso_step_fused
+    return piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_physics, dirichlet_values,
+                           viscosity_field, forcing_term, unrolling_step, warn, full_output)

@@ -70,7 +70,7 @@ class StepSharding(object):
         self.pattern = None                          # (col_indices, row_pointers) of the whole grid: geometry only, built once
         self.exchanges = 0
         comm.sharded = True
-        N.check(N.lib.piso_set_row_window(self.j0, self.j1, int(self.last)), "piso_set_row_window")
+        # (the row window itself is named by every kernel wrapper at call time: _native.use_window)
 
     # ------------------------------------------------------------------------------------------------ pattern of the two matrices
     def set_pattern(self, col_indices, row_pointers, nnz_u):
@@ -133,5 +133,5 @@ class StepSharding(object):
         N.check(N.lib.piso_comm_check(self.comm.handle, N.stream_ptr()), "piso_comm_check")
 
     def close(self):
-        N.lib.piso_set_row_window(-1, -1, 0)
+        N.use_window(None)
         self.comm.sharded = False

@@ -181,6 +181,104 @@ class LinearSolverCudaMultiBicgstabILU(LinearSolver):
 LinearSolverHipMultiBicgstabILU = LinearSolverCudaMultiBicgstabILU
 
 
+class _SingleSolveFn(torch.autograd.Function):
+    """solve_call of diffpiso/linear_solver.py:95-107: gradient w.r.t. the right-hand side by the transposed solve."""
+
+    @staticmethod
+    def forward(ctx, rhs_pair, values, row_ptr, col_indices, x0, solver, nx, ny, transpose):
+        warn = torch.zeros(1, dtype=torch.uint8, device=rhs_pair.device)
+        x, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs_pair, x0, nx, ny, _scalar(solver.accuracy),
+                                           solver.max_iterations, transpose, 0, warn)
+        solver.last_iterations = its
+        ctx.save_for_backward(values, row_ptr, col_indices, x0)
+        ctx.meta = (solver, nx, ny, transpose)
+        return x
+
+    @staticmethod
+    def backward(ctx, ds):
+        values, row_ptr, col_indices, x0 = ctx.saved_tensors
+        solver, nx, ny, transpose = ctx.meta
+        warn = torch.zeros(1, dtype=torch.uint8, device=ds.device)
+        df, _ = multi_bicgstab_ilu_native(values, row_ptr, col_indices, ds.contiguous(), x0, nx, ny, _scalar(solver.accuracy),
+                                          solver.max_iterations, not transpose, 0, warn)
+        return df, None, None, None, None, None, None, None, None
+
+
+class LinearSolverCudaBicgstabILU(LinearSolver):
+    """diffpiso/linear_solver.py:60-110: the single-matrix ILU(0)-BiCGStab (superseded in the reference by the pair solver; none
+    of its scripts constructs it).  The HIP engine solves the two advection matrices of a staggered grid together and takes its
+    structure from the grid, so the ONE matrix must be the u or the v matrix of a grid that is named: `staggered_shape`
+    ([1, ny+1, nx+1, 2]), `component` ('u' | 'v') and `bool_periodic` ((y, x)) are additional keyword arguments of `solve`.  The
+    other component is filled in with a diffusion matrix of the same grid and a zero right-hand side (it converges at once)."""
+
+    def __init__(self, accuracy=1e-5, max_iterations=2000):
+        LinearSolver.__init__(self, "HIP iLU-preconditioned BiCGStab solve", supported_devices=("GPU",), supports_guess=True,
+                              supports_batch=False, solver_type="iterative", input_format="csr")
+        self.accuracy = accuracy
+        self.max_iterations = max_iterations
+        self.last_iterations = None
+
+    def solve(self, matrix_values, row_ptr, col_indices, rhs, initial_guess=None, offset=0, transpose=False,
+              staggered_shape=None, component=None, bool_periodic=(False, False)):
+        if staggered_shape is None or component not in ("u", "v"):
+            raise NotImplementedError("LinearSolverCudaBicgstabILU.solve: the MI355X engine takes the matrix structure from the staggered grid - "
+                                      "pass staggered_shape=[1, ny+1, nx+1, 2], component='u'|'v' (and bool_periodic), or use "
+                                      "LinearSolverCudaMultiBicgstabILU, which is what the reference's scripts use")
+        from .piso import assemble_from_padded
+        ny, nx = int(staggered_shape[1]) - 1, int(staggered_shape[2]) - 1
+        n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
+        dev = rhs.device
+        per_y, per_x = bool(bool_periodic[0]), bool(bool_periodic[1])
+        # the pair's pattern and a well-posed stand-in for the other component: diffusion + identity on a resting fluid
+        pad = torch.zeros((ny + 2) * (nx + 3) + (ny + 3) * (nx + 2), dtype=torch.float32, device=dev)
+        val, rp, col, _, nnz = assemble_from_padded(pad, nx, ny, (1.0, 1.0), per_x, per_y, torch.zeros(n_u + n_v, dtype=torch.uint8, device=dev),
+                                                    torch.ones((ny + 2) * (nx + 2), dtype=torch.float32, device=dev), 1.0, None, 1.0)
+        val = -val                                           # (piso_step hands the solver -matrix_values, piso_tf.py:41)
+        nnz_u, nnz_v = int(nnz[0]), int(nnz[1])
+        lo, hi, r0, rows = (0, nnz_u, 0, n_u) if component == "u" else (nnz_u, nnz_u + nnz_v, n_u + 1, n_v)
+        mv = matrix_values.reshape(-1).to(torch.float32)
+        if mv.numel() != hi - lo or int(row_ptr.numel()) != rows + 1 or int(col_indices.numel()) != hi - lo:
+            raise ValueError("LinearSolverCudaBicgstabILU: the matrix is not the %s matrix of a %d x %d staggered grid (%d values, expected %d)"
+                             % (component, nx, ny, mv.numel(), hi - lo))
+        if not (torch.equal(row_ptr.reshape(-1).to(torch.int32), rp[r0:r0 + rows + 1]) and torch.equal(col_indices.reshape(-1).to(torch.int32), col[lo:hi])):
+            raise ValueError("LinearSolverCudaBicgstabILU: row pointers / column indices are not the 5-point pattern of the grid")
+        val = val.clone()
+        val[lo:hi] = mv
+        flat_rhs = rhs.reshape(-1).to(torch.float32)
+        off = 0 if component == "u" else n_u
+        x0 = torch.zeros(n_u + n_v, dtype=torch.float32, device=dev)
+        if initial_guess is not None:
+            x0[off:off + rows] = initial_guess.reshape(-1).detach().to(torch.float32)
+        embed = torch.zeros(n_u + n_v, dtype=torch.float32, device=dev)
+        pair_rhs = embed.index_put((torch.arange(off, off + rows, device=dev),), flat_rhs)          # (differentiable w.r.t. rhs)
+        sol = _SingleSolveFn.apply(pair_rhs, val, rp, col, x0, self, nx, ny, bool(transpose))
+        return sol[off:off + rows]
+
+
+def mat_vec_mul_csr(matrix_values, row_pointers, column_indices, staggered_field, staggered_shape):
+    """diffpiso/linear_solver.py:181-196: [M_u u, M_v v] of the two advection matrices (CSR pair as `advection_matrix_cuda` returns
+    it) as a staggered tensor - the HIP gather / segment-sum product (`piso_csr_matvec_f32`)."""
+    from .grids import StaggeredGrid
+    from .piso import _CsrMatVec
+    from .stencils import flatten_staggered_data, stagger_flattened_data
+    ny, nx = int(staggered_shape[1]) - 1, int(staggered_shape[2]) - 1
+    field = staggered_field if isinstance(staggered_field, StaggeredGrid) else StaggeredGrid(staggered_field)
+    flat = flatten_staggered_data(field, coord_flip=True)
+    prod = _CsrMatVec.apply(flat, matrix_values.reshape(-1).to(torch.float32), row_pointers.reshape(-1), column_indices.reshape(-1), nx, ny)
+    return stagger_flattened_data(prod, tuple(int(v) for v in staggered_shape), coord_flip=True)
+
+
+def print_residual(matrix_values, row_pointers, column_indices, staggered_field, staggered_shape, rhs):
+    """diffpiso/linear_solver.py:198-206: prints sum |M x - rhs| and returns the residual (flat, in the reference's default
+    flatten order)."""
+    from .grids import StaggeredGrid
+    from .stencils import flatten_staggered_data
+    prod = mat_vec_mul_csr(matrix_values, row_pointers, column_indices, staggered_field, staggered_shape)
+    residual = flatten_staggered_data(StaggeredGrid(prod)) - rhs.reshape(-1)
+    print("linsolve residual", float(residual.abs().sum()))
+    return residual
+
+
 # ------------------------------------------------------------------------------------------------------------------
 class PoissonSolver(object):
     """PhiFlow/phi/physics/pressuresolver/solver_api.py:10-38 (attribute holder)."""
@@ -196,9 +294,10 @@ class PoissonSolver(object):
         return self.name
 
 
-def laplace_matrix_native(nx, ny, active, accessible, a0_vfirst, dtype):
-    # (a row window - the slab-decomposed step - fills this rank's rows only: the others are zero, not uninitialised)
-    L = (torch.zeros if N.lib.piso_get_row_window(None, None, None) else torch.empty)(nx * ny * 5, dtype=dtype, device=a0_vfirst.device)
+def laplace_matrix_native(nx, ny, active, accessible, a0_vfirst, dtype, sharding=None):
+    # (sharding - the slab-decomposed step - fills this rank's rows only: the others are zero, not uninitialised)
+    N.use_window(sharding)
+    L = (torch.zeros if sharding is not None else torch.empty)(nx * ny * 5, dtype=dtype, device=a0_vfirst.device)
     fn = N.lib.piso_laplace_matrix_f64 if dtype == torch.float64 else N.lib.piso_laplace_matrix_f32
     N.check(fn(nx, ny, N.ptr(active), N.ptr(accessible), N.ptr(a0_vfirst.contiguous()), N.ptr(L), N.stream_ptr()),
             "piso_laplace_matrix")
@@ -218,7 +317,8 @@ class DeferredInt(object):
         """The count as an int32 device tensor [1] (the reference's `iterations` output) without a host round trip."""
         if len(self._pending) == 1 and self._base == 0:
             return self._pending[0]
-        return torch.tensor([int(self)], dtype=torch.int32, device=self._pending[0].device if self._pending else None)
+        dev = self._pending[0].device if self._pending else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
+        return torch.tensor([int(self)], dtype=torch.int32, device=dev)
 
     def __int__(self):
         if self._pending:
@@ -263,6 +363,59 @@ class DeferredInt(object):
     def __abs__(self): return abs(int(self))
 
 
+class _Stats(dict):
+    """Cumulative solver counters.  Counts of asynchronous solves are added as DeferredInt (no host wait); whatever LEAVES the
+    solver through the mapping interface - solver.stats["iterations"], dict(solver.stats), .items() - is a plain int (so that
+    json.dumps, numpy and torch see numbers), at the price of the one synchronising read that looking costs."""
+
+    def add(self, key, value):
+        dict.__setitem__(self, key, dict.__getitem__(self, key) + value)
+
+    @staticmethod
+    def _plain(v):
+        return int(v) if isinstance(v, DeferredInt) else v
+
+    def __getitem__(self, key):
+        return self._plain(dict.__getitem__(self, key))
+
+    def get(self, key, default=None):
+        return self._plain(dict.get(self, key, default))
+
+    def items(self):
+        return [(k, self._plain(v)) for k, v in dict.items(self)]
+
+    def values(self):
+        return [self._plain(v) for v in dict.values(self)]
+
+    def copy(self):
+        return dict(self.items())
+
+    def keys(self):
+        return dict.keys(self)
+
+    def __iter__(self):
+        return dict.__iter__(self)
+
+
+class _PlainCount(object):
+    """Descriptor of `last_iterations` / `last_adjoint_iterations`: stored as handed in (possibly a DeferredInt), read as int."""
+
+    def __init__(self, name):
+        self.name = "_" + name
+
+    def __get__(self, obj, cls=None):
+        if obj is None:
+            return self
+        v = getattr(obj, self.name, None)
+        if isinstance(v, DeferredInt):
+            v = int(v)
+            setattr(obj, self.name, v)
+        return v
+
+    def __set__(self, obj, value):
+        setattr(obj, self.name, value)
+
+
 _ASYNC_MAX_CELLS = 4608          # csrc/cg_tiny.h: kTinyMaxCells (the library answers PISO_ERR_NEEDS_HOST for anything it cannot run in one launch)
 
 
@@ -300,8 +453,8 @@ class _PressureSolveFn(torch.autograd.Function):
         x, it = solver._cg(nx, ny, per_x, per_y, L, divergence, _scalar(solver.accuracy), solver.max_iterations,
                            rank_deficient, solver.residual_reset)
         solver.last_iterations = it
-        solver.stats["solves"] += 1
-        solver.stats["iterations"] += it
+        solver.stats.add("solves", 1)
+        solver.stats.add("iterations", it)
         ctx.save_for_backward(L)
         ctx.meta = (solver, nx, ny, per_x, per_y, rank_deficient, divergence.shape)
         iterations = it.device_tensor() if isinstance(it, DeferredInt) else torch.tensor([it], dtype=torch.int32, device=divergence.device)
@@ -314,13 +467,15 @@ class _PressureSolveFn(torch.autograd.Function):
         g, it = solver._cg(nx, ny, per_x, per_y, L, dp.reshape(-1), _scalar(solver.accuracy), solver.max_iterations,
                            rank_deficient, solver.residual_reset)
         solver.last_adjoint_iterations = it
-        solver.stats["adjoint_solves"] += 1
-        solver.stats["adjoint_iterations"] += it
+        solver.stats.add("adjoint_solves", 1)
+        solver.stats.add("adjoint_iterations", it)
         return g.reshape(shape).to(torch.float32), None, None, None, None, None, None, None
 
 
 class PisoPressureSolverCudaCustom(PoissonSolver):
     """diffpiso/piso_cuda_pressure_solver.py:36-114."""
+    last_iterations = _PlainCount("last_iterations")                   # (int on read; a tiny grid's asynchronous solve hands in a DeferredInt)
+    last_adjoint_iterations = _PlainCount("last_adjoint_iterations")
 
     def __init__(self, dx, accuracy=1e-5, max_iterations=2000, residual_reset=10, randomized_restarts=0,
                  cast_to_double=True):
@@ -342,9 +497,12 @@ class PisoPressureSolverCudaCustom(PoissonSolver):
         self.last_iterations = None
         self.last_adjoint_iterations = None
         self.slab_comm = None        # distributed.SlabCommunicator: decompose the CG into y-slabs over the ranks (fp64 only)
-        self.stats = dict(solves=0, iterations=0, adjoint_solves=0, adjoint_iterations=0)   # cumulative; callers may reset
+        self.stats = _Stats(solves=0, iterations=0, adjoint_solves=0, adjoint_iterations=0)   # cumulative; callers may reset
 
     def _cg(self, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient, residual_reset):
+        if self.slab_comm is not None and self.slab_comm.sharded and L.dtype != torch.float64:
+            # (L and div of a sharded step are valid on this rank's rows only: the one-GPU kernel on the whole grid would read garbage)
+            raise N.PisoNativeError("the slab-decomposed pressure CG is fp64 only: a sharded step needs cast_to_double=True")
         if self.slab_comm is not None and self.slab_comm.world > 1 and L.dtype == torch.float64:
             from .distributed import cg_solve_slab, slab_rows
             if self.slab_comm.sharded:       # slab-decomposed STEP: L and div are valid on this rank's rows, the result stays there
@@ -381,7 +539,10 @@ class PisoPressureSolverCudaCustom(PoissonSolver):
         rank_def = self.laplace_rank_deficient
         if isinstance(rank_def, torch.Tensor):
             rank_def = bool(rank_def.reshape(-1)[0].item())
-        L = laplace_matrix_native(nx, ny, active.reshape(-1).contiguous(), accessible.reshape(-1).contiguous(), a0, dt)
+        sharding = getattr(simulation_physics, "sharding", None)
+        if (sharding is not None) != bool(self.slab_comm is not None and self.slab_comm.sharded):
+            raise ValueError("pressure solve: the simulation's `sharding` and this solver's slab communicator disagree")
+        L = laplace_matrix_native(nx, ny, active.reshape(-1).contiguous(), accessible.reshape(-1).contiguous(), a0, dt, sharding)
         per_y, per_x = [bool(b) for b in simulation_physics.bool_periodic]          # given (y, x), flipped for the op (:95)
         pressure, iteration = _PressureSolveFn.apply(divergence, L, self, nx, ny, per_x, per_y, rank_def)
         self.solve_count = self.solve_count + .001

@@ -4,19 +4,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
 import torch
 import diffpiso as dp
-import diffpiso.closure as closure
+import contextlib
+from tests.closure_checker import torch_convolutions
 from torch.profiler import ProfilerActivity, profile
 net, _, _ = dp.initialise_fullyconv_network([[0, 0], [0, 0]], padding="VALID", restore_shape=True, seed=1)
 net = net.cuda()
 x = torch.randn(1, 256, 896, 4).cuda().requires_grad_(True)
 for flag in (True, False):
-    closure.USE_MFMA_CONV = flag
-    for _ in range(2):
-        net(x).sum().backward()
-    torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CUDA]) as prof:
-        net(x).sum().backward()
+    with (contextlib.nullcontext() if flag else torch_convolutions()):
+        for _ in range(2):
+            net(x).sum().backward()
         torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            net(x).sum().backward()
+            torch.cuda.synchronize()
     print("==== MFMA" if flag else "==== torch / MIOpen")
     allrows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
     print("     GPU time of all %d kernel kinds, %d launches: %.1f us" % (len(allrows), sum(e.count for e in allrows), sum(e.device_time_total for e in allrows)))

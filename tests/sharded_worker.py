@@ -1,0 +1,142 @@
+"""One rank of a slab-decomposed (sharded) PISO run that hands back FIELDS (started by tests/test_gpu_sharded_fields.py):
+
+    python tests/sharded_worker.py RANK WORLD PORT CASE OUTDIR
+
+Every rank builds the same case (seeded builders), attaches the peer-mailbox communicator to both linear solvers and a
+`StepSharding` to the simulation parameters, runs the unrolled steps forward and the reverse sweep of L = 1/2 |u_K|^2 (the sum of
+the ranks' parts), and writes ITS rows of u_K, p_K, dL/du_0 and dL/dp_0 to OUTDIR/rank<r>.npz.  `run_case` is also what the test
+calls in its own process for the one-GPU run of the same case.
+
+CASE:  fixture:bench1024_tight_step.npz      the benchmark's workload at 1024^2 with converged solves (committed oracle fixture)
+       fixture:cfg3_tml_512x256.npz          BASELINE config 3, 4 steps (x periodic, walls in y)
+       box:NX:NY:STEPS:TOL:MAXIT:SHIFT[:PERSIST]   decaying turbulence on an NX x NY periodic box (bench.py's builder); SHIFT 0: un-shifted CG;
+                                             PERSIST 0: two-kernel CG iteration"""
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _gen():
+    spec = importlib.util.spec_from_file_location("make_golden_configs", os.path.join(HERE, "golden", "make_golden_configs.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def build_case(case, device):
+    """-> dict(sim, lin, ps, domain, vel_t, p_t, dt, steps, nx, ny, p_tol_adjoint)"""
+    import numpy as np
+    import torch
+    import diffpiso as dp
+    kind, _, rest = case.partition(":")
+    if kind == "fixture" and rest.startswith("bench"):
+        import bench
+        d = np.load(os.path.join(HERE, "golden", rest))
+        meta = json.loads(str(d["meta"]))
+        n, sv = meta["grid"], meta["solver"]
+        P = bench.build_problem(n, device, sv["p_tol"], sv["p_max_it"], sv["p_reset"])
+        P["lin"].accuracy, P["lin"].max_iterations = sv["lin_tol"], sv["lin_max_it"]
+        return dict(sim=P["sim"], lin=P["lin"], ps=P["ps"], domain=P["domain"], vel_t=P["vel_t"], p_t=P["p_t"], dt=P["dt"], steps=1,
+                    nx=n, ny=n, p_tol_adjoint=sv.get("p_tol_adjoint"))
+    if kind == "fixture":
+        from tests.cases import product_setup
+        G = _gen()
+        d = np.load(os.path.join(HERE, "golden", rest))
+        meta = json.loads(str(d["meta"]))
+        c = G.tml_case()
+        P = product_setup(c, device=str(device), **meta["solver"])
+        return dict(sim=P["sim"], lin=P["lin"], ps=P["ps"], domain=P["domain"], vel_t=P["vel_tensor"], p_t=P["pressure"].data, dt=c["dt"],
+                    steps=meta["steps"], nx=c["nx"], ny=c["ny"], p_tol_adjoint=None, dx_yx=c["dx_yx"])
+    if kind == "box":
+        import bench
+        nx, ny, steps, tol, maxit, shift = rest.split(":")[:6]
+        if len(rest.split(":")) > 6:                        # PERSIST 0: two-kernel CG (slabs whose persistent kernels cannot all be resident on ONE shared GPU)
+            import diffpiso._native as N
+            N.set_option("cg_persist", int(rest.split(":")[6]))
+        P = bench.build_problem(int(nx), device, float(tol), int(maxit), 1000, ny=int(ny))
+        P["lin"].accuracy = 1e-6                               # (TOL / MAXIT are the pressure solver's; the advection solves converge: ~3 iterations)
+        if int(shift) == 0:
+            P["ps"].laplace_rank_deficient = False
+        return dict(sim=P["sim"], lin=P["lin"], ps=P["ps"], domain=P["domain"], vel_t=P["vel_t"], p_t=P["p_t"], dt=P["dt"], steps=int(steps),
+                    nx=int(nx), ny=int(ny), p_tol_adjoint=None)
+    raise ValueError(case)
+
+
+def run_case(B, sharding=None):
+    """Forward `steps` unrolled steps + reverse sweep -> (u_K staggered tensor, p_K, dL/du_0, dL/dp_0, loss, warn)."""
+    import torch
+    import diffpiso as dp
+    vel_t = B["vel_t"].clone().requires_grad_(True)
+    p_t = B["p_t"].clone().requires_grad_(True)
+    ext = dp.Material.extrapolation_mode(B["domain"].boundaries)
+    velocity = dp.StaggeredGrid(vel_t, B["domain"].box, extrapolation=ext)
+    pressure = dp.CenteredGrid(p_t, B["domain"].box, dp.pressure_extrapolation(B["domain"].boundaries))
+    va, pa, vn, pn, warn = dp.unroll_piso_steps(velocity, pressure, B["dt"], B["sim"], step_count=B["steps"])
+    u = vn.staggered_tensor()
+    if sharding is None:
+        loss = 0.5 * (u ** 2).sum()
+    else:
+        loss = 0.5 * ((u * sharding.owned_mask_staggered(u.device)) ** 2).sum()
+    if B.get("p_tol_adjoint"):
+        B["ps"].accuracy = B["p_tol_adjoint"]
+    loss.backward()
+    return u.detach(), pn.data.detach(), vel_t.grad, p_t.grad, float(loss.detach()), float(sum(float(w.detach().sum()) for w in warn))
+
+
+def main():
+    rank, world, port = (int(v) for v in sys.argv[1:4])
+    case, outdir = sys.argv[4], sys.argv[5]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    out = {"rank": rank, "world": world, "ok": False}
+    comm = None
+    try:
+        from diffpiso.distributed import SlabCommunicator
+        from diffpiso.sharding import StepSharding
+        B = build_case(case, device)
+        nx, ny = B["nx"], B["ny"]
+        comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=26 * nx + 64)
+        B["ps"].slab_comm = comm
+        B["lin"].slab_comm = comm
+        sh = B["sim"].sharding = StepSharding(comm, nx, ny)
+        u, p, du, dp_, loss, warn = run_case(B, sh)
+        sh.check()
+        j0, j1, last = sh.j0, sh.j1, 1 if sh.last else 0
+        np.savez(os.path.join(outdir, "rank%d.npz" % rank), j0=j0, j1=j1, last=last,
+                 u_v=u[0, j0:j1 + last, :, 0].cpu().numpy(), u_u=u[0, j0:j1, :, 1].cpu().numpy(), p=p[0, j0:j1, :, 0].cpu().numpy(),
+                 du_v=du[0, j0:j1 + last, :, 0].cpu().numpy(), du_u=du[0, j0:j1, :, 1].cpu().numpy(), dp=dp_[0, j0:j1, :, 0].cpu().numpy())
+        st = comm.stats()
+        out.update(ok=True, loss=loss, warn=warn, stats=st, halo_exchanges=sh.exchanges,
+                   cg_iterations=[int(B["ps"].last_iterations or 0), int(B["ps"].last_adjoint_iterations or 0)],
+                   bicgstab_iterations=[int(v) for v in (B["lin"].last_iterations or ())],
+                   max_memory_allocated=int(torch.cuda.max_memory_allocated(device)))
+    except Exception as e:        # the parent reads the reason
+        import traceback
+        out["error"] = "%r\n%s" % (e, traceback.format_exc()[-1500:])
+    finally:
+        print("SLAB_WORKER " + json.dumps(out), flush=True)
+        try:
+            if comm is not None:
+                comm.close()
+        except Exception:
+            pass
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+if __name__ == "__main__":
+    main()

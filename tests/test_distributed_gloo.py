@@ -120,9 +120,14 @@ def test_step_sharding_halo_messages_are_consistent():
             sh = [StepSharding(FakeComm(r, world), nx, ny) for r in range(world)]
             for r in range(world):
                 j0, j1, last = C.c_int(), C.c_int(), C.c_int()
-                StepSharding(FakeComm(r, world), nx, ny)
+                # the row window is an attribute of every CALL (N.use_window names the sharding a kernel wrapper works for), not of
+                # the process: building a sharding does not touch it, naming one sets exactly its rows, naming none clears it
+                assert N.lib.piso_get_row_window(C.byref(j0), C.byref(j1), C.byref(last)) == 0
+                N.use_window(sh[r])
                 assert N.lib.piso_get_row_window(C.byref(j0), C.byref(j1), C.byref(last)) == 1
                 assert (j0.value, j1.value, last.value) == (r * ny // world, (r + 1) * ny // world, int(r == world - 1))
+                N.use_window(None)
+                assert N.lib.piso_get_row_window(C.byref(j0), C.byref(j1), C.byref(last)) == 0
                 up, lo = (r + 1) % world, (r - 1) % world
                 for kind in ("msgs_faces", "msgs_faces_vfirst", "msgs_cells"):
                     mine, theirs_up, theirs_lo = msgs(getattr(sh[r], kind)), msgs(getattr(sh[up], kind)), msgs(getattr(sh[lo], kind))
@@ -133,4 +138,4 @@ def test_step_sharding_halo_messages_are_consistent():
             assert top[1] == (n_u + (ny - HALO) * nx, (HALO + 1) * nx)
             assert msgs(sh[0].msgs_faces)[2][1] == top[1]
     finally:
-        N.lib.piso_set_row_window(-1, -1, 0)
+        N.use_window(None)

@@ -8,6 +8,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from tests.closure_checker import torch_convolutions
+
 pytestmark = pytest.mark.gpu
 LAYERS = [(7, 4, 16), (5, 16, 16), (5, 16, 32), (3, 32, 64), (3, 64, 64), (1, 64, 64), (1, 64, 2)]
 
@@ -56,11 +58,8 @@ def test_network_matches_torch_path_and_uses_the_matrix_cores(padding):
     x = torch.randn(1, 48, 160, 4, generator=torch.Generator().manual_seed(0)).cuda()
     x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
     out1 = net(x1)
-    closure.USE_MFMA_CONV = False
-    try:
+    with torch_convolutions():
         out2 = net2(x2)
-    finally:
-        closure.USE_MFMA_CONV = True
     assert out1.shape == out2.shape == (1, 48, 160, 2)
     assert rel(out1, out2) < 5e-6
     g = torch.randn(out1.shape, generator=torch.Generator().manual_seed(1)).cuda()
@@ -88,9 +87,9 @@ def test_config4_network_timing_mfma_vs_miopen():
     net = net.cuda()
     x = torch.randn(1, 256, 896, 4, generator=torch.Generator().manual_seed(0)).cuda().requires_grad_(True)
     res = {}
+    import contextlib
     for flag in (True, False):
-        closure.USE_MFMA_CONV = flag
-        try:
+        with (contextlib.nullcontext() if flag else torch_convolutions()):
             for _ in range(2):
                 net(x).sum().backward()
             torch.cuda.synchronize()
@@ -99,8 +98,6 @@ def test_config4_network_timing_mfma_vs_miopen():
                 net(x).sum().backward()
             torch.cuda.synchronize()
             res[flag] = (time.perf_counter() - t0) / 5
-        finally:
-            closure.USE_MFMA_CONV = True
     flops = 3 * 2 * 81856 * 236 * 876          # fwd + dgrad + wgrad, VALID output sizes shrink layer by layer (upper bound: first layer's)
     print("closure fwd+bwd at 256x896: MFMA kernels %.2f ms, torch / MIOpen %.2f ms (~%.1f TFLOP/s fp32 on the MFMA path)"
           % (1e3 * res[True], 1e3 * res[False], flops / res[True] / 1e12))
@@ -119,11 +116,8 @@ def test_weight_layout_cache_is_bound_to_the_parameter_lifetime():
         net, _, _ = dp.initialise_fullyconv_network([[0, 0], [0, 0]], padding="SAME", seed=seed)
         net = net.cuda()
         out = net(x)
-        closure.USE_MFMA_CONV = False
-        try:
+        with torch_convolutions():
             want = net(x)
-        finally:
-            closure.USE_MFMA_CONV = True
         assert rel(out, want) < 5e-6, seed
         # an in-place update (optimiser step) and a checkpoint load (copy_) both invalidate the layouts
         with torch.no_grad():

@@ -1,5 +1,5 @@
 """The fused glue kernels (csrc/glue.hip, diffpiso/fused.py) against the torch transcription of the reference's helpers
-(diffpiso/stencils.py, diffpiso/piso.py::_piso_step_reference -- itself pinned by the golden vectors generated from the
+(diffpiso/stencils.py, tests/piso_step_transcription.py -- itself pinned by the golden vectors generated from the
 reference's own piso_helpers.py): raw C-ABI kernels bit for bit where the operation order is the same, the composed step
 forward and reverse mode to float32 round-off, for all four boundary set-ups."""
 import ctypes as C
@@ -102,20 +102,26 @@ def test_fused_step_matches_the_torch_transcription(name):
     """One full step, forward and reverse mode, fused kernels vs torch ops: same solver kernels underneath, so everything agrees
     to float32 round-off of the glue (fields 1e-6, gradients 1e-5)."""
     import diffpiso as dp
-    import diffpiso.piso as piso_mod
+    from tests.piso_step_transcription import piso_step_transcription
     c = make_case(name, 24, 40, seed=7, variable_viscosity=(name == "spatial_ml"))
     kw = dict(SOLVER)
     if name == "cavity":
-        # stay above the float32 inconsistency floor of the shifted system (tests/test_oracle_step.py); float64 advection solve:
-        # the float32 transposed solve is borderline at this tolerance and zero-on-failure would hide the comparison
-        kw.update(p_tol=1e-6, lin_double=True, lin_tol=1e-10)
+        # The cavity's shifted pressure system is rank deficient and, with float32 right-hand sides, inconsistent: a solve to a
+        # tolerance stops at different iterations for inputs that differ by 1 ulp (6e-3 in the gradients), and on the shifted -
+        # indefinite - operator even a FIXED number of iterations amplifies a 1-ulp difference in the constant mode to 1e-3.  This
+        # test is about the GLUE: both paths run 60 iterations of the UN-shifted CG (accuracy 1e-30 is never met, the cap ends every
+        # solve; without the shift round-off in the null space grows linearly, not exponentially), which makes the comparison
+        # independent of the solver's stopping iteration.  The shifted cavity solves are covered by tests/test_gpu_configs.py and
+        # tests/test_gpu_kernels.py.  float64 advection solve: the float32 transposed solve is borderline and zero-on-failure would
+        # hide the comparison.
+        kw.update(p_tol=1e-30, p_max_it=60, p_reset=1000, lin_double=True, lin_tol=1e-10, rank_deficient=False)
     P = product_setup(c, **kw)
     rng = np.random.default_rng(0)
     forcing = (0.1 * rng.standard_normal(c["vel"].shape)).astype(np.float32)
     res = {}
     for fusedflag in (True, False):
-        piso_mod.FUSED_GLUE = fusedflag
-        try:
+        step = dp.piso_step if fusedflag else piso_step_transcription
+        if True:
             vel_t = P["vel_tensor"].clone().requires_grad_(True)
             velocity = dp.StaggeredGrid(vel_t, P["velocity"].box, extrapolation=P["velocity"].extrapolation)
             p_t = P["pressure"].data.clone().requires_grad_(True)
@@ -124,29 +130,22 @@ def test_fused_step_matches_the_torch_transcription(name):
             inc2 = dp.CenteredGrid(torch.zeros_like(p_t) + 1e-12, pressure.box, pressure.extrapolation)
             f_t = torch.tensor(forcing, device="cuda").requires_grad_(True)
             dv_t = torch.tensor(c["dirichlet_values"], device="cuda").requires_grad_(True)
-            v3, pn, warn = dp.piso_step(velocity, pressure, inc1, inc2, c["dt"], P["sim"], dv_t, forcing_term=f_t)
+            v3, pn, warn = step(velocity, pressure, inc1, inc2, c["dt"], P["sim"], dv_t, forcing_term=f_t)
             gen = torch.Generator(device="cpu").manual_seed(3)
             gv = torch.randn(v3.staggered_tensor().shape, generator=gen).cuda()
             gp = torch.randn(pn.data.shape, generator=gen).cuda()
             gp = gp - gp.mean()
             ((v3.staggered_tensor() * gv).sum() + (pn.data * gp).sum()).backward()
             res[fusedflag] = (v3.staggered_tensor().detach(), pn.data.detach(), vel_t.grad, p_t.grad, f_t.grad, dv_t.grad, float(warn.sum()))
-        finally:
-            piso_mod.FUSED_GLUE = True
     a, b = res[True], res[False]
     assert a[6] == b[6] == 0
     names = ["u", "p", "d_vel", "d_p", "d_forcing", "d_dirichlet"]
     errs = {n: rel(x, y) for n, x, y in zip(names, a[:6], b[:6]) if float(y.abs().max()) > 0}
     print("fused vs torch glue:", name, {k: "%.1e" % v for k, v in errs.items()})
-    # (cavity: the rank-deficient CG stops at slightly different iterations for 1-ulp different inputs, tests/test_gpu_configs.py)
-    assert errs["u"] < (1e-4 if name == "cavity" else 2e-6) and errs["p"] < 2e-5      # (cavity: solver-tolerance level, see below)
-    # cavity: the two runs' ADJOINT pressure solves see right-hand sides that differ by 1 ulp, and on the shifted, inconsistent
-    # system (absolute tolerance 1e-6) they then stop at different iterations: the gradients agree at the solver-tolerance level
-    # only (measured 6e-3 with the single-workgroup CG this 24 x 40 grid runs on, 1e-5 by luck of an identical stopping iteration
-    # with the chip-wide kernels).  The glue itself is held to round-off by the other three set-ups and the per-kernel tests above.
-    g_tol = 2e-2 if name == "cavity" else 1e-5
+    assert errs["u"] < 2e-6 and errs["p"] < 2e-5
+    g_tol = 1e-5
     assert errs["d_vel"] < g_tol and errs["d_forcing"] < g_tol
-    assert errs["d_p"] < (2e-2 if name == "cavity" else 5e-4)            # cancels to ~1 % of its summands (DESIGN.md "Oracle", findings)
+    assert errs["d_p"] < 5e-4            # cancels to ~1 % of its summands (DESIGN.md "Oracle", findings)
     # cavity: the adjoint pressure solves are rank deficient; their constant mode (mean(b) / (c N), round-off of the CG) is
     # invisible to every interior face but feeds the wall faces through the divergence adjoint: d/d(dirichlet) is not a
     # reproducible quantity there (the two paths differ by O(1), the oracle likewise)
@@ -157,23 +156,21 @@ def test_fused_step_matches_the_torch_transcription(name):
 def test_fused_step_launch_count():
     """What the fusion is for: a forward step issues a few dozen launches instead of a few hundred (solver iterations aside)."""
     import diffpiso as dp
-    import diffpiso.piso as piso_mod
+    from tests.piso_step_transcription import piso_step_transcription
     from torch.profiler import ProfilerActivity, profile
     c = make_case("periodic", 32, 128, seed=1)
     P = product_setup(c, lin_tol=1e-3, lin_max_it=2, p_tol=1e-1, p_max_it=10, p_reset=1000)
     counts = {}
     for flag in (True, False):
-        piso_mod.FUSED_GLUE = flag
-        try:
+        step = dp.piso_step if flag else piso_step_transcription
+        if True:
             inc = dp.CenteredGrid(torch.zeros_like(P["pressure"].data), P["pressure"].box, P["pressure"].extrapolation)
             with torch.no_grad():
-                dp.piso_step(P["velocity"], P["pressure"], inc, inc, c["dt"], P["sim"], torch.tensor(c["dirichlet_values"], device="cuda"))
+                step(P["velocity"], P["pressure"], inc, inc, c["dt"], P["sim"], torch.tensor(c["dirichlet_values"], device="cuda"))
                 torch.cuda.synchronize()
                 with profile(activities=[ProfilerActivity.CUDA]) as prof:
-                    dp.piso_step(P["velocity"], P["pressure"], inc, inc, c["dt"], P["sim"], torch.tensor(c["dirichlet_values"], device="cuda"))
+                    step(P["velocity"], P["pressure"], inc, inc, c["dt"], P["sim"], torch.tensor(c["dirichlet_values"], device="cuda"))
                     torch.cuda.synchronize()
             counts[flag] = sum(e.count for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA)
-        finally:
-            piso_mod.FUSED_GLUE = True
     print("device launches per forward step: fused %d, torch glue %d" % (counts[True], counts[False]))
     assert counts[True] < 0.6 * counts[False]

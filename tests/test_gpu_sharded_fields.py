@@ -1,0 +1,217 @@
+"""FIELD-level parity of the slab-decomposed (sharded) step: W processes, one slab each, real hipIpc mailboxes
+(all ranks share the test box's GPU) -- u, p, dL/du_0 and dL/dp_0 are gathered from the ranks' rows and held
+  (a) to the one-GPU product run of the same case, rel-L2 per field <= 1e-6 (summation order of the reductions is all that differs), and
+  (b) to the committed ORACLE fixtures of that case at the north star's 1e-5 (the bounds of tests/test_gpu_golden_configs.py).
+A halo bug that perturbs a few rows next to a slab edge by 1e-3 cannot hide in a loss or a norm here: the edge rows are compared
+on their own as well."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _spawn(world, case, timeout=600):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = tempfile.mkdtemp(prefix="sharded_")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), str(port), case, out],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    res = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        lines = [l for l in so.splitlines() if l.startswith("SLAB_WORKER ")]
+        assert lines, "rank died without a report:\n%s\n%s" % (so[-2000:], se[-4000:])
+        res.append(json.loads(lines[-1][len("SLAB_WORKER "):]))
+    for r in res:
+        if not r.get("ok") and ("piso_comm_peer_create" in r.get("error", "") or "piso_comm_peer_connect" in r.get("error", "")):
+            pytest.skip("peer transport unavailable here: %s" % r["error"][:300])
+    for r in res:
+        assert r["ok"], r
+    return sorted(res, key=lambda r: r["rank"]), out
+
+
+def _gather(out, world, ny, nx):
+    """The ranks' rows -> full arrays (staggered [ny+1, nx+1, 2], cells [ny, nx]); every row must arrive exactly once."""
+    u = np.full((ny + 1, nx + 1, 2), np.nan, np.float32)
+    du = np.full((ny + 1, nx + 1, 2), np.nan, np.float32)
+    u[ny, :, 1], du[ny, :, 1] = 0, 0                      # (the staggered tensor's unused corner row of u)
+    p = np.full((ny, nx), np.nan, np.float32)
+    dp = np.full((ny, nx), np.nan, np.float32)
+    edges = []
+    for r in range(world):
+        d = np.load(os.path.join(out, "rank%d.npz" % r))
+        j0, j1, last = int(d["j0"]), int(d["j1"]), int(d["last"])
+        assert np.isnan(u[j0:j1, 0, 1]).all() and np.isnan(p[j0:j1, 0]).all(), "rows handed in twice"
+        u[j0:j1 + last, :, 0], u[j0:j1, :, 1] = d["u_v"], d["u_u"]
+        du[j0:j1 + last, :, 0], du[j0:j1, :, 1] = d["du_v"], d["du_u"]
+        p[j0:j1], dp[j0:j1] = d["p"], d["dp"]
+        edges += [j0, j0 + 1, j1 - 2, j1 - 1]
+    for a in (u, du, p, dp):
+        assert not np.isnan(a).any(), "rows missing"
+    return u, p, du, dp, sorted(set(edges))
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def _one_gpu(case, cg_persist=None):
+    sys.path.insert(0, HERE)
+    import sharded_worker as W
+    import diffpiso._native as N
+    B = W.build_case(case, torch.device("cuda"))
+    if cg_persist is not None:
+        N.set_option("cg_persist", cg_persist)
+    try:
+        u, p, du, dp, loss, warn = W.run_case(B, None)
+    finally:
+        if cg_persist is not None:
+            N.set_option("cg_persist", -1)
+    assert warn == 0
+    its = (int(B["ps"].last_iterations or 0), int(B["ps"].last_adjoint_iterations or 0), [int(v) for v in (B["lin"].last_iterations or ())])
+    return (u[0].cpu().numpy(), p[0, :, :, 0].cpu().numpy(), du[0].cpu().numpy(), dp[0, :, :, 0].cpu().numpy(), loss, its, B)
+
+
+def _errors(a, b, edges, name, dp_scale):
+    e_all, e_edge = _rel(a, b), _rel(a[edges], b[edges])
+    if name == "dL/dp_0" and dp_scale is not None:      # cancels to ~1 % of its summands: round-off scales with those (see test_gpu_golden_configs)
+        e_all = float(np.linalg.norm(a.astype(np.float64) - b)) / dp_scale
+        e_edge = float(np.linalg.norm(a[edges].astype(np.float64) - b[edges])) / (dp_scale * np.sqrt(len(edges) / float(a.shape[0])))
+    return e_all, e_edge
+
+
+def _compare_with_one_gpu(tag, sharded, single, edges, bound, dp_scale=None, yardstick=None):
+    """rel-L2 per field over the whole grid AND over the rows next to the slab edges only (bound on both).
+    yardstick (optional): the same fields from a SECOND one-GPU run that differs from the first in nothing but the summation order of
+    its pressure CG (two-kernel iteration instead of the persistent kernel).  Two correct runs of the float32 step differ by that much;
+    the sharded run - another summation order - may differ from the one-GPU run by `bound` or by three times the yardstick, and its
+    rows next to the slab edges by no more than twice what the whole field does (a halo bug is local to them)."""
+    names = ("u", "p", "dL/du_0", "dL/dp_0")
+    bad = {}
+    for k, name in enumerate(names):
+        e_all, e_edge = _errors(sharded[k], single[k], edges, name, dp_scale)
+        lim = bound
+        note = ""
+        if yardstick is not None:
+            y_all, y_edge = _errors(yardstick[k], single[k], edges, name, dp_scale)
+            lim = max(bound, 3 * y_all)
+            note = "; two one-GPU summation orders differ by %.2e / %.2e" % (y_all, y_edge)
+        print("%s %s: sharded vs one GPU rel-L2 %.2e, rows next to the slab edges %.2e (bound %.1e)%s" % (tag, name, e_all, e_edge, lim, note))
+        if not (e_all <= lim and e_edge <= 2 * max(lim, e_all)):
+            bad[name] = (e_all, e_edge, lim)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_benchmark_workload_1024_fields_vs_one_gpu_and_oracle_fixture(world):
+    """The benchmark's workload at 1024^2 with converged solves, ONE grid cut into 2 / 4 slabs: every kernel of the step on the
+    rank's rows, persistent slab CG, slab ILU(0)-BiCGStab.  Fields against the one-GPU product (1e-6) and the oracle fixture (1e-5)."""
+    from tests.test_gpu_golden_configs import _check, _load
+    case = "fixture:bench1024_tight_step.npz"
+    u1, p1, du1, dp1, loss1, its1, B = _one_gpu(case)
+    yard = _one_gpu(case, cg_persist=0)[:4]
+    res, out = _spawn(world, case)
+    u, p, du, dp, edges = _gather(out, world, 1024, 1024)
+    d, meta = _load("bench1024_tight_step.npz")
+    dx = 2 * np.pi / 1024
+    summands = np.sqrt(2.0) * float(d["dt"]) / dx * float(d["d_vel_norm"])
+    _compare_with_one_gpu("bench1024 x%d" % world, (u, p, du, dp), (u1, p1, du1, dp1), edges, 1e-6, dp_scale=max(summands, float(d["d_p_norm"])), yardstick=yard)
+    loss = sum(r["loss"] for r in res)
+    assert abs(loss - loss1) <= 1e-6 * abs(loss1)
+    for r in res:
+        assert r["warn"] == 0 and r["stats"]["verification_failures"] == 0 and r["halo_exchanges"] > 0, r
+        assert r["bicgstab_iterations"] == its1[2], (r["bicgstab_iterations"], its1[2])
+    # (b) the oracle fixture: the same bounds the one-GPU run is held to
+    stride = int(d["stride"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None]
+    bad = []
+    _check("sharded u_1", t(u), d["vel_sub"], float(d["vel_norm"]), stride, 1e-5, bad)
+    _check("sharded p_1", t(p)[..., None], d["p_sub"], float(d["p_norm"]), stride, 1e-5, bad)
+    _check("sharded dL/du_0", t(du), d["d_vel_sub"], float(d["d_vel_norm"]), stride, 1e-5, bad)
+    _check("sharded dL/dp_0", t(dp)[..., None], d["d_p_sub"], float(d["d_p_norm"]), stride, 1e-5, bad, scale_norm=max(summands, float(d["d_p_norm"])))
+    assert not bad, bad
+
+
+def test_sharded_config3_mixing_layer_512x256_two_ranks_fields_vs_one_gpu_and_oracle_fixture():
+    """BASELINE config 3 at its size (x periodic, WALLS in y, float32 advection solve), 4 unrolled steps forward + reverse sweep on
+    two slabs: fields against the one-GPU product and the oracle fixture."""
+    from tests.test_gpu_golden_configs import _check, _load
+    case = "fixture:cfg3_tml_512x256.npz"
+    u1, p1, du1, dp1, loss1, its1, B = _one_gpu(case)
+    yard = _one_gpu(case, cg_persist=0)[:4]
+    ny, nx = B["ny"], B["nx"]
+    res, out = _spawn(2, case)
+    u, p, du, dp, edges = _gather(out, 2, ny, nx)
+    d, meta = _load("cfg3_tml_512x256.npz")
+    dy, dx = (float(v) for v in B["dx_yx"])
+    summands = np.sqrt(2.0) * float(B["dt"]) / min(dx, dy) * float(d["d_vel_norm"])
+    _compare_with_one_gpu("cfg3 x2", (u, p, du, dp), (u1, p1, du1, dp1), edges, 1e-6, dp_scale=max(summands, float(d["d_p_norm"])), yardstick=yard)
+    for r in res:
+        assert r["warn"] == 0 and r["halo_exchanges"] > 0, r
+    stride = int(d["stride"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None]
+    bad = []
+    _check("sharded cfg3 u_4", t(u), d["vel_sub"], float(d["vel_norm"]), stride, 1e-5, bad)
+    _check("sharded cfg3 p_4", t(p)[..., None], d["p_sub"], float(d["p_norm"]), stride, 1e-5, bad)
+    _check("sharded cfg3 dL/du_0", t(du), d["d_vel_sub"], float(d["d_vel_norm"]), stride, 1e-5, bad)
+    _check("sharded cfg3 dL/dp_0", t(dp)[..., None], d["d_p_sub"], float(d["d_p_norm"]), stride, 1e-5, bad, scale_norm=max(summands, float(d["d_p_norm"])))
+    assert not bad, bad
+
+
+def _bench_dump(env_extra, args, nproc, outdir, timeout=600):
+    """bench.py (torch.distributed.run for nproc > 1) with --dump-fields: the path tests/test_gpu_multiproc.py::test_config5_4096_eight_slabs runs."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    cmd = [sys.executable]
+    if nproc > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [os.path.join(ROOT, "bench.py")] + args + ["--dump-fields", outdir]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=timeout, cwd=ROOT)
+    if p.returncode != 0 and ("piso_comm_peer_create" in p.stderr or "piso_comm_peer_connect" in p.stderr):
+        pytest.skip("peer transport unavailable here")
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and lines, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
+    return json.loads(lines[-1])
+
+
+def test_sharded_config5_4096_eight_slabs_fields_after_fixed_iterations_vs_one_gpu():
+    """BASELINE config 5 (4096^2, 8 slabs, mailbox halo exchange + all-reduced dot products): one step forward + reverse sweep with
+    the pressure solves stopped after 100 UN-shifted CG iterations on both sides (the shifted operator's iterates are not
+    reproducible between summation orders) - FIELDS of the eight slabs against the one-GPU step, not just the loss.
+    (Eight processes share the box's one GPU: the CG runs its two-kernel iteration - eight persistent slab kernels of 128 workgroups
+    cannot be resident side by side on 256 CUs.)"""
+    common = ["--steps", "1", "--warmup", "0", "--grid", "4096", "--no-cpu-baseline", "--no-extras", "--max-iterations", "100", "--unshifted", "--tol", "1e-30", "--lin-tol", "1e-9"]
+    d1, d1b, d8 = tempfile.mkdtemp(prefix="cfg5_one_"), tempfile.mkdtemp(prefix="cfg5_one_b_"), tempfile.mkdtemp(prefix="cfg5_eight_")
+    one = _bench_dump({}, ["--gpus", "1"] + common, 1, d1)
+    _bench_dump({}, ["--gpus", "1", "--cg-persist", "0"] + common, 1, d1b)         # the yardstick: the one-GPU step on the two-kernel CG iteration
+    eight = _bench_dump({"PISO_BENCH_SHARE_GPU": "1", "PISO_BENCH_SLAB_CHECK": "0"}, ["--gpus", "8", "--decomp", "slab"] + common, 8, d8)
+    assert eight["n_gpus"] == 8 and eight["sharded"]["ranks_seen"] == 8 and eight["config"]["warn"] == 0.0
+    assert one["config"]["last_cg_iterations_fwd"] == 100 == eight["config"]["last_cg_iterations_fwd"]       # both sides ran into the cap
+    u1, p1, du1, dp1, _ = _gather(d1, 1, 4096, 4096)
+    yard = _gather(d1b, 1, 4096, 4096)[:4]
+    u, p, du, dp, edges = _gather(d8, 8, 4096, 4096)
+    # the SAME truncated computation on both sides: round-off (float32 glue, summation order of the dot products) is all that may differ
+    _compare_with_one_gpu("cfg5 x8", (u, p, du, dp), (u1, p1, du1, dp1), edges, 1e-6, yardstick=yard)
+    assert abs(one["config"]["loss"] - eight["config"]["loss"]) <= 1e-6 * abs(one["config"]["loss"])

@@ -50,6 +50,26 @@ def test_deferred_iteration_count_behaves_like_an_int():
     assert len(many._pending) <= 65 and many == 400
 
 
+
+def test_iteration_counts_leave_the_solver_as_plain_ints():
+    """`solver.last_iterations` and whatever is read out of `solver.stats` are ints even after asynchronous solves handed in
+    DeferredInt counts: json.dumps / numpy / torch see numbers (bench.py dumps exactly this pattern)."""
+    import json
+    import diffpiso as dp
+    from diffpiso.solvers import DeferredInt
+    ps = dp.PisoPressureSolverCudaCustom(dx=[])
+    ps.stats.add("iterations", DeferredInt(0, [torch.tensor([5], dtype=torch.int32)]))
+    ps.stats.add("iterations", 3)
+    ps.stats.add("solves", 2)
+    ps.last_iterations = DeferredInt(0, [torch.tensor([7], dtype=torch.int32)])
+    assert type(ps.last_iterations) is int and ps.last_iterations == 7 and ps.last_adjoint_iterations is None
+    assert json.loads(json.dumps(dict(ps.stats))) == dict(solves=2, iterations=8, adjoint_solves=0, adjoint_iterations=0)
+    assert json.dumps({"it": ps.stats["iterations"], "last": ps.last_iterations}) == '{"it": 8, "last": 7}'
+    assert int(np.asarray(ps.stats["iterations"])) == 8 and int(torch.tensor(ps.last_iterations)) == 7
+    for key in ps.stats:                                   # the reset idiom of bench.py
+        ps.stats[key] = 0
+    assert sum(ps.stats.values()) == 0
+
 def test_device_constant_uploads_once_and_notices_in_place_changes():
     """grids.device_constant: a small numpy array handed over again every step (the reference's scripts pass sim.dirichlet_values to every
     piso_step) is converted once and found again by identity + checksum; an array modified in place is converted again."""
