@@ -23,7 +23,60 @@ f32 = np.float32
 USE_OMP_CG = False
 
 
+RHS_ULP_NOISE = None      # np.random.Generator: every pressure right-hand side is moved by at most one float32 ulp (sensitivity tests)
+USE_NUMPY_CG = False      # a THIRD summation order of the same algorithm (numpy's pairwise reductions): tests that measure how far two
+                          # orders of the oracle itself drift apart on the shifted - indefinite - operator (small grids only)
+
+
+def cg_numpy(nx, ny, per_x, per_y, L, b, accuracy, max_iterations, rank_deficient, reset_steps):
+    """oracle_cg_f64 (oracle/piso_oracle.c, pressure_solve_op.cu.cc:140-418) restated with numpy: same control flow - zero initial
+    guess, reset every `reset_steps`, alpha guarded / beta unguarded, stopping test every 5th iteration with the device-flag
+    cadence - but every sum and dot product is numpy's (pairwise / blocked) instead of a left-to-right loop."""
+    N = nx * ny
+    L = np.asarray(L, np.float64).reshape(N, 5)
+    b = np.asarray(b, np.float64).ravel()
+    rows = np.arange(N)
+    i, j = rows % nx, rows // nx
+    off = np.array([-nx, -1, 0, 1, nx])
+    poff = np.array([N * per_y, nx * per_x, 0, -nx * per_x, -N * per_y])
+    onb = np.stack([j == 0, i == 0, np.zeros(N, bool), i == nx - 1, j == ny - 1], axis=1)
+    ci = (rows[:, None] + off[None, :] + onb * poff[None, :]) * (L != 0.0)          # calcZ_v4 :57-92 (index 0 where the coefficient is 0)
+
+    def apply(v, vsum):
+        return (L * v[ci]).sum(axis=1) + vsum
+
+    c = 0.1 / N * np.abs(L[:, 2]).sum() if rank_deficient else 0.0
+    x = np.zeros(N)
+    r = b - apply(x, c * x.sum() if rank_deficient else 0.0)
+    p = r.copy()
+    flag_dev, checker, it = 0, 1, 0
+    while it < max_iterations:
+        if (it + 1) % reset_steps == 0:
+            r = b - apply(x, c * x.sum() if rank_deficient else 0.0)
+            p = r.copy()
+            flag_dev = 0
+        z = apply(p, c * p.sum() if rank_deficient else 0.0)
+        p_r, p_z = float(np.dot(p, r)), float(np.dot(p, z))
+        alpha = p_r / p_z if abs(p_z) > 0.0 else 0.0
+        x = x + alpha * p
+        r = r - alpha * z
+        if checker % 5 == 0:
+            if np.any(np.abs(r) >= accuracy):
+                flag_dev = 0
+            if flag_dev:
+                it += 1
+                break
+            flag_dev = 1
+        checker += 1
+        beta = -float(np.dot(r, z)) / p_z
+        p = beta * p + r
+        it += 1
+    return x, it
+
+
 def _cg(nx, ny, per_x, per_y, L, b, tol, max_it, rank_deficient, reset, dt):
+    if USE_NUMPY_CG and dt == np.float64:
+        return cg_numpy(nx, ny, per_x, per_y, L, b, np.float32(tol), max_it, rank_deficient, reset)
     if USE_OMP_CG and dt == np.float64:
         return native.cg_solve_omp(nx, ny, per_x, per_y, L, b, tol, max_it, rank_deficient, reset)
     return native.cg_solve(nx, ny, per_x, per_y, L, b, tol, max_it, rank_deficient, reset, dt)
@@ -284,7 +337,10 @@ def pressure_solve(setup, a0_t, div):
     dt = np.float64 if s.p_double else np.float32
     a0 = flatten_staggered(np.asarray(a0_t, f32), coord_flip=False)
     L = native.laplace_matrix(s.nx, s.ny, s.active, s.accessible, a0, dt)
-    x, it = _cg(s.nx, s.ny, s.periodic_yx[1], s.periodic_yx[0], L, np.asarray(div).astype(dt).ravel(),
+    b = np.asarray(div).astype(dt).ravel()
+    if RHS_ULP_NOISE is not None:            # (sensitivity tests: the float32 right-hand side moved by at most one ulp, seeded)
+        b = (np.asarray(div, f32).ravel() * (f32(1) + f32(6e-8) * RHS_ULP_NOISE.choice(np.array([-1, 0, 1], f32), size=b.size))).astype(dt)
+    x, it = _cg(s.nx, s.ny, s.periodic_yx[1], s.periodic_yx[0], L, b,
                 s.p_tol, s.p_max_it, s.rank_deficient, s.p_reset, dt)
     return x.reshape(s.ny, s.nx).astype(f32), it, L
 

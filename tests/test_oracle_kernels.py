@@ -259,3 +259,23 @@ def test_cg_vs_dense_solve(name, reset):
     assert it % 5 == 0 and it >= 10 and (it % reset != 0)
     if s.rank_deficient:
         assert abs(x[act].mean()) < 1e-8
+
+
+@pytest.mark.parametrize("name", ["periodic", "xper_ywall", "cavity"])
+def test_cg_numpy_summation_order_is_the_same_algorithm(name):
+    """`piso_ref.cg_numpy` (the oracle CG with numpy's pairwise reductions: the second summation order that tests of the shifted,
+    indefinite operator measure the oracle's own spread with) follows the C oracle iterate by iterate on UN-shifted systems - same
+    control flow, resets and stopping cadence - and stops at the same iteration."""
+    c = make_case(name, 24, 40, seed=3)
+    s = oracle_setup(c, p_tol=1e-9, p_max_it=400, p_reset=10)
+    _, _, t = R.piso_step(s, c["vel"], c["p"], c["dt"], c["dirichlet_values"], None)
+    L, b = t["L1"], np.asarray(t["div1"], np.float64).ravel()
+    per_x, per_y = s.periodic_yx[1], s.periodic_yx[0]
+    for nit in (1, 9, 10, 11, 57):
+        xo, io = native.cg_solve(s.nx, s.ny, per_x, per_y, L, b, 1e-30, nit, False, 10)
+        xn, inn = R.cg_numpy(s.nx, s.ny, per_x, per_y, L, b, np.float32(1e-30), nit, False, 10)
+        assert io == inn == nit
+        assert np.linalg.norm(xo - xn) <= 1e-11 * np.linalg.norm(xo), (name, nit)
+    xo, io = native.cg_solve(s.nx, s.ny, per_x, per_y, L, b, 1e-6, 400, False, 25)
+    xn, inn = R.cg_numpy(s.nx, s.ny, per_x, per_y, L, b, np.float32(1e-6), 400, False, 25)
+    assert io == inn and io < 400 and np.linalg.norm(xo - xn) <= 1e-9 * np.linalg.norm(xo)
