@@ -303,6 +303,77 @@ def cpu_baseline(P, n, tol, cg_iters_per_step, bicg_solves_per_step=2, sample_it
                 % (n, sample_iters, threads, t_cg_iter, os.cpu_count(), t_asm, t_bicg, its, bicg_solves_per_step, cg_iters_per_step))
 
 
+def cpu_baseline_pricing_check(tol, max_it, reset, n=256):
+    """Is the PRICING of `cpu_baseline` right?  At n = 256 a whole CPU-oracle step (forward + reverse sweep, OpenMP CG, the bench's
+    solver settings) is cheap enough to be TIMED for real; the same step is then priced exactly as the 2048^2 figure is (one timed
+    assembly, one timed BiCGStab solve, a timed sample of CG iterations, multiplied by the counts the step needed).  Measured and
+    priced seconds stand side by side in the JSON line."""
+    from oracle import native as O, piso_ref as R
+    vel = turbulence_velocity(n)
+    dx = 2 * np.pi / n
+    dt = 0.5 * dx / float(np.abs(vel).max())
+    s = R.OracleSetup(n, n, (dx, dx), (True, True), np.zeros((1, n + 1, n + 1, 2), bool), np.ones((1, n + 2, n + 2, 1), np.float32),
+                      np.ones((1, n + 2, n + 2, 1), np.float32), viscosity=1e-3, lin_tol=tol, lin_max_it=min(max_it, 2000), p_tol=tol,
+                      p_max_it=max_it, p_reset=reset)
+    dvals = np.zeros((1, n + 1, n + 1, 2), np.float32)
+    R.USE_OMP_CG = True
+    try:
+        O.cg_solve_omp(n, n, True, True, O.laplace_matrix(n, n, s.active, s.accessible, np.ones(2 * n * (n + 1), np.float32)),
+                       np.zeros(n * n), 1e-30, 4, True, 1000)                       # (spin up the thread pool)
+        t0 = time.perf_counter()
+        vo, po, tape = R.piso_step(s, vel, np.zeros((n, n), np.float32), dt, dvals, None)
+        g = R.piso_step_backward(s, tape, vo, np.zeros_like(po))
+        measured = time.perf_counter() - t0
+    finally:
+        R.USE_OMP_CG = False
+    cg_its = int(tape["it1"]) + int(tape["it2"]) + int(sum(tape.get("adjoint_its", [])))
+    beta = dx * dx / dt
+    t0 = time.perf_counter()
+    val, rp, col, A_t, A_flat = R.advection_matrix(s, vel, beta)
+    t_asm = time.perf_counter() - t0
+    rhs = (R.flatten_staggered(vel, True) * np.float32(beta)).astype(np.float32)
+    t0 = time.perf_counter()
+    x, warn, its = O.multi_bicgstab_ilu(-val, rp, col, rhs, R.flatten_staggered(vel, True), s.n_u, s.n_v, tol, 100)
+    t_bicg = time.perf_counter() - t0
+    a0 = ((np.float32(1) / (np.float32(beta) - A_t)) * np.float32(1.0)).astype(np.float32)
+    L = O.laplace_matrix(n, n, s.active, s.accessible, R.flatten_staggered(a0, False))
+    div = R.fv_divergence(R.stagger_flattened(x, n, n, True), s.dx_yx).astype(np.float64).ravel()
+    sample = 2000
+    t0 = time.perf_counter()
+    O.cg_solve_omp(n, n, True, True, L, div, 1e-30, sample, True, 1000)
+    t_cg = (time.perf_counter() - t0) / sample
+    priced = 2 * t_asm + 2 * t_bicg + cg_its * t_cg
+    return {"grid": [n, n], "measured_s_per_step": measured, "priced_s_per_step": priced, "priced_over_measured": priced / measured,
+            "cg_iterations_of_the_step": cg_its,
+            "note": "a whole oracle step (forward + reverse sweep) timed for real at %d^2 against the pricing formula of the %s figure: "
+                    "2 assemblies (%.3f s) + 2 BiCGStab solves (%.3f s) + CG iterations x %.2e s; what the formula leaves out is the "
+                    "numpy glue of the step" % (n, "2048^2", t_asm, t_bicg, t_cg)}
+
+
+def sharded_headline(attempt, share_gpu):
+    """The `--decomp auto` policy for the headline of an N > 1 run, as a pure function of what the attempts report (CPU-testable:
+    tests/test_host_cpu.py).  attempt(transport, port_offset, limit_s) -> (rank 0's child line or None, error dict or None,
+    every rank's attempt ended well, the child said this transport cannot be set up here).  Order: the PEER transport (mailboxes
+    over hipIpc / xGMI, persistent slab CG); only if the environment REFUSES it - and every rank has its own GPU - the RCCL transport,
+    once; else the replicas figure alone.  Returns (child line to adopt or None, text for sharded_run.skipped or None, error dict
+    for sharded_run or None, exit code): a refused transport is reported and exits 0; a run that FAILED or hung exits 3."""
+    child, err, all_ok, refused = attempt("peer", 11, 600)
+    if not all_ok:
+        return None, None, err or {"error": "another rank's sharded run failed"}, 3
+    if not refused:
+        if child is None:
+            return None, None, err or {"error": "the sharded run printed no line"}, 0
+        return child, None, None, 0
+    skipped = "peer transport could not be set up here: " + str((child or {}).get("sharded_unavailable", "see the other ranks"))
+    if share_gpu:                  # (RCCL refuses two ranks on one device: nothing else to try)
+        return None, skipped, None, 0
+    child2, err2, ok2, refused2 = attempt("rccl", 13, 420)
+    if ok2 and not refused2 and child2 is not None:
+        return child2, None, None, 0
+    # whatever happens to the RCCL attempt is reported, never fatal: that path cannot run with more than one rank before it meets a node
+    return None, skipped + "; the RCCL transport was tried instead: " + json.dumps(err2 or {"error": "it failed on another rank or was refused as well"}), None, 0
+
+
 def kernel_source_sha():
     h = hashlib.sha256()
     for f in ("cg_persist.h", "cg_persist1.h", "cg_kernels.h", "cg.hip", "peer.h"):
@@ -592,6 +663,10 @@ def main():
         from diffpiso.distributed import SlabCommunicator
         from diffpiso.sharding import StepSharding
         # mailbox rows: the longest halo message is two face rows of u and three of v, five matrix values each
+        def stage(text):       # (the parent of a sharded child that hangs reports the last stage it saw)
+            if args.sharded_child and rank == 0:
+                print("STAGE " + text, flush=True)
+        stage("transport set-up (%s, %d ranks)" % (args.transport, world))
         comm_err = None
         try:
             P["ps"].slab_comm = SlabCommunicator(rank=rank, world=world, device=device, transport=args.transport, row_capacity=26 * n + 64)
@@ -623,6 +698,8 @@ def main():
     elif args.cg_persist >= 0:
         N.set_option("cg_persist", args.cg_persist)
     torch.cuda.reset_peak_memory_stats(device)
+    if args.sharded_child and rank == 0:
+        print("STAGE warm-up (%d unrolled step%s of the sharded box)" % (args.warmup, "" if args.warmup == 1 else "s"), flush=True)
     for _ in range(args.warmup):
         run_unrolled(P, 1)
     if args.warmup > 0:
@@ -642,6 +719,8 @@ def main():
             s_[k_] = 0
     N.lib.piso_cg_profile_enable(1, 16)              # HIP-event timing of every persistent segment / every 16th K1, K2 launch
     clock = {}
+    if args.sharded_child and rank == 0:
+        print("STAGE timed run (%d steps)" % args.steps, flush=True)
     barrier()
     t0 = time.perf_counter()
     keep = {} if args.dump_fields else None
@@ -806,6 +885,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline and ny_grid == n:
             try:
                 out["cpu_baseline"] = cpu_baseline(P, n, args.tol, int(round(cg_per_step)) or 4000)
+                try:
+                    out["cpu_baseline"]["pricing_check"] = cpu_baseline_pricing_check(args.tol, args.max_iterations, args.residual_reset)
+                except Exception as e:
+                    out["cpu_baseline"]["pricing_check"] = {"error": repr(e)}
             except Exception as e:   # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     rc = 0
@@ -829,6 +912,7 @@ def main():
             env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset),
                        MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"))
             env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+            env.setdefault("NCCL_DEBUG", "WARN")               # (a failing RCCL set-up says why on stderr: the tail travels in sharded_run)
             cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", "--decomp", "slab-weak", "--transport", transport, "--gpus", str(world),
                    "--grid", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup), "--tol", repr(args.tol),
                    "--max-iterations", str(args.max_iterations), "--residual-reset", str(args.residual_reset), "--no-cpu-baseline", "--no-extras"]
@@ -843,8 +927,13 @@ def main():
                     child = json.loads(lines[-1]) if lines else None
                     if child is None:
                         err = {"error": "the sharded run (%s transport) printed no line" % transport, "stderr_tail": cp.stderr[-800:]}
-            except subprocess.TimeoutExpired:
-                err = {"error": "the sharded run (%s transport) timed out after %d s" % (transport, limit_s)}
+            except subprocess.TimeoutExpired as te:
+                # which stage was it in?  the child prints a STAGE line before every phase (set-up, warm-up, timed run)
+                so = te.stdout.decode(errors="replace") if isinstance(te.stdout, bytes) else (te.stdout or "")
+                se = te.stderr.decode(errors="replace") if isinstance(te.stderr, bytes) else (te.stderr or "")
+                stages = [l for l in so.splitlines() if l.startswith("STAGE ")]
+                err = {"error": "the sharded run (%s transport) timed out after %d s" % (transport, limit_s),
+                       "last_stage": stages[-1][6:] if stages else "before the transport was set up", "stderr_tail": se[-800:]}
             except Exception as e:
                 err = {"error": repr(e)}
             # [0]: every rank's attempt ended well; [1]: rank 0's child said the transport cannot be set up here
@@ -853,38 +942,21 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return child, err, bool(t[0].item() > 0), bool(t[1].item() < 0)
 
-        child, err, all_ok, refused = sharded_attempt("peer", 11, 600)
-        skipped = None
-        if all_ok and refused:
-            # hipIpc handles / peer access refused by the environment: not a failure.  The RCCL transport carries the same sharded step
-            # (send / recv + all-reduce on the stream, two-kernel CG: slower) - tried once, and whatever happens to it is reported,
-            # never fatal: that path cannot be exercised with more than one rank before it meets a multi-GPU node.
-            skipped = "peer transport could not be set up here: " + str((child or {}).get("sharded_unavailable", "see the other ranks"))
-            if not share_gpu:
-                child2, err2, ok2, refused2 = sharded_attempt("rccl", 13, 420)
-                if ok2 and not refused2:
-                    child, err = child2, None
-                    skipped = None
-                else:
-                    child = None
-                    skipped += "; the RCCL transport was tried instead: " + json.dumps(err2 or {"error": "it failed on another rank or was refused as well"})
+        child, skipped, err, rc_sharded = sharded_headline(sharded_attempt, share_gpu)
         if rank == 0:
             replicas = {"value": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak",
                         "note": "one independent %d^2 problem per GPU, no data-path collective (the run timed first)" % n}
-            if all_ok and skipped is not None:
-                out["sharded_run"] = {"skipped": skipped}
-                out["replicas_only"] = True
-            elif all_ok and child is not None:
+            if child is not None:
                 for k in ("value", "ms_per_step", "scaling", "config", "roofline", "phases", "sharded"):
                     if k in child:
                         out[k] = child[k]
                 out["replicas"] = replicas
                 out["parallel_efficiency_vs_replicas"] = out["value"] / replicas["value"]
             else:
-                out["sharded_run"] = err or {"error": "another rank's sharded run failed"}
+                out["sharded_run"] = {"skipped": skipped} if skipped is not None else (err or {"error": "another rank's sharded run failed"})
                 out["replicas_only"] = True
-        if not all_ok:
-            rc = 3
+        if rc_sharded:
+            rc = rc_sharded
     if world > 1 and not slab and os.environ.get("PISO_BENCH_SLAB_CHECK", "1") != "0":
         # Not part of the metric: exercise the slab-decomposed solvers on the real multi-GPU node; the result travels INSIDE the
         # JSON line (`slab_cg_self_check`).  Every rank runs it in a CHILD process (own process group on the next port): the
@@ -954,6 +1026,66 @@ def self_check_child(args):
         pass
 
 
+def config4_training_iteration(device, steps=16):
+    """BASELINE config 4: spatially evolving mixing layer 1024 x 256 with the CNN closure in the loop (VALID padding + restore_shape, no
+    closure inside the sponge: spatial_mixing_layer_differentiable_training.py:6-10,46-55), the reference's training settings
+    (solver precision 1e-6, 10000 iterations, reset 1000: combined_training_integrated.py:487-490), ONE training iteration = a 16-step
+    unroll through the reference-signature run_piso_steps forward + the reverse sweep down to the convolution kernels' gradients.
+    Synthetic start: the inlet's tanh profile everywhere plus a seeded perturbation; random-init network damped to a perturbation."""
+    import torch
+    import torch.nn.functional as F
+    import diffpiso as dp
+    phys = {"average_velocity": 1, "velocity_difference": 1, "inlet_profile_sharpness": 2, "viscosity": .002}
+    simpar = {"HRres": [256, 1024], "dx_ratio": 1, "dt": 0.4, "dt_ratio": 1, "box": dp.box[0:256, 0:1024], "sponge_ratio": .875, "relative_sponge_max": 20}
+    domain, sim, psolver, velocity, pressure, visc, bcx = dp.spatialMixingLayer_setup(simpar, 1e-6, phys, step_count=steps, device=device)
+    ny, nx = 256, 1024
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    v0 = torch.zeros((1, ny + 1, nx + 1, 2))
+    v0[0, :ny, :, 1] = torch.tensor(bcx[0, 1:-1, 0, 0])[:, None] + 0.02 * torch.randn((ny, nx + 1), generator=gen)
+    v0[0, 1:ny, :nx, 0] = 0.02 * torch.randn((ny - 1, nx), generator=gen)
+    dmask = torch.tensor(np.asarray(sim.dirichlet_mask))
+    v0 = torch.where(dmask, torch.tensor(np.asarray(sim.dirichlet_values, np.float32)), v0).to(device)
+    sim.dirichlet_values = torch.tensor(np.asarray(sim.dirichlet_values, np.float32), device=device)
+    net, weights, _ = dp.initialise_fullyconv_network([[0, 0], [0, 0]], padding="VALID", restore_shape=True, seed=1)
+    net = net.to(device)
+    with torch.no_grad():
+        for w in net.weights:
+            w.mul_(0.6)
+
+    def wrapper(neural_network, input, fluid, physical_parameters, simulation_parameters, loss_buffer_width, buffer_width):
+        sponge_start = int(simulation_parameters["HRres"][1] * simulation_parameters["sponge_ratio"]) // simulation_parameters["dx_ratio"]
+        out = neural_network(input[:, :, :sponge_start, :])
+        return F.pad(out, (0, 0, 0, int(fluid.resolution[1]) - sponge_start))
+
+    td = dict(step_count=steps, loss_influence_range=steps + 1, pressure_included=True, HR_buffer_width=[[0, 0], [0, 0]])
+
+    def iteration():
+        for w in net.weights:
+            w.grad = None
+        vel = dp.StaggeredGrid(v0.clone(), domain.box, extrapolation=velocity.extrapolation)
+        out = dp.run_piso_steps(vel, pressure, domain, phys, simpar, td, net, wrapper, sim, visc, None, None)
+        loss = 0.5 * (out[3].staggered_tensor() ** 2).sum()
+        loss.backward()
+        return float(loss.detach()), float(sum(float(w.detach().sum()) for w in out[6]))
+
+    for s_ in (psolver.stats, sim.linear_solver.stats):
+        for k_ in s_:
+            s_[k_] = 0
+    iteration()
+    torch.cuda.synchronize()
+    it0 = (psolver.stats["iterations"], psolver.stats["adjoint_iterations"])
+    t0 = time.perf_counter()
+    loss, warn = iteration()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0)
+    gnorm = float(torch.sqrt(sum((w.grad.double() ** 2).sum() for w in net.weights)))
+    return {"ms_per_training_iteration": ms, "unrolled_steps": steps, "ms_per_unrolled_step": ms / steps,
+            "cg_iterations_fwd_adjoint": [psolver.stats["iterations"] - it0[0], psolver.stats["adjoint_iterations"] - it0[1]],
+            "loss": loss, "weight_grad_norm": gnorm, "solver_warnings": warn,
+            "what": "1024 x 256 spatial mixing layer + sponge, 7-layer CNN closure (fp32 MFMA convolutions) in every step, forward + reverse "
+                    "sweep down to the convolution kernels, solver precision 1e-6 / 10000 iterations / reset 1000"}
+
+
 def other_configs(device):
     """Driver-visible timings of the smaller BASELINE.json configurations (extra keys, not the headline)."""
     import torch
@@ -986,6 +1118,10 @@ def other_configs(device):
     torch.cuda.synchronize()
     res["config3_512x256_fwd_adjoint_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / 4
     res["config3_last_cg_iterations_fwd_adjoint"] = [P3["ps"].last_iterations, P3["ps"].last_adjoint_iterations]
+    try:                                                                # config 4: one training iteration with the CNN closure in the loop
+        res["config4_1024x256_cnn_closure_16_step_unroll"] = config4_training_iteration(device)
+    except Exception as e:
+        res["config4_1024x256_cnn_closure_16_step_unroll"] = "failed: %r" % (e,)
     # config 5's grid on ONE GPU: the state of a 4096^2 solve (3 x 134 MB) does not fit the chip, so the CG runs the two-kernel
     # iteration (cg_k1 / cg_k2) -- the case the 8-slab decomposition is for (8 slabs of 4096 x 512 fit their GPUs' registers + LDS)
     import ctypes as C

@@ -316,3 +316,45 @@ def test_build_from_a_tree_without_binaries(tmp_path):
     assert os.path.isfile(dst / "oracle" / "_build" / "libpiso_oracle.so") and os.path.isfile(dst / "oracle" / "_build" / "libpiso_oracle_omp.so")
     lib = ctypes.CDLL(built)
     assert b"gfx950" in ctypes.cast(lib.piso_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()
+
+
+def test_bench_auto_policy_tries_peer_then_rccl_then_reports_replicas():
+    """bench.py's `--decomp auto` policy for the N > 1 headline (bench.sharded_headline), with stub attempts: the peer transport
+    first; the RCCL transport only if the environment REFUSES the peer transport and every rank has its own GPU; a refused transport
+    is reported next to the replicas figure with exit code 0, a run that failed or hung costs exit code 3 - and nothing is tried
+    after a failure."""
+    import bench
+    line = {"value": 30.0, "ms_per_step": 266.0, "sharded": {"ranks_seen": 8}}
+    refused = {"sharded_unavailable": "hipIpcGetMemHandle: invalid argument"}
+
+    def script(*answers):
+        calls, it = [], iter(answers)
+
+        def attempt(transport, port_offset, limit_s):
+            calls.append((transport, port_offset, limit_s))
+            return next(it)
+        return attempt, calls
+
+    # 1. the peer transport works: its line is the headline, nothing else is tried
+    att, calls = script((line, None, True, False))
+    assert bench.sharded_headline(att, False) == (line, None, None, 0) and [c[0] for c in calls] == ["peer"]
+    # 2. peer refused by the environment, one GPU per rank: RCCL is tried once and carries the headline
+    att, calls = script((refused, None, True, True), (line, None, True, False))
+    assert bench.sharded_headline(att, False) == (line, None, None, 0) and [c[0] for c in calls] == ["peer", "rccl"]
+    assert calls[0][1] != calls[1][1]                                  # the two attempts rendezvous on different ports
+    # 3. peer refused and the RCCL attempt fails / hangs: reported, replicas only, exit code 0 (that path cannot be tested before it meets a node)
+    att, calls = script((refused, None, True, True), (None, {"error": "timed out after 420 s", "last_stage": "transport set-up (rccl, 8 ranks)"}, False, False))
+    child, skipped, err, rc = bench.sharded_headline(att, False)
+    assert child is None and err is None and rc == 0 and [c[0] for c in calls] == ["peer", "rccl"]
+    assert "hipIpcGetMemHandle" in skipped and "RCCL transport was tried instead" in skipped and "last_stage" in skipped
+    # 4. peer refused while the ranks share one GPU (RCCL refuses two ranks per device): nothing else to try
+    att, calls = script((refused, None, True, True))
+    child, skipped, err, rc = bench.sharded_headline(att, True)
+    assert child is None and rc == 0 and "could not be set up" in skipped and [c[0] for c in calls] == ["peer"]
+    # 5. the peer run FAILED on some rank (not refused): exit code 3, replicas only, RCCL is not a fall-back for failures
+    att, calls = script((None, {"error": "the sharded run (peer transport) ended with code 1", "stderr_tail": "..."}, False, False))
+    child, skipped, err, rc = bench.sharded_headline(att, False)
+    assert child is None and skipped is None and rc == 3 and "ended with code 1" in err["error"] and [c[0] for c in calls] == ["peer"]
+    # 6. ... also when this rank's own attempt looked fine but another rank's did not
+    att, calls = script((line, None, False, False))
+    assert bench.sharded_headline(att, False)[3] == 3
