@@ -1,8 +1,8 @@
-"""The PISO step on fused HIP glue kernels (csrc/glue.hip) -- the fast path behind `piso_step`.
+"""The PISO step on fused HIP glue kernels (csrc/glue.hip) -- the implementation behind `piso_step`.
 
-Same mathematics, statement for statement, as `piso._piso_step_reference` (the torch transcription of
-diffpiso/piso_tf.py:11-81), but every stencil / layout / element-wise statement of the step is ONE launch on the flat
-"u-first" face vector instead of ~10 torch ops each, forward and reverse mode:
+Same mathematics, statement for statement, as diffpiso/piso_tf.py:11-81 (the torch transcription that the tests hold this to is
+tests/piso_step_transcription.py), with every stencil / layout / element-wise statement of the step as ONE launch on the flat
+"u-first" face vector instead of ~10 framework ops each, forward and reverse mode:
 
   piso_pad_velocity          custom_padded + flatten                                   (piso_helpers.py:35-55, piso_tf.py:93)
   piso_face_forward  RHS     beta u - G(p) + f dxdy, Dirichlet rows                    (piso_tf.py:36-39, piso_helpers.py:169-172, :236-274)

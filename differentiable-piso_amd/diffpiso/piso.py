@@ -1,9 +1,9 @@
 """The PISO step: implicit advection-diffusion predictor + two pressure correctors on a 2-D staggered grid.
 
 Host-side mirror of diffpiso/piso_tf.py (piso_step, advection_matrix_cuda, pressure_extrapolation, SimulationParameters):
-same names, argument order and return values; the three heavy operations call libpiso_hip.so through the C ABI
-(include/piso_hip.h), the element-wise glue is torch on the device, reverse mode is torch autograd with custom nodes
-for the solves (frozen-coefficient adjoint: no gradient through matrix assembly, diffpiso/piso_tf.py:125-126).
+same names, argument order and return values; assembly, the two linear solves and the stencil glue call libpiso_hip.so through
+the C ABI (include/piso_hip.h; fused.py), reverse mode is torch autograd with custom nodes for the solves and the glue
+(frozen-coefficient adjoint: no gradient through matrix assembly, diffpiso/piso_tf.py:125-126).
 """
 import ctypes as C
 
