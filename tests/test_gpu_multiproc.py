@@ -13,12 +13,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_parent_gpu_memory():
+    """The ranks are child processes on the SAME GPU: hand back what this (pytest) process has cached there - after the full-size
+    fixture tests that is tens of GB, and eight children of a 4096^2 step on top of it have run one of them out of memory."""
+    import gc
+    import torch
+    gc.collect()
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
+
 def run_ranks(world, nx, ny, walls, timeout=600, worker="slab_worker.py", extra=None):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    _free_parent_gpu_memory()
     tail = [str(nx), str(ny), str(int(walls)), "1"] if extra is None else extra
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker), str(r), str(world), str(port)] + tail,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
@@ -72,6 +85,7 @@ def test_bench_two_ranks_on_one_gpu():
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PISO_BENCH_SHARE_GPU="1")
+    _free_parent_gpu_memory()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "1024",
            "--max-iterations", "300"]
@@ -121,6 +135,7 @@ def _bench(env_extra, args, nproc):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    _free_parent_gpu_memory()
     if nproc > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
@@ -144,6 +159,8 @@ def _bench(env_extra, args, nproc):
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     if p.returncode != 0 and ("piso_comm_peer_create" in p.stderr or "piso_comm_peer_connect" in p.stderr):
         pytest.skip("peer transport unavailable here")
+    if p.returncode != 0 or not lines:
+        print("bench.py %s ended with code %d; stderr tail:\n%s" % (" ".join(args), p.returncode, p.stderr[-6000:]))     # (untruncated, unlike the assertion's repr)
     assert p.returncode == 0 and lines, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
     return json.loads(lines[-1])
 

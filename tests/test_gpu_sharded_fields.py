@@ -17,6 +17,18 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_parent_gpu_memory():
+    """The ranks are child processes on the SAME GPU: hand back what this (pytest) process has cached there - after the full-size
+    fixture tests that is tens of GB, and eight children of a 4096^2 step on top of it have run one of them out of memory."""
+    import gc
+    import torch
+    gc.collect()
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -26,6 +38,7 @@ def _spawn(world, case, timeout=600):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    _free_parent_gpu_memory()
     out = tempfile.mkdtemp(prefix="sharded_")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(r), str(world), str(port), case, out],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
@@ -185,6 +198,7 @@ def _bench_dump(env_extra, args, nproc, outdir, timeout=600):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    _free_parent_gpu_memory()
     cmd = [sys.executable]
     if nproc > 1:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)]
@@ -193,6 +207,8 @@ def _bench_dump(env_extra, args, nproc, outdir, timeout=600):
     if p.returncode != 0 and ("piso_comm_peer_create" in p.stderr or "piso_comm_peer_connect" in p.stderr):
         pytest.skip("peer transport unavailable here")
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        print("bench.py %s ended with code %d; stderr tail:\n%s" % (" ".join(args), p.returncode, p.stderr[-6000:]))
     assert p.returncode == 0 and lines, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
     return json.loads(lines[-1])
 
