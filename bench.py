@@ -61,10 +61,10 @@ BICG_BYTES_PER_ROW_ONCE = 148.0  # ILU0 factor 88 + initial residual 60
 PERSIST_STENCIL_PASSES = 2
 PERSIST_PUBLISHED_VECTORS = {1: 1, 2: 2}   # exchanges per iteration -> vectors whose perimeters are published (2: r and p; 1: z')
 # floors of one persistent iteration (scripts/barrier_bench.hip, scripts/fp64_rate.hip measured on MI355X)
-EXCHANGE_US = 4.4            # one tagged-record grid exchange over 256 workgroups
+EXCHANGE_US = 2.4            # one tagged-record grid exchange over 256 workgroups as a tree over the XCDs (barrier_bench V30 / V31; flat: 3.7 - 5.3)
 FP64_ISSUE_CYCLES = 4.75     # cycles per fp64 VALU instruction per SIMD with two waves resident
-FP64_INSTR_PER_CELL = {1: 29.2, 2: 38}   # counted in the ISA of cg_persist1: 935 fp64 add / fma per wave and iteration, 32 cells per lane
-VALU_INSTR_PER_CELL = {1: 52.3, 2: None}   # ... of 1674 VALU instructions in all (round 2: 2034) (conversions, DPP shifts, lane reads, moves): EVERY
+FP64_INSTR_PER_CELL = {1: 30.6, 2: 38}   # counted in the ISA of cg_persist1 (scripts/isa_loop.py): 980 fp64 instructions per wave and iteration, 32 cells per lane
+VALU_INSTR_PER_CELL = {1: 50.2, 2: None}   # ... of 1606 VALU instructions in all (round 3: 1674, round 2: 2034) (conversions, DPP shifts, lane reads, moves): EVERY
                                            # VALU instruction of a 64-wide wave costs ~4.5 SIMD cycles (scripts/fp64_rate.hip)
 CLOCK_GHZ = 2.4
 

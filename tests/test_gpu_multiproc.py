@@ -195,6 +195,7 @@ def test_decomposed_step_two_ranks_matches_one_gpu():
     assert abs(one["config"]["last_cg_iterations_fwd"] - two["config"]["last_cg_iterations_fwd"]) <= 30
 
 
+@pytest.mark.eight_ranks
 def test_config5_4096_eight_slabs():
     """BASELINE.json config 5 at its size and rank count: decaying turbulence 4096^2, 8-slab decomposition, mailbox halo exchange and
     all-reduced dot products - eight processes (here: sharing the one GPU, so the CG runs its two-kernel iteration; eight

@@ -213,6 +213,7 @@ def _bench_dump(env_extra, args, nproc, outdir, timeout=600):
     return json.loads(lines[-1])
 
 
+@pytest.mark.eight_ranks
 def test_sharded_config5_4096_eight_slabs_fields_after_fixed_iterations_vs_one_gpu():
     """BASELINE config 5 (4096^2, 8 slabs, mailbox halo exchange + all-reduced dot products): one step forward + reverse sweep with
     the pressure solves stopped after 100 UN-shifted CG iterations on both sides (the shifted operator's iterates are not
