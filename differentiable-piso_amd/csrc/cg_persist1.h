@@ -156,11 +156,17 @@ __device__ __forceinline__ F karg(unsigned off) {
 #ifndef PISO_PERSIST1_HIER
 #define PISO_PERSIST1_HIER 1                    // chip-wide launches exchange through the tree workgroup -> XCD leader -> everybody (grid_exchange8_hier)
 #endif
+#ifndef PISO_PERSIST1_SH_LATE
+#define PISO_PERSIST1_SH_LATE 1
+#endif
+#ifndef PISO_PERSIST1_PARK_RING
+#define PISO_PERSIST1_PARK_RING 1
+#endif
 #ifndef PISO_PERSIST1_LOCAL_ALL
 #define PISO_PERSIST1_LOCAL_ALL 1               // XCD-local launches: every wave polls the group's records (no second barrier): grid_exchange8_local
 #endif
 #ifndef PISO_PERSIST1_AHEAD
-#define PISO_PERSIST1_AHEAD 0                   // rows of z' = L p that the U pass finds precomputed (see kAhead)
+#define PISO_PERSIST1_AHEAD 2                   // rows of z' = L p that the U pass finds precomputed (see kAhead)
 #endif
 #ifndef PISO_PERSIST1_PACK
 #define PISO_PERSIST1_PACK 1                    // end cells of a region's rows published as one packed block per region (see kPack)
@@ -731,7 +737,11 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   constexpr bool kRingLds = (!SLAB || PISO_PERSIST1_RING_SLAB != 0) && sizeof(CT) == 4 && (NQ == 1 || PISO_PERSIST1_RING_SMALL != 0);
   // kLean: the round-3 forms of the end-cell store (range-checked, all lanes) and of the coefficient offset (kept in a VGPR)
   constexpr bool kLean = !SLAB || PISO_PERSIST1_LEAN_SLAB != 0;
-  constexpr int kRingBytes = 64 * (int)sizeof(T) + 64 * (int)sizeof(CT);
+  // kParkRing: the ring-column copies of p AND r (one value per lane) live in the wave's LDS ring block between their two uses per
+  // iteration (D's start, U's end) instead of in registers across both row loops
+  constexpr bool kParkRing = kRingLds && PISO_PERSIST1_PARK_RING != 0;
+  constexpr int kRingBytes = 64 * (int)sizeof(T) + 64 * (int)sizeof(CT) + (kParkRing ? 64 * (int)sizeof(T) : 0);
+  constexpr unsigned kRingR = 64u * (unsigned)sizeof(T) + 64u * (unsigned)sizeof(CT);      // byte offset of the parked r column inside a ring block
   __shared__ __attribute__((aligned(16))) unsigned char ring_s[kRingLds ? kPersistWaves * NQ * kRingBytes : 16];
   const int nx = a.nx, ny = a.ny;
   const int lane = threadIdx.x & 63;
@@ -1012,6 +1022,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // coefficients are still in registers.  Same instructions on the same registers as D's z': bitwise the same values.
   constexpr int kAhead = (kHier && kZigZag && NQ == 1 && NT == 16 && SYM && RECON && sizeof(T) == 8 && sizeof(CT) == 4) ? PISO_PERSIST1_AHEAD : 0;
   static_assert(kAhead <= Dw || kAhead == 0, "the rows computed ahead are rows whose coefficients D left in registers");
+  constexpr bool kShLate = kAhead > 0 && !SLAB && NQ == 1 && SYM && PISO_PERSIST1_SH_LATE != 0;
   constexpr int kRes = (NQ == 1 && NT == 16 && SYM && RECON) ? PISO_PERSIST1_RESIDENT : 0;
   auto issue_coef = [&](int t) __attribute__((always_inline)) {
     if (t < kRes && !first_fill) return;
@@ -1033,6 +1044,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   typedef __attribute__((address_space(3))) unsigned char lds_u8;
   unsigned ring_a = (unsigned)(unsigned long)(lds_u8*)ring_s + (unsigned)(wave * NQ * kRingBytes);
   asm volatile("" : "+v"(ring_a));
+  if constexpr (kParkRing) {                                 // the entry's ring columns go to the wave's block at once
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const unsigned rb = ring_a + (unsigned)(q * kRingBytes) + (unsigned)lane * (unsigned)sizeof(T);
+      *(lds_T*)(unsigned long)rb = edge[q];
+      *(lds_T*)(unsigned long)(rb + kRingR) = eR[q];
+    }
+  }
   if constexpr (SYM) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -1051,6 +1070,16 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       cSh[q] = bld<CT, V>(RoS, (has[q] && valid) ? coef_offset(q) : 0xffffffffu, (unsigned)jw * rowC);
     }
   }
+  // kShLate (with kAhead, one 16-row region, no slab edge): S of the row above the region is requested again in every D pass together
+  // with the coefficients of the region's last row - its registers are then free from the rows computed ahead to the next request
+  // (across U and the first rows of D) instead of held for the whole launch
+  auto reload_csh = [&]() __attribute__((always_inline)) {
+    if constexpr (SYM && NQ == 1) {
+      bool valid;
+      const int jw = row_wrap(j0[0] + R, valid);
+      cSh[0] = bld<CT, V>(RoS, (has[0] && valid) ? coef_offset(0) : 0xffffffffu, (unsigned)jw * rowC);
+    }
+  };
   // the ring values of row t (every lane receives them; lanes 0 / 63 are the ones that matter): issued one row ahead
   T rgl[NT], rgr[NT];
   CT rgw[NT];
@@ -1231,8 +1260,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
 #pragma unroll
           for (int e = 0; e < V; ++e) pp[q][jj].v[e] = fma(beta, pp[q][jj].v[e], rr[q][jj].v[e]);
         }
+        if constexpr (kParkRing) {
+          const unsigned rb = ring_a + (unsigned)(q * kRingBytes) + (unsigned)lane * (unsigned)sizeof(T);
+          const T e_old = *(lds_T*)(unsigned long)rb, r_col = *(lds_T*)(unsigned long)(rb + kRingR);
+          *(lds_T*)(unsigned long)rb = fma(beta, e_old, r_col);
+        } else {
         edge[q] = fma(beta, edge[q], eR[q]);
         if constexpr (kRingLds) *(lds_T*)(unsigned long)(ring_a + (unsigned)(q * kRingBytes) + (unsigned)lane * (unsigned)sizeof(T)) = edge[q];
+        }
         T* hs = halo_s + (kParkHalos ? (size_t)((wave * NQ + q) * 2) * 64 * V + lane * V : 0);
         if constexpr (kParkHalos) {
           pnb[q] = ldv<T, V>(hs); pna[q] = ldv<T, V>(hs + 64 * V);
@@ -1268,6 +1303,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         // (rows 0 .. D-1 of the U pass are issued behind the drain of the perimeter stores, see the exchange: issued here they would
         // be in flight when the wave waits for vmcnt(0), and the wait would cover their trip as well)
         if constexpr (D < NT) { if (t + D < NT || !(kPrefetchBehindDrain || kZigZag)) issue_coef(t + D < NT ? t + D : t + D - NT); }
+        if constexpr (kShLate) { if (t + D == NT - 1) reload_csh(); }
         PISO_SB_A2;
       }
     }
@@ -1385,7 +1421,12 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           const bool ok = (side == 0 ? lcol_ok[q] : rcol_ok[q]) && j0[q] + er_unused < a.ny_true;
           if (!ok) vse = 0;
         }
+        if constexpr (kParkRing) {
+          const unsigned rb = ring_a + (unsigned)(q * kRingBytes) + (unsigned)lane * (unsigned)sizeof(T) + kRingR;
+          *(lds_T*)(unsigned long)rb = fma(-alpha, eZ[q] + vse, (T) * (lds_T*)(unsigned long)rb);
+        } else {
         eR[q] = fma(-alpha, eZ[q] + vse, eR[q]);
+        }
       }
       lU[1] = (lane == 0) ? (T)cnt_wave : (T)0;              // (the exchange adds the lanes of a wave)
     }
