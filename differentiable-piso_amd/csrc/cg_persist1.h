@@ -21,6 +21,10 @@
 // Every region keeps copies of r and p on the ring of cells around it and advances them with the SAME fma's as their
 // owners (bitwise equal), using the published perimeter of z' - so one vector's perimeter crosses the fabric per iteration
 // instead of two, and nothing has to be visible between D and U of one iteration: one exchange.
+// Round 4: the exchange is a tree that follows the hardware (workgroup -> XCD leader through that XCD's L2 -> everybody: every wave
+// polls the eight XCD records itself, no second barrier; grid_exchange8_hier), the end cells of a region's rows are published as
+// one packed block per region (kPack: the L2 was full of single-cell cache lines), z' of U's first rows is computed while the
+// exchange's records travel (kAhead), and whatever only the rare paths need is read again from the kernarg segment (karg).
 // The one-step recurrences start from directly summed quantities in every iteration (no drift); they replace two dot
 // products by algebraically equal expressions, so iterates differ from cg_k1 / cg_k2 at round-off level (like any two
 // summation orders); converged answers and the stopping cadence are the reference's.  A segment starts from and ends in the
@@ -43,15 +47,6 @@ namespace piso {
 //     GPUs' records in rank order (bitwise the same totals on every GPU, so every GPU takes the same decisions);
 //   * N of the slab's last row comes from the N array (its S twin lives on the neighbour), sums of the previous K2 from a.gB.
 struct NoSlab {};
-#ifndef PISO_X1
-#define PISO_X1 0
-#endif
-#ifndef PISO_X2
-#define PISO_X2 0
-#endif
-#ifndef PISO_X3
-#define PISO_X3 0
-#endif
 // region shape of the persistent kernels for an nx x ny grid (V cells per lane, `cus` compute units): one region of 16 rows per
 // wave has the smallest halo overhead and is taken when it keeps at least 3/4 of the waves busy (or when forced); else two
 // regions of 2 / 4 rows per wave (two regions of 8 rows do not fit the registers: such shapes - ny a multiple of 8 but not of 16 on
@@ -1143,7 +1138,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     if (jj == 0 || jj == R - 1) {
       bst<T, V, kPub>(Rd, vT[q], sT, val);
       if constexpr (kPack) bst<T, V, kPub>(Rd, vEnd[q], row_base(q, 1, rowT) + (unsigned)(jj * 16), val);    // (its end cells into the packed block as well)
-      if constexpr (SLAB && !PISO_X3) {
+      if constexpr (SLAB) {
         // my first row is the row ABOVE the lower neighbour's slab (its side 1), my last row the row BELOW the upper one's (side 0)
         if (jj == 0) {
           unsigned zoff;
@@ -1196,7 +1191,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       eZ[q] = bld1<T, kHalo>(Rz, vo, 0);
       bool vbq, vaq;
       const int jb = row_wrap(j0[q] - 1, vbq), ja = row_wrap(j0[q] + R, vaq);
-      if constexpr (SLAB && !PISO_X2) {                                  // (wave-uniform branches: no per-lane offset registers to keep)
+      if constexpr (SLAB) {                                  // (wave-uniform branches: no per-lane offset registers to keep)
         if (!(ef[q] & 4u)) hbZ[q] = bld<T, V, kHalo>(Rz, vT[q], (unsigned)(j0[q] - 1) * rowT);
         else if (ef[q] & 1u) {
           unsigned zoff;
@@ -1334,7 +1329,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     if constexpr (kHier) healthy = grid_exchange8_hier<T>(c, sD, epoch, smem, hx, hier_s + 2, z_ahead, (kPersistDiag && c.timing) ? tsub : nullptr);
     else if constexpr (kLocalAll) healthy = grid_exchange8_local<T>(c, sD, epoch, smem, slot, nslots, hier_s + 2, (kPersistDiag && c.timing) ? tsub : nullptr);
     else healthy = grid_exchange8<T, LOCAL>(c, sD, epoch, smem, slot, nslots, prefetch_u, (kPersistDiag && c.timing) ? tsub : nullptr);
-    if constexpr (SLAB && !PISO_X1) { if (healthy) healthy = xgpu_exchange8<T>(sl_off, sD, epoch, smem + 2 * kX1Sm); }
+    if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl_off, sD, epoch, smem + 2 * kX1Sm); }
     tick(1);
     if (!healthy) break;
     // ---- the stopping test of iteration k, one exchange late but before anything moves (x = x_k): (:312-335)
