@@ -1,5 +1,5 @@
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
 rank, world, port = (int(v) for v in sys.argv[1:4])
 name, nx, ny = sys.argv[4], int(sys.argv[5]), int(sys.argv[6])

@@ -1,7 +1,7 @@
 """The cavity's pressure solves at the reference script's settings (accuracy 1e-8, 1000 iterations, reset 10, shifted): where do the
 product's single-workgroup CG and the oracle stop for a range of accuracies, and how far apart are their iterates?"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
 import numpy as np, torch
 from oracle import piso_ref as R, native
