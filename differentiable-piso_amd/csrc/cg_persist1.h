@@ -818,7 +818,14 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       asm volatile("" : "+s"(ef[q]));
     }
   }
-  if constexpr (SLAB) {                                     // the mirror of the argument list is the argument list
+  {                                                         // the mirror of the argument list IS the argument list (every instance: the exit block relies on it)
+    typedef CgArgs<T> A;
+    if (karg<T*>((unsigned)offsetof(KArgs, a) + (unsigned)offsetof(A, r)) != a.r || karg<int*>((unsigned)offsetof(KArgs, c) + (unsigned)offsetof(PersistCtl, err)) != c.err) {
+      if (threadIdx.x == 0) *c.err = 1;
+      return;
+    }
+  }
+  if constexpr (SLAB) {
     if (karg<char*>(sl_off + (unsigned)offsetof(SlabCtl, rows_own)) != sl.rows_own || karg<size_t>(pv_off + (unsigned)offsetof(PeerView, row_cap)) != sl.pv.row_cap) {
       if (threadIdx.x == 0) *c.err = 1;
       return;
@@ -1361,7 +1368,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         const int t = kZigZag ? NT - 1 - tt : tt;
         const int q = t / R, jj = t - q * R;
         if constexpr (kHaloAt > 0) { if (tt == kHaloAt) issue_halos(Rz); }
-        if (tt + 1 < NT && tt + 1 >= kAhead) ring_issue(kZigZag ? t - 1 : t + 1);
+        if (tt + 1 < NT && tt + 1 > kAhead) ring_issue(kZigZag ? t - 1 : t + 1);      // (row kAhead's values were requested in front of the loop)
         T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V + jj * 64 * V;
         Vec<T, V> xv = ldv<T, V>(xl);                        // x += alpha p (:303); the LDS latency hides under the stencil
         const Vec<T, V> z = (tt < kAhead) ? zs[tt < kAhead ? tt : 0] : zrow(t);
