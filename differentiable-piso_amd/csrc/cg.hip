@@ -197,10 +197,17 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     // Small regions: ONE wave with work per SIMD instead of two (waves 4-7 of a workgroup own nothing), twice the workgroups, wherever
     // the doubled grid still fits the chip: a wave then never waits at the exchange's first barrier for the wave it shares a SIMD
     // with (0.6 us of a ~4 us iteration).  Measured: 256^2 3.80 -> 3.47 us per iteration, 512^2 4.45 -> 4.08, 1024 x 256 4.48 -> 4.08,
-    // 512 x 256 4.07 -> 3.96 (64 workgroups chip-wide instead of 32 on one XCD), 1024 x 512 unchanged.  Option cg_persist_half 0: never.
-    if ((persist_R == 2 || persist_R == 4) && persist_NQ == 2 && 2 * persist_grid <= cus && opt(OPT_CG_PERSIST_HALF) != 0) {
-      pc.waves = kPersistWaves / 2;
-      persist_grid = (shape.nreg + pc.waves * persist_NQ - 1) / (pc.waves * persist_NQ);
+    // 1024 x 512 unchanged.  Option cg_persist_half 0: never, 1: wherever it fits.  Automatic (-1) leaves out the one case where the
+    // doubling would push a grid that fits ONE XCD (17-32 workgroups) out of it: since the XCD-local exchange polls its own XCD's
+    // records only, 32 full workgroups there beat 64 half ones chip-wide (512 x 256, round 4: 3.98 against 4.19 us per iteration).
+    {
+      const int half = opt(OPT_CG_PERSIST_HALF);
+      const bool fits = (persist_R == 2 || persist_R == 4) && persist_NQ == 2 && 2 * persist_grid <= cus;
+      const bool leaves_xcd = local_ok && persist_grid <= kXcdCus && 2 * persist_grid > kXcdCus;
+      if (fits && half != 0 && (half == 1 || !leaves_xcd)) {
+        pc.waves = kPersistWaves / 2;
+        persist_grid = (shape.nreg + pc.waves * persist_NQ - 1) / (pc.waves * persist_NQ);
+      }
     }
     xcd_local = local_ok && (persist_R == 2 || persist_R == 4) && persist_grid <= kXcdCus;
     if (persist_R && n < 16384 && force != 1 && !a.nx_true) persist_R = 0;    // tiny grids: two-kernel path (a padded grid is here BECAUSE it is small)

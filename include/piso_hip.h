@@ -48,7 +48,8 @@ int piso_device_count(void);
 /* Tuning / test knobs (no counterpart in the reference).  Each knob `name` takes its default ONCE, at library load, from the
  * environment variable PISO_<NAME IN UPPER CASE>; -1 = not set (automatic).  Process-wide, not thread-safe against a
  * concurrent solve.  Names: cg_persist (0 forbid / 1 force the persistent CG kernel), cg_persist_r (2|4|16 rows per region),
- * cg_persist_half (0: small regions never run with one working wave per SIMD and twice the workgroups),
+ * cg_persist_half (0: small regions never run with one working wave per SIMD and twice the workgroups; 1: wherever that fits the
+ * chip, also where it pushes a grid out of one XCD),
  * slab_force (1: a communicator of ONE rank still runs the slab code paths - a ring with itself; tests), conv_lds (0: the closure's
  * forward / input-gradient convolutions read their operands straight from L2 instead of staging them through LDS),
  * cg_segment (iterations per persistent launch),

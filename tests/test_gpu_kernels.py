@@ -158,7 +158,8 @@ def _persist_iterations():
 @pytest.mark.parametrize("name", CASES)
 @pytest.mark.parametrize("shape,reset,segment,rows", [((16, 128), 1000, 7, 2), ((64, 256), 200, 16, 4), ((36, 384), 1000, 1000, 2),
                                                       ((32, 128), 1000, 30, 4), ((16, 256), 25, 1000, 2),
-                                                      ((32, 128), 1000, 9, 16), ((64, 256), 300, 1000, 16)])
+                                                      ((32, 128), 1000, 9, 16), ((64, 256), 300, 1000, 16),
+                                                      ((256, 512), 1000, 1000, 2)])      # 32 full workgroups on ONE XCD (config 3's grid)
 def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, piso_option):
     """The persistent segment kernel (cg_persist1.h: r / p in registers, x in LDS, ONE grid-wide exchange per iteration instead of launches)
     is the path the 2048^2 benchmark runs; force it on small grids and hold it to the same bar as the two-kernel path:
