@@ -71,8 +71,12 @@ struct BiArgs {
   // vectors
   const T* rhs;
   T *x, *r, *rh, *p, *v, *t, *y, *ph, *sh;
-  T* parts;                       // [2 comps][4 quantities][kBiParts]
-  CompScalars<T>* sc;             // [2]
+  T* parts;                       // [2 comps][4 quantities][kBiParts]: where THIS launch writes its partial sums
+  const T* parts_in;              // the partial sums the previous producer wrote (the other of the two buffers: a launch never
+                                  // reads the buffer it writes, so its blocks may reduce `parts_in` while others already store)
+  CompScalars<T>* sc;             // [2]: the scalars this launch works with
+  const CompScalars<T>* sc_prev;  // fold != 0: the record BEFORE the folded stages (`sc` is then written by block 0, read by nobody)
+  int fold;                       // scalar stages the blocks of this launch apply themselves before they start (see folded_scalars)
   int* flags;                     // [0]: unsupported pattern, [1]: NaN seen
   float tol;
   int nparts;                     // blocks per component that write partial records (<= kBiParts; the rest stays zero)
@@ -297,12 +301,16 @@ __global__ __launch_bounds__(kBlock) void bi_factor(BiArgs<T> a) {
 //   forward  (L y = in):            y(k) = in(k)         - LW(k) y(k-1) - LS(k) y(k-W)
 //   backward (U z = y):             z(k) = y(k) dinv(k)  - UE(k) z(k+1) - UN(k) z(k+W)
 // ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ CompScalars<T> folded_scalars(const BiArgs<T>& a, int c, T* smem);   // (with the scalar stages, below)
+
 template <typename T, int E, bool FWD>
 __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restrict__ in, T* __restrict__ out) {
   __shared__ Affine<T> smem[4];
+  __shared__ T smem_fold[16];
   const int c = blockIdx.y;
   const Geo& g = a.g;
-  if (a.sc[c].done) return;
+  if (folded_scalars(a, c, smem_fold).done) return;         // (folded, forward sweep of s: the ||s|| test)
   const int band = a.bb[c] + blockIdx.x;
   if (band >= a.be[c]) return;
   const int W = g.W[c], H = g.H[c], r0 = g.r0[c];
@@ -403,6 +411,82 @@ __device__ __forceinline__ T stencil_row(const BiArgs<T>& a, int c, int row, con
   return acc;
 }
 
+// ---- the scalar recurrences between the vector kernels (multi_bicgstab_ilu_linear_solve_op.cu.cc:263-408): one STAGE per reduction
+enum { ST_INIT = 0, ST_RHO_BETA = 1, ST_ALPHA = 2, ST_CHECK_S = 3, ST_OMEGA = 4, ST_CHECK_R = 5 };
+
+template <typename T>
+__device__ __forceinline__ T sqrt_t(T v);
+template <>
+__device__ __forceinline__ float sqrt_t<float>(float v) { return sqrtf(v); }
+template <>
+__device__ __forceinline__ double sqrt_t<double>(double v) { return sqrt(v); }
+
+// q: the (up to four) sums of the previous vector kernel, in its order
+template <typename T>
+__device__ __forceinline__ void apply_stage(CompScalars<T>& s, int stage, const T (&q)[4], T tol) {
+  switch (stage) {
+    case ST_INIT:                       // ||r0|| "lucky guess" test (:288-292); rho for the first iteration is rh.r = ||r||^2
+      s.nrm = sqrt_t<T>(q[0]);
+      if (s.nrm < tol) s.done = 1;
+      s.rho_prev = s.rho;               // rho / alpha / omega are NOT reset on a restart (as coded)
+      s.rho = q[0];
+      s.beta = (s.rho / s.rho_prev) * (s.alpha / s.omega);
+      break;
+    case ST_RHO_BETA:                   // start of an iteration after the first: rho = rh.r (:309-312)
+      s.rho_prev = s.rho;
+      s.rho = q[1];
+      s.beta = (s.rho / s.rho_prev) * (s.alpha / s.omega);
+      break;
+    case ST_ALPHA:                      // alpha = rho / rh.v (:336-338)
+      s.alpha = s.rho / q[0];
+      s.it_count += 1;                  // one ST_ALPHA per started iteration (it_count++, :306)
+      break;
+    case ST_CHECK_S:                    // ||s|| test (:347-351)
+      s.nrm = sqrt_t<T>(q[0]);
+      if (s.nrm < tol) s.done = 1;
+      break;
+    case ST_OMEGA:                      // omega = t.r / t.t (:372-374)
+      s.omega = q[0] / q[1];
+      break;
+    case ST_CHECK_R:                    // ||r|| test (:386-390)
+      s.nrm = sqrt_t<T>(q[0]);
+      if (s.nrm < tol) s.done = 1;
+      break;
+  }
+}
+
+// the four sums of component c from the partial records of the previous producer, in ONE fixed order (every caller - the scalar
+// kernel, every block of a kernel with folded stages - gets bitwise the same sums)
+template <typename T>
+__device__ __forceinline__ void sum_partials(const BiArgs<T>& a, int c, T (&q)[4], T* smem) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q[k] = 0;
+  for (int b = threadIdx.x; b < a.nparts; b += kBlock) {       // (four independent loads in flight per pass)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] += a.parts_in[(c * 4 + k) * kBiParts + b];
+  }
+  block_sum<T, 4>(q, smem);
+}
+
+// The scalars a vector kernel works with.  fold == 0: the record a scalar kernel left in a.sc.  Otherwise (one GPU, small systems -
+// a scalar launch of 4 us + its gap is a fifth of the kernels of an iteration there): EVERY block of the consuming kernel applies the
+// stages itself - low nibble (stage + 1) first, then the high nibble if set - to the record a.sc_prev with the sums of a.parts_in, all
+// in the scalar kernel's order, so every block holds bitwise the same scalars; block 0 of the component stores them to a.sc (the
+// OTHER of two records: no block of this launch reads what it writes).  Called by all threads of the block before anything diverges.
+template <typename T>
+__device__ __forceinline__ CompScalars<T> folded_scalars(const BiArgs<T>& a, int c, T* smem) {
+  if (a.fold == 0) return a.sc[c];
+  CompScalars<T> s = a.sc_prev[c];
+  if (!s.done) {
+    T q[4];
+    sum_partials(a, c, q, smem);
+    apply_stage(s, (a.fold & 15) - 1, q, (T)a.tol);
+    if ((a.fold >> 4) != 0 && !s.done) apply_stage(s, (a.fold >> 4) - 1, q, (T)a.tol);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.sc[c] = s;
+  return s;
+}
+
 // r = rhs - B x ; rh = r ; p = v = 0 ; partial ||r||^2   (:266-300)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bi_residual_init(BiArgs<T> a) {
@@ -423,8 +507,9 @@ __global__ __launch_bounds__(kBlock) void bi_residual_init(BiArgs<T> a) {
 // p = r + beta (p - omega v)   (:316-318)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bi_update_p(BiArgs<T> a) {
+  __shared__ T smem[16];
   const int c = blockIdx.y;
-  const CompScalars<T> s = a.sc[c];
+  const CompScalars<T> s = folded_scalars(a, c, smem);      // (folded: ||r|| test of the iteration before, then rho / beta)
   if (s.done) return;
   const int n = a.g.n[c], r0 = a.g.r0[c];
   for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
@@ -464,7 +549,7 @@ template <typename T, int WHICH>
 __global__ __launch_bounds__(kBlock) void bi_update_xr(BiArgs<T> a) {
   __shared__ T smem[16];
   const int c = blockIdx.y;
-  const CompScalars<T> s = a.sc[c];
+  const CompScalars<T> s = folded_scalars(a, c, smem);      // (folded: alpha / omega from the product's sums)
   if (s.done) return;
   const int n = a.g.n[c], r0 = a.g.r0[c];
   const T coef = WHICH == 0 ? s.alpha : s.omega;
@@ -493,15 +578,6 @@ __global__ __launch_bounds__(kBlock) void bi_zero_x(BiArgs<T> a, int comp_mask) 
 // ------------------------------------------------------------------------------------------------------------------
 // scalar kernels: one block per component reduces the partials of the previous vector kernel and advances the recurrences
 // ------------------------------------------------------------------------------------------------------------------
-enum { ST_INIT = 0, ST_RHO_BETA = 1, ST_ALPHA = 2, ST_CHECK_S = 3, ST_OMEGA = 4, ST_CHECK_R = 5 };
-
-template <typename T>
-__device__ __forceinline__ T sqrt_t(T v);
-template <>
-__device__ __forceinline__ float sqrt_t<float>(float v) { return sqrtf(v); }
-template <>
-__device__ __forceinline__ double sqrt_t<double>(double v) { return sqrt(v); }
-
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bi_scalar(BiArgs<T> a, int stage, BiPeer bp) {
   __shared__ T smem[16];
@@ -516,11 +592,7 @@ __global__ __launch_bounds__(kBlock) void bi_scalar(BiArgs<T> a, int stage, BiPe
 #pragma unroll
     for (int k = 0; k < 4; ++k) q[k] = (T)bp.gsum[c * 4 + k];
   } else {
-  for (int b = threadIdx.x; b < a.nparts; b += kBlock) {       // (four independent loads in flight per pass)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) q[k] += a.parts[(c * 4 + k) * kBiParts + b];
-  }
-  block_sum<T, 4>(q, smem);
+    sum_partials(a, c, q, smem);
   }
   if (bp.on == 2) {
     if (threadIdx.x < 4) bp.gsum[c * 4 + threadIdx.x] = (double)(threadIdx.x == 0 ? q[0] : (threadIdx.x == 1 ? q[1] : (threadIdx.x == 2 ? q[2] : q[3])));
@@ -537,36 +609,7 @@ __global__ __launch_bounds__(kBlock) void bi_scalar(BiArgs<T> a, int stage, BiPe
     if (!good && lane == 0) *bp.err = 1;
   }
   if (threadIdx.x != 0) return;
-  const T tol = (T)a.tol;
-  switch (stage) {
-    case ST_INIT:                       // ||r0|| "lucky guess" test (:288-292); rho for the first iteration is rh.r = ||r||^2
-      s.nrm = sqrt_t<T>(q[0]);
-      if (s.nrm < tol) s.done = 1;
-      s.rho_prev = s.rho;               // rho / alpha / omega are NOT reset on a restart (as coded)
-      s.rho = q[0];
-      s.beta = (s.rho / s.rho_prev) * (s.alpha / s.omega);
-      break;
-    case ST_RHO_BETA:                   // start of an iteration after the first: rho = rh.r (:309-312)
-      s.rho_prev = s.rho;
-      s.rho = q[1];
-      s.beta = (s.rho / s.rho_prev) * (s.alpha / s.omega);
-      break;
-    case ST_ALPHA:                      // alpha = rho / rh.v (:336-338)
-      s.alpha = s.rho / q[0];
-      s.it_count += 1;                  // one ST_ALPHA per started iteration (it_count++, :306)
-      break;
-    case ST_CHECK_S:                    // ||s|| test (:347-351)
-      s.nrm = sqrt_t<T>(q[0]);
-      if (s.nrm < tol) s.done = 1;
-      break;
-    case ST_OMEGA:                      // omega = t.r / t.t (:372-374)
-      s.omega = q[0] / q[1];
-      break;
-    case ST_CHECK_R:                    // ||r|| test (:386-390)
-      s.nrm = sqrt_t<T>(q[0]);
-      if (s.nrm < tol) s.done = 1;
-      break;
-  }
+  apply_stage(s, stage, q, (T)a.tol);
   a.sc[c] = s;
 }
 
@@ -578,7 +621,7 @@ __global__ void bi_init_scalars(BiArgs<T> a) {
     s.done = 0; s.it_count = 0; s.failed = 0; s.pad = 0;
     a.sc[threadIdx.x] = s;
   }
-  for (int i = threadIdx.x; i < 2 * 4 * kBiParts; i += blockDim.x) a.parts[i] = 0;
+  for (int i = threadIdx.x; i < 2 * 2 * 4 * kBiParts; i += blockDim.x) a.parts[i] = 0;      // (both buffers)
   if (threadIdx.x == 0) { a.flags[0] = 0; a.flags[1] = 0; }
 }
 
@@ -634,7 +677,7 @@ static size_t bi_workspace_bytes(int nx, int ny) {
   b += 18 * align_up(ntot * sizeof(T), 256);
   b += align_up((size_t)(g.F[0] + g.F[1]) * kExcSlots * sizeof(int), 256);
   b += align_up((size_t)(g.F[0] + g.F[1]) * kExcSlots * sizeof(T), 256);
-  b += align_up(2 * 4 * kBiParts * sizeof(T), 256) + align_up(2 * sizeof(CompScalars<T>), 256) + 256;
+  b += align_up(2 * 2 * 4 * kBiParts * sizeof(T), 256) + align_up(2 * 2 * sizeof(CompScalars<T>), 256) + 256;
   return b + 8192;
 }
 
@@ -656,9 +699,9 @@ struct BiHost {
 template <typename T, int E>
 static void launch_factor(const BiArgs<T>& a, dim3 gb, hipStream_t s) { bi_factor<T, E><<<gb, kBlock, 0, s>>>(a); }
 template <typename T, int E>
-static void launch_sweeps(const BiArgs<T>& a, dim3 gb, const T* in, T* out, hipStream_t s) {
-  bi_sweep<T, E, true><<<gb, kBlock, 0, s>>>(a, in, a.y);
-  bi_sweep<T, E, false><<<gb, kBlock, 0, s>>>(a, a.y, out);
+static void launch_sweeps(const BiArgs<T>& aL, const BiArgs<T>& aU, dim3 gb, const T* in, T* out, hipStream_t s) {
+  bi_sweep<T, E, true><<<gb, kBlock, 0, s>>>(aL, in, aL.y);
+  bi_sweep<T, E, false><<<gb, kBlock, 0, s>>>(aU, aU.y, out);
 }
 
 // pc = NULL: one GPU.  Else (peer transport): this rank works on the face rows of its y-slab of cell rows; val / rowptr / col /
@@ -687,8 +730,9 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   a.y = ar.take<T>(ntot); a.ph = ar.take<T>(ntot); a.sh = ar.take<T>(ntot);
   a.ecol = ar.take<int>((size_t)(g.F[0] + g.F[1]) * kExcSlots);
   a.eval = ar.take<T>((size_t)(g.F[0] + g.F[1]) * kExcSlots);
-  a.parts = ar.take<T>(2 * 4 * kBiParts);
-  a.sc = ar.take<CompScalars<T>>(2);
+  T* const pbuf0 = ar.take<T>(2 * 2 * 4 * kBiParts);                      // two buffers of partial sums (see BiArgs::parts_in)
+  CompScalars<T>* const scbuf0 = ar.take<CompScalars<T>>(2 * 2);         // two scalar records (see BiArgs::sc_prev)
+  a.parts = pbuf0; a.parts_in = pbuf0; a.sc = scbuf0; a.sc_prev = scbuf0; a.fold = 0;
   a.flags = ar.take<int>(2);
   a.rhs = rhs; a.x = x_out; a.tol = tol;
   if (!ar.ok()) { set_error_msg("piso_multi_bicgstab_ilu: workspace too small"); return PISO_ERR_INVALID_ARG; }
@@ -740,14 +784,29 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   };
   auto halo = [&](T* vec) -> int { return slab ? exchange_on(vec, stream) : PISO_OK; };
   // one stage of the scalar recurrences (peer transport / one GPU: one launch; RCCL: the ranks' sums, an all-reduce, the rest)
+  // Arguments of the NEXT launch.  Two buffers of partial sums: a launch reads the one the last producer wrote and writes the other;
+  // two scalar records: a launch with folded stages (folded_scalars) reads one and leaves the other as the current one.
+  int cur = 0, pw = 0;
+  auto next = [&](int fold, bool produces) -> BiArgs<T> {
+    BiArgs<T> b = a;
+    b.parts_in = pbuf0 + (size_t)pw * (2 * 4 * kBiParts);
+    b.parts = pbuf0 + (size_t)(pw ^ 1) * (2 * 4 * kBiParts);
+    b.fold = fold;
+    b.sc_prev = scbuf0 + 2 * cur;
+    if (fold) cur ^= 1;
+    b.sc = scbuf0 + 2 * cur;
+    if (produces) pw ^= 1;
+    return b;
+  };
   auto scalar = [&](int stage) -> int {
+    const BiArgs<T> sa = next(0, false);
     if (slab && rccl) {
       BiPeer b = bp;
-      b.on = 2; bi_scalar<T><<<2, kBlock, 0, stream>>>(a, stage, b);
+      b.on = 2; bi_scalar<T><<<2, kBlock, 0, stream>>>(sa, stage, b);
       { const int rc = comm_rccl_allreduce_f64(pc, bp.gsum, 8, stream); if (rc != PISO_OK) return rc; }
-      b.on = 3; bi_scalar<T><<<2, kBlock, 0, stream>>>(a, stage, b);
+      b.on = 3; bi_scalar<T><<<2, kBlock, 0, stream>>>(sa, stage, b);
     } else {
-      bi_scalar<T><<<2, kBlock, 0, stream>>>(a, stage, next_seq());
+      bi_scalar<T><<<2, kBlock, 0, stream>>>(sa, stage, next_seq());
     }
     return PISO_OK;
   };
@@ -777,6 +836,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   const dim3 grid_vs(gv, 2), grid_e(ge > 0 ? ge : 1, 2);
   // y = B in with the edge rows of `in` fetched from the neighbours meanwhile (one GPU: one launch)
   auto spmv = [&](int which, T* in, T* out) -> int {
+    const BiArgs<T> a = next(0, true);                        // (slab mode: both launches write the same buffer of partial sums)
     if (!slab) {
       if (which == 0) bi_spmv<T, 0><<<grid_v, kBlock, 0, stream>>>(a, in, out, 0, 0);
       else bi_spmv<T, 1><<<grid_v, kBlock, 0, stream>>>(a, in, out, 0, 0);
@@ -815,21 +875,27 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   else launch_factor<T, 32>(a, grid_b, stream);
   PISO_LAUNCH_CHECK();
 
-  auto precond = [&](const T* in, T* out) {
-    if (need <= 1) launch_sweeps<T, 1>(a, grid_b, in, out, stream);
-    else if (need <= 2) launch_sweeps<T, 2>(a, grid_b, in, out, stream);
-    else if (need <= 3) launch_sweeps<T, 3>(a, grid_b, in, out, stream);
-    else if (need <= 4) launch_sweeps<T, 4>(a, grid_b, in, out, stream);
-    else if (need <= 5) launch_sweeps<T, 5>(a, grid_b, in, out, stream);
-    else if (need <= 8) launch_sweeps<T, 8>(a, grid_b, in, out, stream);
-    else if (need <= 9) launch_sweeps<T, 9>(a, grid_b, in, out, stream);
-    else if (need <= 16) launch_sweeps<T, 16>(a, grid_b, in, out, stream);
-    else launch_sweeps<T, 32>(a, grid_b, in, out, stream);
+  auto precond = [&](const T* in, T* out, int fold) {           // (fold: scalar stages the blocks of the forward sweep apply first)
+    const BiArgs<T> aL = next(fold, false), aU = next(0, false);
+    if (need <= 1) launch_sweeps<T, 1>(aL, aU, grid_b, in, out, stream);
+    else if (need <= 2) launch_sweeps<T, 2>(aL, aU, grid_b, in, out, stream);
+    else if (need <= 3) launch_sweeps<T, 3>(aL, aU, grid_b, in, out, stream);
+    else if (need <= 4) launch_sweeps<T, 4>(aL, aU, grid_b, in, out, stream);
+    else if (need <= 5) launch_sweeps<T, 5>(aL, aU, grid_b, in, out, stream);
+    else if (need <= 8) launch_sweeps<T, 8>(aL, aU, grid_b, in, out, stream);
+    else if (need <= 9) launch_sweeps<T, 9>(aL, aU, grid_b, in, out, stream);
+    else if (need <= 16) launch_sweeps<T, 16>(aL, aU, grid_b, in, out, stream);
+    else launch_sweeps<T, 32>(aL, aU, grid_b, in, out, stream);
   };
+  // Scalar stages folded into their consumers (folded_scalars): one GPU, systems whose partial records a block re-reads in passing
+  // (<= 512 per component: grids up to 1024 x 512).  14 -> 9 launches per iteration; at 2048^2 the 1024 x 2 blocks of a vector kernel
+  // would each read 16 KB of records for nothing measurable.  Option bicg_fold: 0 never, 1 on one GPU at any size.
+  const bool fold_ok = !slab && opt(OPT_BICG_FOLD) != 0 && (gv <= 512 || opt(OPT_BICG_FOLD) == 1);
+  auto F = [&](int stage) -> int { return fold_ok ? stage + 1 : 0; };
 
   BiHost<T> host;
   auto fetch = [&]() -> int {
-    PISO_HIP_CHECK(hipMemcpyAsync(host.sc, a.sc, 2 * sizeof(CompScalars<T>), hipMemcpyDeviceToHost, stream));
+    PISO_HIP_CHECK(hipMemcpyAsync(host.sc, scbuf0 + 2 * cur, 2 * sizeof(CompScalars<T>), hipMemcpyDeviceToHost, stream));
     PISO_HIP_CHECK(hipMemcpyAsync(host.flags, a.flags, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
     PISO_HIP_CHECK(hipStreamSynchronize(stream));
     return PISO_OK;
@@ -840,7 +906,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   for (int restart = 0; restart < 2; ++restart) {
     // r = b - B x, rh = r, p = v = 0, ||r|| test, first rho / beta
     { const int rc = halo(a.x); if (rc != PISO_OK) return rc; }
-    bi_residual_init<T><<<grid_v, kBlock, 0, stream>>>(a);
+    bi_residual_init<T><<<grid_v, kBlock, 0, stream>>>(next(0, true));
     { const int rc = scalar(ST_INIT); if (rc != PISO_OK) return rc; }
     PISO_LAUNCH_CHECK();
     int it = 0, look = ntot < 32768 ? 1 : 2;                 // (tiny systems - the lid-driven cavity converges in one iteration: a second one is 13 launches for nothing)
@@ -851,18 +917,23 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
       const int chunk = (max_it - it) < look ? (max_it - it) : look;
       if (look < 2) look = 2; else if (it >= 4 && look < 16) look *= 2;
       for (int q = 0; q < chunk; ++q, ++it) {
-        if (it > 0) { const int rc = scalar(ST_RHO_BETA); if (rc != PISO_OK) return rc; }
-        bi_update_p<T><<<grid_v, kBlock, 0, stream>>>(a);
-        precond(a.p, a.ph);
+        // (folded: the ||r|| test that ended the iteration before - inside a chunk nobody else has applied it yet - then rho / beta)
+        int fold_p = 0;
+        if (it > 0) {
+          if (fold_ok) fold_p = q > 0 ? (F(ST_CHECK_R) | (F(ST_RHO_BETA) << 4)) : F(ST_RHO_BETA);
+          else { const int rc = scalar(ST_RHO_BETA); if (rc != PISO_OK) return rc; }
+        }
+        bi_update_p<T><<<grid_v, kBlock, 0, stream>>>(next(fold_p, false));
+        precond(a.p, a.ph, 0);
         { const int rc = spmv(0, a.ph, a.v); if (rc != PISO_OK) return rc; }
-        { const int rc = scalar(ST_ALPHA); if (rc != PISO_OK) return rc; }
-        bi_update_xr<T, 0><<<grid_v, kBlock, 0, stream>>>(a);
-        { const int rc = scalar(ST_CHECK_S); if (rc != PISO_OK) return rc; }
-        precond(a.r, a.sh);
+        if (!fold_ok) { const int rc = scalar(ST_ALPHA); if (rc != PISO_OK) return rc; }
+        bi_update_xr<T, 0><<<grid_v, kBlock, 0, stream>>>(next(F(ST_ALPHA), true));
+        if (!fold_ok) { const int rc = scalar(ST_CHECK_S); if (rc != PISO_OK) return rc; }
+        precond(a.r, a.sh, F(ST_CHECK_S));
         { const int rc = spmv(1, a.sh, a.t); if (rc != PISO_OK) return rc; }
-        { const int rc = scalar(ST_OMEGA); if (rc != PISO_OK) return rc; }
-        bi_update_xr<T, 1><<<grid_v, kBlock, 0, stream>>>(a);
-        { const int rc = scalar(ST_CHECK_R); if (rc != PISO_OK) return rc; }
+        if (!fold_ok) { const int rc = scalar(ST_OMEGA); if (rc != PISO_OK) return rc; }
+        bi_update_xr<T, 1><<<grid_v, kBlock, 0, stream>>>(next(F(ST_OMEGA), true));
+        if (!fold_ok || q == chunk - 1) { const int rc = scalar(ST_CHECK_R); if (rc != PISO_OK) return rc; }   // (the host looks at it)
       }
       PISO_LAUNCH_CHECK();
       { const int rc = fetch(); if (rc != PISO_OK) return rc; }
@@ -883,9 +954,9 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
       if (nrm > (T)tol * 100 || nrm != nrm) fail_now |= 1 << c;
     }
     if (!fail_now) break;
-    bi_zero_x<T><<<grid_v, kBlock, 0, stream>>>(a, fail_now);
+    bi_zero_x<T><<<grid_v, kBlock, 0, stream>>>(next(0, false), fail_now);
     if (restart == 0) {
-      bi_set_done<T><<<1, 64, 0, stream>>>(a, !(fail_now & 1), !((fail_now >> 1) & 1));
+      bi_set_done<T><<<1, 64, 0, stream>>>(next(0, false), !(fail_now & 1), !((fail_now >> 1) & 1));
     } else {
       failed_mask = fail_now;
     }

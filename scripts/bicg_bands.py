@@ -19,7 +19,7 @@ val, rp, col, A, nnz, Aflat = dp.advection_matrix_cuda(velocity, sim.dirichlet_m
 x0 = dp.flatten_staggered_data(velocity, True)
 rhs = x0 * beta
 warn = torch.zeros(1, dtype=torch.uint8, device=dev)
-for band in (0, 32, 16, 8, 4):
+for band in (0, 32, 16, 8, 4, 2):
     for tol, iters, label in ((0.0, 10, "fixed work"), (1e-6, 100, "solve to 1e-6"), (1e-9, 100, "solve to 1e-9")):
         best = None
         for rep in range(3):

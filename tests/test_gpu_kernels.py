@@ -306,6 +306,35 @@ def test_bicgstab_matches_oracle(name, transpose, dtype, band):
     assert rel < (1e-7 if dtype == np.float64 else 2e-5), rel
 
 
+@pytest.mark.parametrize("name", ["periodic", "cavity", "spatial_ml"])
+@pytest.mark.parametrize("transpose", [False, True])
+@pytest.mark.parametrize("tol,max_it", [(1e-5, 200), (1e-30, 7), (1e-30, 1)])
+def test_bicgstab_folded_scalar_stages_are_bitwise_neutral(name, transpose, tol, max_it, piso_option):
+    """Small systems on one GPU fold the scalar stages of an iteration (rho / beta, alpha, the two norm tests, omega) into the
+    kernels that consume them (bicgstab.hip: folded_scalars; 14 -> 9 launches per iteration).  Same sums in the same order: the
+    solution, the iteration counts and the failure path (tolerance out of reach: x = 0 after the one restart) must be bitwise those
+    of the path with a scalar launch per stage."""
+    from diffpiso.solvers import multi_bicgstab_ilu_native
+    ny, nx = 40, 36
+    c = make_case(name, ny, nx, seed=3, variable_viscosity=(name == "spatial_ml"))
+    s = oracle_setup(c)
+    beta = float(np.prod(c["dx_yx"])) / c["dt"]
+    val, rp, col, _, _ = R.advection_matrix(s, c["vel"], beta)
+    rhs = np.random.default_rng(5).standard_normal(s.n_u + s.n_v).astype(f32)
+    x0 = R.flatten_staggered(c["vel"], True)
+    out = []
+    for fold in (0, 1, -1):
+        piso_option("bicg_fold", fold)
+        warn = torch.zeros(1, dtype=torch.uint8, device="cuda")
+        x, its = multi_bicgstab_ilu_native(dev(-val), dev(rp), dev(col), dev(rhs), dev(x0), nx, ny, tol, max_it, transpose, -1, warn)
+        out.append((x.cpu().numpy(), [int(i) for i in its], int(warn.item())))
+    for x, its, w in out[1:]:
+        assert its == out[0][1] and w == out[0][2]
+        np.testing.assert_array_equal(x, out[0][0])
+    if tol > 1e-10:
+        assert max(out[0][1]) < max_it and np.abs(out[0][0]).max() > 0
+
+
 def test_bicgstab_failure_and_nan_semantics():
     from diffpiso.solvers import multi_bicgstab_ilu_native
     c = make_case("periodic", 12, 12, seed=2)
