@@ -26,7 +26,7 @@ One JSON line on stdout (rank 0) with, besides the contract's keys:
                 the bytes the PMC counters saw per iteration (profiles/traffic.json, same kernel sources) / the measured iteration
                 time / the HBM peak; `design_byte_model` is the 18.9 B per cell model beside it; `algorithmic_equivalent` is
                 SURVEY.md 8(d)'s 128 B per cell and iteration of the textbook iteration; `binds` names what binds the kernel
-                (VALU issue + one grid exchange; `bound` stays the contract's "hbm" = the peak frac is priced against) and `floors_us_per_iteration` / `frac_of_binding_floor` price it
+                (VALU issue + one grid exchange; `bound` stays the contract's "hbm" = the peak frac is priced against) and `floors_us_per_iteration` / `frac_of_binding_floor` (fp64 arithmetic only) / `frac_of_compiled_loop_floor` (every vector instruction of the loop as compiled) price it
   bicgstab      fixed-work run of the ILU(0)-BiCGStab (both components, every launch does work), 296 B per row and iteration
   phases        forward / adjoint ms per step, CG iterations per step, CG share of the step
   slab_kernel_loopback   (N = 1) us per iteration of the SLAB instance of the persistent CG kernel in a ring of one rank (edge rows
@@ -817,6 +817,10 @@ def main():
                                                            "ratio above 1 is traffic this design avoids, not bandwidth"},
                         "floors_us_per_iteration": floors, "binding_floor": "fp64_valu_issue + grid_exchanges (serial)",
                         "frac_of_binding_floor": serial_floor / it_us,
+                        # the same with ALL vector instructions of the loop as compiled (conversions, DPP shifts, address arithmetic
+                        # beside the fp64 arithmetic): how close the kernel runs to what its own instruction stream allows
+                        "frac_of_compiled_loop_floor": ((floors["valu_issue_of_the_compiled_loop"] + floors["grid_exchanges"]) / it_us
+                                                        if "valu_issue_of_the_compiled_loop" in floors else None),
                         "two_kernel_path": {"k1_avg_launch_ms": k1_ms, "k1_achieved": k1_gbs, "k1_launches_sampled": int(cnt[0]),
                                             "k2_avg_launch_ms": k2_ms, "k2_achieved": k2_gbs}}
             cg_ms_total = ms_sum[2]
