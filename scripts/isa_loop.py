@@ -93,6 +93,8 @@ def main():
                 sum(v for k, v in c.items() if k.endswith("_f64") or k.endswith("_f64_e32") or k.endswith("_f64_e64")),
                 sum(v for k, v in c.items() if k.startswith("v_cvt")), c["v_mov_b32_dpp"], sum(v for k, v in c.items() if k.startswith("s_load")),
                 sum(v for k, v in c.items() if k.startswith("buffer_") or k.startswith("global_")), sum(v for k, v in c.items() if k.startswith("ds_"))))
+            if os.environ.get("ISA_HIST"):
+                print("   opcodes:", ", ".join("%s %d" % kv for kv in c.most_common(60)))
     print("asm:", asm)
 
 
