@@ -178,6 +178,9 @@ __device__ __forceinline__ F karg(unsigned off) {
 #ifndef PISO_PERSIST1_POLL_DELAY2
 #define PISO_PERSIST1_POLL_DELAY2 24            // s_sleep units in front of the first polling pass of the tree's second level
 #endif
+#ifndef PISO_PERSIST1_POLL_DELAY2_NOAHEAD
+#define PISO_PERSIST1_POLL_DELAY2_NOAHEAD 8     // ... where no rows are computed ahead in front of it (small regions on mid-size grids: 24 -> 8: 4.27 -> 4.15 us at 512^2 / 1024 x 256, 0: 4.22)
+#endif
 #ifndef PISO_PERSIST1_POLL_SLEEP
 #define PISO_PERSIST1_POLL_SLEEP 1              // s_sleep units (64 cycles) between two polling passes
 #endif
@@ -394,7 +397,7 @@ __device__ __forceinline__ unsigned hier_enter(const PersistCtl& c, int* lds2) {
   __syncthreads();
   return (unsigned)__builtin_amdgcn_readfirstlane(lds2[0]);
 }
-template <typename T, typename F = NoPrefetch>
+template <typename T, int DELAY2, typename F = NoPrefetch>
 __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[kX1Values], unsigned epoch, T* smem, unsigned hx, int* flag,
                                                     F while_records_travel = F(), unsigned long long* tsub = nullptr) {
   unsigned long long t0 = (kPersistDiag && tsub) ? wall_clock64() : 0;
@@ -473,7 +476,7 @@ __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[
     // every wave: the eight XCD records (lane l: word l % 16 of record 4 i + l / 16), added in XCD order
     u64 w[2];
     unsigned spins = 0;
-    if (PISO_PERSIST1_POLL_DELAY2 > 0) __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_DELAY2);
+    if (DELAY2 > 0) __builtin_amdgcn_s_sleep(DELAY2);
     while (true) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) w[i] = __hip_atomic_load(rec2 + lw + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1333,7 +1336,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         }
       }
     };
-    if constexpr (kHier) healthy = grid_exchange8_hier<T>(c, sD, epoch, smem, hx, hier_s + 2, z_ahead, (kPersistDiag && c.timing) ? tsub : nullptr);
+    if constexpr (kHier) healthy = grid_exchange8_hier<T, (kAhead > 0 ? PISO_PERSIST1_POLL_DELAY2 : PISO_PERSIST1_POLL_DELAY2_NOAHEAD)>(c, sD, epoch, smem, hx, hier_s + 2, z_ahead, (kPersistDiag && c.timing) ? tsub : nullptr);
     else if constexpr (kLocalAll) healthy = grid_exchange8_local<T>(c, sD, epoch, smem, slot, nslots, hier_s + 2, (kPersistDiag && c.timing) ? tsub : nullptr);
     else healthy = grid_exchange8<T, LOCAL>(c, sD, epoch, smem, slot, nslots, prefetch_u, (kPersistDiag && c.timing) ? tsub : nullptr);
     if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl_off, sD, epoch, smem + 2 * kX1Sm); }
@@ -1447,7 +1450,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   if (!first && healthy && !st.done) {
     T sX[kX1Values] = {0, 0, 0, 0, 0, 0, lU[0], lU[1]};
     ++epoch;
-    if constexpr (kHier) healthy = grid_exchange8_hier<T>(c, sX, epoch, smem, hx, hier_s + 2);     // (nothing to compute ahead)
+    if constexpr (kHier) healthy = grid_exchange8_hier<T, PISO_PERSIST1_POLL_DELAY2_NOAHEAD>(c, sX, epoch, smem, hx, hier_s + 2);     // (nothing to compute ahead)
     else if constexpr (kLocalAll) healthy = grid_exchange8_local<T>(c, sX, epoch, smem, slot, nslots, hier_s + 2);
     else healthy = grid_exchange8<T, LOCAL>(c, sX, epoch, smem, slot, nslots);
     if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl_off, sX, epoch, smem + 2 * kX1Sm); }
