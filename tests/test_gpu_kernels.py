@@ -306,16 +306,20 @@ def test_bicgstab_matches_oracle(name, transpose, dtype, band):
     assert rel < (1e-7 if dtype == np.float64 else 2e-5), rel
 
 
-@pytest.mark.parametrize("name", ["periodic", "cavity", "spatial_ml"])
-@pytest.mark.parametrize("transpose", [False, True])
-@pytest.mark.parametrize("tol,max_it", [(1e-5, 200), (1e-30, 7), (1e-30, 1)])
-def test_bicgstab_folded_scalar_stages_are_bitwise_neutral(name, transpose, tol, max_it, piso_option):
+_FOLD_CASES = [(name, (40, 36), transpose, tol, max_it) for name in ("periodic", "cavity", "spatial_ml") for transpose in (False, True)
+               for tol, max_it in ((1e-5, 200), (1e-30, 7), (1e-30, 1))]
+_FOLD_CASES += [("periodic", (512, 520), False, 1e-5, 200), ("periodic", (512, 520), False, 1e-30, 1)]   # 261 partial records per component:
+                                                                                                       # more than one pass of a block
+
+
+@pytest.mark.parametrize("name,shape,transpose,tol,max_it", _FOLD_CASES)
+def test_bicgstab_folded_scalar_stages_are_bitwise_neutral(name, shape, transpose, tol, max_it, piso_option):
     """Small systems on one GPU fold the scalar stages of an iteration (rho / beta, alpha, the two norm tests, omega) into the
     kernels that consume them (bicgstab.hip: folded_scalars; 14 -> 9 launches per iteration).  Same sums in the same order: the
     solution, the iteration counts and the failure path (tolerance out of reach: x = 0 after the one restart) must be bitwise those
     of the path with a scalar launch per stage."""
     from diffpiso.solvers import multi_bicgstab_ilu_native
-    ny, nx = 40, 36
+    ny, nx = shape
     c = make_case(name, ny, nx, seed=3, variable_viscosity=(name == "spatial_ml"))
     s = oracle_setup(c)
     beta = float(np.prod(c["dx_yx"])) / c["dt"]
