@@ -15,6 +15,9 @@
  *     diffpiso/linear_solver.py:39-44, diffpiso/piso_helpers.py:326-343) and dense numpy solves.
  *     cuSPARSE csrilu02/csrsv2/csrmv/csr2csc (CUDA 10.0, closed source) are restated from their published
  *     definition (ILU(0) in IKJ order on the CSR pattern, unit-lower / non-unit-upper substitution).
+ *   - oracle_laplace_* (at A0 = 1) and the recurrence of oracle_cg_* (no shift, no restart, fixed iteration counts) ARE pinned
+ *     against outputs of the reference's own Python: PhiFlow's sparse_pressure_matrix and conjugate_gradient, run here by
+ *     tests/golden/make_golden_pressure.py (tests/test_oracle_pressure_phiflow.py: matrix entry for entry, iterates to 1e-11).
  *
  * Every function cites the reference file:line it follows (paths relative to the reference root).
  * 2-D only (dimSize == 2), batch size 1 -- the only configuration any reference script uses.
