@@ -74,3 +74,17 @@ def test_hip_cg_iterates_are_phiflows(name, path, piso_option):
             assert _persist_iterations() == 0
     finally:
         N.lib.piso_cg_profile_enable(0, 8)
+
+
+@pytest.mark.parametrize("name", ["periodic", "closed", "open", "xper_ywall", "spatial_ml", "yper_xopen"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_hip_laplace_operator_is_the_references_divergence_of_the_scaled_gradient(name, dtype):
+    """The HIP Laplace kernel with random A0 against the composition of the reference's own Python helpers
+    (tests/golden/laplace_operator.npz; see the oracle's test of the same name for the open-side term)."""
+    from diffpiso.solvers import laplace_matrix_native
+    from test_oracle_pressure_phiflow import check_laplace_operator, load_op
+    g = load_op(name)
+    ny, nx = [int(v) for v in g["resolution"]]
+    L = laplace_matrix_native(nx, ny, dev(g["active_ext"].reshape(-1), torch.float32), dev(g["accessible_ext"].reshape(-1), torch.float32),
+                              dev(g["a0_flat_vfirst"], torch.float32), dtype)
+    check_laplace_operator(g, L.cpu().numpy().astype(np.float64))

@@ -72,3 +72,66 @@ def test_oracle_cg_iterates_are_phiflows(name, solver):
         assert it == k
         want = g["x_%d" % k]
         assert np.abs(x - want).max() <= 1e-11 * np.abs(want).max(), (name, k)
+
+
+# ---- the A0-weighted operator against the composition of the reference's own gradient / divergence helpers
+GOLD_OP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "laplace_operator.npz")
+OP_CASES = ["periodic", "closed", "open", "xper_ywall", "spatial_ml", "yper_xopen"]
+
+
+def load_op(name):
+    z = np.load(GOLD_OP)
+    return {k.split("/", 1)[1]: z[k] for k in z.files if k.startswith(name + "/")}
+
+
+def op_periodic_xy(g):
+    ext = str(g["pressure_extrapolation"])
+    # 'periodic' on both axes, or a per-axis list ((y_lo, y_hi), (x_lo, x_hi)) / [y, x]: periodic axes read 'periodic'
+    if ext.strip("'\"") == "periodic":
+        return True, True
+    parts = eval(ext)                                        # (a repr of strings / lists of strings written by the generator)
+    per = []
+    for e in parts:
+        lo, hi = (e, e) if isinstance(e, str) else e
+        per.append(lo == "periodic" and hi == "periodic")
+    return per[1], per[0]                                    # (x, y)
+
+
+def open_face_dirichlet_term(g):
+    """What the CUDA matrix has and the Python composition has not.  At an OPEN side the matrix treats the cell outside as p' = 0
+    ("Dirichlet BC for pressure are always zero", laplace_op.cu.cc:83: the diagonal loses a0 of that face, :122-131) while the
+    pressure's extrapolation there is 'boundary' (piso_tf.py:140-162 -> material.py:86-92), so finite_volume_gradient_tensor sees a
+    zero difference across the face: the two differ by exactly  - a0(face) p(cell)  on the cells along open sides - a property of
+    the reference (its corrected velocity is not discretely divergence-free there), reproduced piece by piece here."""
+    ny, nx = [int(v) for v in g["resolution"]]
+    a0, act, acc, p = g["a0_staggered"][0], g["active_ext"], g["accessible_ext"], g["p"]
+    out = np.zeros((ny, nx))
+    for j in range(ny):
+        for i in range(nx):
+            for dj, di, face in ((-1, 0, a0[j, i, 0]), (1, 0, a0[j + 1, i, 0]), (0, -1, a0[j, i, 1]), (0, 1, a0[j, i + 1, 1])):
+                if act[j + 1 + dj, i + 1 + di] == 0 and acc[j + 1 + dj, i + 1 + di] == 1:
+                    out[j, i] -= face * p[j, i]
+    return out.reshape(-1)
+
+
+def check_laplace_operator(g, L):
+    ny, nx = [int(v) for v in g["resolution"]]
+    per_x, per_y = op_periodic_xy(g)
+    got = expand(L, nx, ny, per_x, per_y) @ g["p"].reshape(-1)
+    quirk = open_face_dirichlet_term(g)
+    want = g["L_p"].reshape(-1) + quirk
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()        # (A0 travels as float32, as in the reference: piso_cuda_pressure_solver.py:70)
+    return float(np.abs(quirk).max())
+
+
+@pytest.mark.parametrize("name", OP_CASES)
+def test_oracle_laplace_operator_is_the_references_divergence_of_the_scaled_gradient(name):
+    """piso_tf.py:51-58: L(A0) p with A0 = dx_factor / (beta - A) must be finite_volume_divergence(finite_volume_gradient_tensor(p) /
+    (beta - A) / prod(dx)) - both helpers run from the reference (tests/golden/make_golden_laplace_operator.py) - up to the Dirichlet
+    term of open sides (open_face_dirichlet_term).  Pins the A0 weights, their v-first face indexing, the mask rule and every
+    boundary type of the native Laplace restatement."""
+    g = load_op(name)
+    ny, nx = [int(v) for v in g["resolution"]]
+    L = O.laplace_matrix(nx, ny, g["active_ext"], g["accessible_ext"], g["a0_flat_vfirst"], np.float64)
+    quirk = check_laplace_operator(g, L)
+    assert (quirk > 0) == (name in ("open", "spatial_ml", "yper_xopen"))
