@@ -4,8 +4,8 @@ The reference's CUDA Laplace / CG ops (CUDAsrc/laplace_op.cu.cc, pressure_solve_
 were derived from can be RUN here: PhiFlow's `sparse_pressure_matrix` (PhiFlow/phi/physics/pressuresolver/sparse.py:87-130) is the
 same mask rule - off-diagonal = active(neighbour) * active(self), diagonal = - sum accessible(neighbour) - without the A0 face weights,
 and `phi.math.optim.conjugate_gradient` (PhiFlow/phi/math/optim.py:46-79) is the same recurrence - alpha = p.r / p.Ap,
-beta = - r'.Ap / p.Ap - without shift, restarts and the every-fifth-iteration stopping cadence.  So, with A0 = 1, no shift, no restart
-and a FIXED number of iterations, the oracle's Laplace matrix must equal PhiFlow's entry for entry (which also pins the neighbour /
+beta = - r'.Ap / p.Ap - without the shift and the every-fifth-iteration stopping cadence (a restart is a fresh call with the previous x
+as its guess).  So, with A0 = 1, no shift and a FIXED number of iterations, the oracle's Laplace matrix must equal PhiFlow's entry for entry (which also pins the neighbour /
 wrap-around rule the CG applies it with) and its iterates must equal PhiFlow's to round-off.  The fixture holds inputs (masks, right-hand
 side) and outputs (matrix triplets, iterates) only.
 
@@ -66,6 +66,7 @@ CASES = {
     "xper_ywall_16x128": ((16, 128), (pf.CLOSED, pf.PERIODIC), None),
 }
 ITERATIONS = (1, 2, 3, 7, 25)
+RESETS = (4, 10)
 
 
 def make(name, res, boundaries, obstacle, rng):
@@ -101,6 +102,17 @@ def make(name, res, boundaries, obstacle, rng):
         assert int(res_k.iterations) == k, (name, k, res_k.iterations)
         out["x_%d" % k] = np.asarray(res_k.x, np.float64).reshape(-1)
         out["r_%d" % k] = np.asarray(res_k.residual, np.float64).reshape(-1)
+    # Restarts.  The CUDA loop recomputes r = b - A x, p = r at the top of every iteration k with (k + 1) % reset == 0
+    # (pressure_solve_op.cu.cc:260-274) and then takes that iteration's step: reset - 1 iterations from x0 = 0, then blocks of `reset`
+    # iterations, each starting from the true residual - which is PhiFlow's CG called again with the previous x as its initial guess.
+    for reset in RESETS:
+        x = np.zeros((1, N))
+        done = 0
+        for block in [reset - 1] + [reset] * 2:
+            x = np.asarray(conjugate_gradient(apply_A, b.reshape(1, N).copy(), np.asarray(x, np.float64).copy(), accuracy=None, max_iterations=block).x, np.float64)
+            done += block
+            out["x_reset%d_%d" % (reset, done)] = x.reshape(-1).copy()
+    out["resets"] = np.array(RESETS)
     return out
 
 

@@ -88,3 +88,23 @@ def test_hip_laplace_operator_is_the_references_divergence_of_the_scaled_gradien
     L = laplace_matrix_native(nx, ny, dev(g["active_ext"].reshape(-1), torch.float32), dev(g["accessible_ext"].reshape(-1), torch.float32),
                               dev(g["a0_flat_vfirst"], torch.float32), dtype)
     check_laplace_operator(g, L.cpu().numpy().astype(np.float64))
+
+
+@pytest.mark.parametrize("name,path", _PATHS)
+def test_hip_cg_restart_cadence_is_phiflows_cg_called_again(name, path, piso_option):
+    """residual_reset on every HIP path (inside the one-workgroup kernel, between two-kernel iterations, between persistent segments)
+    against PhiFlow's CG called again with the previous x as its guess (see the oracle's test of the same name)."""
+    from diffpiso.solvers import cg_solve_native
+    g = load(name)
+    L, nx, ny = hip_laplace(g)
+    per_y, per_x = [bool(v) for v in g["periodic_yx"]]
+    if path == "two_kernel":
+        piso_option("cg_persist", 0); piso_option("cg_tiny", 0)
+    elif path == "persistent":
+        piso_option("cg_persist", 1); piso_option("cg_pad", 0)
+    b = dev(g["b"])
+    for reset in [int(v) for v in g["resets"]]:
+        for k in (reset - 1, 2 * reset - 1, 3 * reset - 1):
+            x, it = cg_solve_native(nx, ny, per_x, per_y, L, b, 1e-30, k, False, reset)
+            want = g["x_reset%d_%d" % (reset, k)]
+            assert int(it) == k and np.abs(x.cpu().numpy() - want).max() <= 1e-9 * np.abs(want).max(), (name, path, reset, k)

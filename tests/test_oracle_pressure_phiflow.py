@@ -74,6 +74,21 @@ def test_oracle_cg_iterates_are_phiflows(name, solver):
         assert np.abs(x - want).max() <= 1e-11 * np.abs(want).max(), (name, k)
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_cg_restart_cadence_is_phiflows_cg_called_again(name):
+    """residual_reset: r = b - A x, p = r at the top of every iteration k with (k + 1) % reset == 0 (pressure_solve_op.cu.cc:260-274),
+    then that iteration's step - i.e. PhiFlow's CG run for reset - 1 iterations, then called again (initial guess = previous x) for
+    blocks of `reset` iterations.  Pins the cadence and the restart formula."""
+    g = load(name)
+    L, nx, ny = oracle_laplace(g)
+    per_y, per_x = [bool(v) for v in g["periodic_yx"]]
+    for reset in [int(v) for v in g["resets"]]:
+        for k in (reset - 1, 2 * reset - 1, 3 * reset - 1):
+            x, it = O.cg_solve(nx, ny, per_x, per_y, L, g["b"], 1e-30, k, False, reset)
+            want = g["x_reset%d_%d" % (reset, k)]
+            assert it == k and np.abs(x - want).max() <= 1e-10 * np.abs(want).max(), (name, reset, k)
+
+
 # ---- the A0-weighted operator against the composition of the reference's own gradient / divergence helpers
 GOLD_OP = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "laplace_operator.npz")
 OP_CASES = ["periodic", "closed", "open", "xper_ywall", "spatial_ml", "yper_xopen"]
