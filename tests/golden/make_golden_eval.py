@@ -1,8 +1,9 @@
 """Golden fixtures for the "next" rows of SURVEY.md 8(f): LES strain / Smagorinsky viscosity (diffpiso/LES_models.py), the
 numpy energy spectrum (diffpiso/evaluation_tools.py:92-113) and the staggered pieces the losses are built from
 (PhiFlow: StaggeredGrid(tensor), at_centers, math.gradient 'forward').  Same machinery as make_golden.py: the reference's own
-Python on PhiFlow's numpy backend; only inputs and outputs are stored.  The TensorFlow arithmetic of diffpiso/losses.py and
-EK_spectrum_2D_tf cannot run here (no TensorFlow): those are restated in oracle/eval_ref.py and marked "parity unpinned".
+Python on PhiFlow's numpy backend; only inputs and outputs are stored.  EK_spectrum_2D_tf cannot run here (no TensorFlow): it is
+restated in oracle/eval_ref.py and marked "parity unpinned"; three of the four losses of diffpiso/losses.py ARE executed, by
+make_golden_losses.py.
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_eval.py
 """

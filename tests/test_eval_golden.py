@@ -225,3 +225,40 @@ def test_analysis_helpers_match_reference_golden():
     k3, e3 = dp.EK_spectrum_3D(d["spec3d/velocity_centered"], None)
     np.testing.assert_allclose(k3, d["spec3d/wavenumbers"], rtol=1e-12)
     np.testing.assert_allclose(e3, d["spec3d/energy"], rtol=1e-10)
+
+
+def test_losses_against_the_references_own_loss_code(golden_dir, device):
+    """tests/golden/losses.npz: outputs of the reference's diffpiso/losses.py, executed on PhiFlow's numpy backend with three
+    TensorFlow primitives supplied (l2_loss, reduce_sum, abs: tests/golden/make_golden_losses.py).  Pins which slices enter, the
+    buffer widths and the sponge cut, the per-step factors, the averaging windows with their edge rules and the grouping of the
+    per-step mode - for the product's losses and for the numpy restatement the other loss tests use."""
+    g = np.load(os.path.join(golden_dir, "losses.npz"))
+    gt, pred = g["gt"], [p for p in g["pred"]]
+    steps = len(pred)
+    bw = [[int(v) for v in row] for row in g["buffer_width"]]
+    lf = [float(v) for v in g["loss_factors"]]
+    box = dp.box[0:float(g["box"][0]), 0:float(g["box"][1])]
+    grids = [dp.StaggeredGrid(torch.tensor(p, dtype=torch.float64, device=device), box, extrapolation="periodic") for p in pred]
+    gtt = torch.tensor(gt, dtype=torch.float64, device=device)
+    zero = torch.zeros((), dtype=torch.float64, device=device)
+    close = lambda a, b: np.testing.assert_allclose(np.asarray([float(v) for v in np.atleast_1d(a)]), np.atleast_1d(b), rtol=2e-6)      # (PhiFlow holds the fields in float32)
+    f = lambda t: [float(v) for v in t] if isinstance(t, (list, tuple)) else float(t)
+    close(f(dp.L2_field_loss(zero, [grids], [gtt], steps, bw, lf, 0)[1]), g["l2_buffered"])
+    tot, c = dp.L2_field_loss(zero + 2.0, [grids], [gtt], [1, 4], None, 0.7, 0)
+    close(f(c), g["l2_range_1_4"]); close(f(tot), g["l2_range_1_4_total"])
+    close(f(dp.L2_field_loss(zero, [grids], [gtt], steps, bw, lf, 10)[1]), g["l2_sponge_10"])
+    per, groups = dp.L2_field_loss([zero] * steps, [grids], [gtt], steps, bw, lf, 0, sum_steps=False, loss_influence_range=2)
+    close(f(per), g["l2_per_step"]); close(f(groups), g["l2_groups"])
+    close(f(dp.strain_rate_loss(zero, [grids], [gtt], steps, None, 2.0)[1]), g["strain"])
+    per, contrib = dp.strain_rate_loss([zero] * steps, [grids], [gtt], steps, None, [1.0 + s for s in range(steps)], sum_steps=False, loss_influence_range=2)
+    close(f(per), g["strain_per_step"]); close(f(contrib), g["strain_contrib"])
+    for window in (None, 3, 2):
+        close(f(dp.multistep_averaging_loss(zero, [grids], [gtt], steps, bw, 1.3, loss_influence_range=window)[1]), g["averaging_%s" % window])
+    per, _ = dp.multistep_averaging_loss([zero] * steps, [grids], [gtt], steps, bw, 1.3, sum_steps=False, loss_influence_range=3)
+    close(f(per), g["averaging_per_step"])
+    # the numpy restatement (oracle/eval_ref.py) that the other loss tests compare with
+    close(E.l2_field_loss([pred], [gt], [0, steps], bw, lf, 0), g["l2_buffered"])
+    close(E.l2_field_loss([pred], [gt], [1, 4], None, [0.7] * 4, 0), g["l2_range_1_4"])
+    close(E.strain_rate_loss([pred], [gt], [0, steps], [2.0] * steps, (float(g["box"][0]) / 12, float(g["box"][1]) / 16)), g["strain"])
+    for window in (None, 3, 2):
+        close(E.multistep_averaging_loss([pred], [gt], [0, steps], bw, 1.3, window), g["averaging_%s" % window])
