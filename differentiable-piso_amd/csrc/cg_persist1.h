@@ -219,8 +219,29 @@ __device__ __forceinline__ double lanes_xor4(double v) {    // lane l <- lane l 
   return dpp_update<0x114, 0xa>(dpp_update<0x104, 0x5>(v, v), v);
 }
 __device__ __forceinline__ double lanes_xor8(double v) { return dpp_move<0x128>(v); }                  // row_ror:8
-__device__ __forceinline__ double lanes_xor16(double v) { return __shfl_xor(v, 16, 64); }            // (ds_bpermute_b32 x 2)
-__device__ __forceinline__ double lanes_xor32(double v) { return __shfl_xor(v, 32, 64); }
+// v + (v of lane l ^ 16) and v + (v of lane l ^ 32): gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd rows (the upper
+// half) of one register with the even rows (the lower half) of another - two swaps of the value with itself leave "mine" and "the
+// partner's" in two registers of EVERY lane, no trip through the LDS crossbar (ds_bpermute: ~100 cycles each in a dependent chain
+// that every wave of the chip waits for).  Both lanes of a pair add the same two numbers (a + b, b + a: the same bits), as before.
+#ifndef PISO_PERSIST1_PERMLANE_SWAP
+#define PISO_PERSIST1_PERMLANE_SWAP 1
+#endif
+template <int ROWS>
+__device__ __forceinline__ double sum_xor_rows(double v) {
+#if PISO_PERSIST1_PERMLANE_SWAP
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+  const auto r0 = ROWS == 16 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto r1 = ROWS == 16 ? __builtin_amdgcn_permlane16_swap(hi, hi, false, false) : __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const double x = __longlong_as_double((long long)(((unsigned long long)r1[0] << 32) | r0[0]));
+  const double y = __longlong_as_double((long long)(((unsigned long long)r1[1] << 32) | r0[1]));
+  return x + y;
+#else
+  return v + __shfl_xor(v, ROWS, 64);                       // (ds_bpermute_b32 x 2)
+#endif
+}
+__device__ __forceinline__ double sum_xor16(double v) { return sum_xor_rows<16>(v); }
+__device__ __forceinline__ double sum_xor32(double v) { return sum_xor_rows<32>(v); }
 // Eight per-lane partial sums -> lane l holds the WAVE total of value l & 7.  Reduce-scatter butterfly over lane bits 0, 1, 2 (a
 // lane keeps half of its values and receives the partner's contribution to them: 7 + 7 + ... instructions instead of three full
 // butterflies of eight values), then plain butterflies of the ONE remaining value over bits 3 (DPP), 4 and 5 (LDS crossbar).
@@ -238,8 +259,8 @@ __device__ __forceinline__ double wave_reduce_scatter8(const double (&v)[8]) {
     b[m] = (b1 ? a[2 * m + 1] : a[2 * m]) + dpp_move<0x4E>(b1 ? a[2 * m] : a[2 * m + 1]);      // quad_perm [2,3,0,1]
   double c = (b2 ? b[1] : b[0]) + lanes_xor4(b2 ? b[0] : b[1]);                                 // value l & 7, summed over 8 lanes
   c += lanes_xor8(c);
-  c += lanes_xor16(c);
-  c += lanes_xor32(c);
+  c = sum_xor16(c);
+  c = sum_xor32(c);
   return c;
 }
 // slot / nslots: this workgroup's record and the number of records in play (blockIdx.x / gridDim.x, or the rank / size of the
@@ -328,8 +349,8 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
       const u64 bits = (w[i] >> 32) | ((u64)hi_other << 32);
       acc += __longlong_as_double((long long)bits);          // (odd lanes add garbage that nobody reads; absent records add 0)
     }
-    acc += lanes_xor16(acc);                                 // the four records-per-instruction groups of lanes (LDS crossbar)
-    acc += lanes_xor32(acc);
+    acc = sum_xor16(acc);                                 // the four records-per-instruction groups of lanes (LDS crossbar)
+    acc = sum_xor32(acc);
     if (lane < 2 * NV && !(lane & 1)) sm[64 + wave * NV + (lane >> 1)] = (T)acc;   // this wave's 32 records, value lane / 2
     if (lane == 0) {
       sm[128 + wave] = good ? (T)0 : (T)1;
@@ -343,8 +364,8 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
     // with the total of value l % 8 - the same bits in every wave of every workgroup (same inputs, same order)
     double t = (double)sm[64 + lane];
     t += lanes_xor8(t);
-    t += lanes_xor16(t);
-    t += lanes_xor32(t);
+    t = sum_xor16(t);
+    t = sum_xor32(t);
 #pragma unroll
     for (int q = 0; q < NV; ++q) v[q] = (T)read_lane_c(t, q);
     const T bad = sm[128 + (lane & (kPersistWaves - 1))];
@@ -461,8 +482,8 @@ __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[
         const double val = __longlong_as_double((long long)((w[i] >> 32) | ((u64)hi_other << 32)));   // (odd lanes: garbage that nobody reads)
         acc += (lw < lim - i * 64) ? val : 0.0;
       }
-      acc += lanes_xor16(acc);
-      acc += lanes_xor32(acc);                                // even lane 2 q (of every group of 16): the XCD's sum of value q
+      acc = sum_xor16(acc);
+      acc = sum_xor32(acc);                                // even lane 2 q (of every group of 16): the XCD's sum of value q
       const double other = dpp_move<0xB1>(acc);              // odd lanes: the even neighbour's sum
       const u64 bits = (u64)__double_as_longlong((lane & 1) ? other : acc);
       const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
@@ -496,8 +517,8 @@ __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[
       const double val = __longlong_as_double((long long)((w[i] >> 32) | ((u64)hi_other << 32)));
       acc += (((present >> (i * 4)) >> (lw >> 4)) & 1u) ? val : 0.0;
     }
-    acc += lanes_xor16(acc);
-    acc += lanes_xor32(acc);                                  // lane 2 q: the total of value q - the same bits in every wave of the chip
+    acc = sum_xor16(acc);
+    acc = sum_xor32(acc);                                  // lane 2 q: the total of value q - the same bits in every wave of the chip
 #pragma unroll
     for (int q = 0; q < NV; ++q) v[q] = (T)read_lane_c(acc, 2 * q);
   }
@@ -569,8 +590,8 @@ __device__ __forceinline__ bool grid_exchange8_local(const PersistCtl& c, T (&v)
       const double val = __longlong_as_double((long long)((w[i] >> 32) | ((u64)hi_other << 32)));
       acc += (lw < lim - i * 64) ? val : 0.0;
     }
-    acc += lanes_xor16(acc);
-    acc += lanes_xor32(acc);
+    acc = sum_xor16(acc);
+    acc = sum_xor32(acc);
 #pragma unroll
     for (int q = 0; q < NV; ++q) v[q] = (T)read_lane_c(acc, 2 * q);
   }
@@ -637,8 +658,8 @@ __device__ __forceinline__ bool xgpu_exchange8(unsigned sl_off, T (&v)[kX1Values
       const unsigned hi_other = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(w[i] >> 32), 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
       acc += __longlong_as_double((long long)((w[i] >> 32) | ((peer_u64)hi_other << 32)));   // (odd lanes: garbage nobody reads)
     }
-    acc += lanes_xor16(acc);                                 // ranks r, r + 1, r + 2, r + 3 (+ 4) sit in the four rows of lanes
-    acc += lanes_xor32(acc);
+    acc = sum_xor16(acc);                                 // ranks r, r + 1, r + 2, r + 3 (+ 4) sit in the four rows of lanes
+    acc = sum_xor32(acc);
     if (lane < 2 * kX1Values && !(lane & 1)) smx[lane >> 1] = (T)acc;
     if (lane == 0) smx[kX1Values] = good ? (T)0 : (T)1;
   }
