@@ -32,7 +32,7 @@ One JSON line on stdout (rank 0) with, besides the contract's keys:
   slab_kernel_loopback   (N = 1) us per iteration of the SLAB instance of the persistent CG kernel in a ring of one rank (edge rows
                 and totals through the rank's own peer mailbox) next to the plain kernel on the same system: the kernel-level
                 weak-scaling efficiency of the sharded N > 1 headline before any xGMI hop
-  other_configs ms per step of BASELINE.json's config 2 (256^2 forward) and config 3 (512x256 fwd + adjoint, 4 steps)
+  other_configs ms per step of BASELINE.json's configs 1-4 (+ us per pressure-CG iteration inside them) and config 5's grid on one GPU
   cpu_baseline  the C oracle (a port of the reference's algorithm) on all host cores, bounded sample (rank 0, N = 1 only)
 """
 import argparse
@@ -1075,8 +1075,14 @@ def config4_training_iteration(device, steps=16):
     for s_ in (psolver.stats, sim.linear_solver.stats):
         for k_ in s_:
             s_[k_] = 0
+    import ctypes as C
+    import diffpiso._native as N
+    N.lib.piso_cg_profile_enable(1, 16)              # (the warm-up iteration carries the event records of the CG clock, the timed one none)
     iteration()
     torch.cuda.synchronize()
+    ms_cg, cnt_cg = (C.c_double * 4)(), (C.c_longlong * 4)()
+    N.lib.piso_cg_profile_read(ms_cg, cnt_cg)
+    N.lib.piso_cg_profile_enable(0, 16)
     it0 = (psolver.stats["iterations"], psolver.stats["adjoint_iterations"])
     t0 = time.perf_counter()
     loss, warn = iteration()
@@ -1085,6 +1091,7 @@ def config4_training_iteration(device, steps=16):
     gnorm = float(torch.sqrt(sum((w.grad.double() ** 2).sum() for w in net.weights)))
     return {"ms_per_training_iteration": ms, "unrolled_steps": steps, "ms_per_unrolled_step": ms / steps,
             "cg_iterations_fwd_adjoint": [psolver.stats["iterations"] - it0[0], psolver.stats["adjoint_iterations"] - it0[1]],
+            "cg_us_per_iteration": (1e3 * ms_cg[2] / cnt_cg[2]) if cnt_cg[2] > 0 else None,
             "loss": loss, "weight_grad_norm": gnorm, "solver_warnings": warn,
             "what": "1024 x 256 spatial mixing layer + sponge, 7-layer CNN closure (fp32 MFMA convolutions) in every step, forward + reverse "
                     "sweep down to the convolution kernels, solver precision 1e-6 / 10000 iterations / reset 1000"}
@@ -1092,8 +1099,28 @@ def config4_training_iteration(device, steps=16):
 
 def other_configs(device):
     """Driver-visible timings of the smaller BASELINE.json configurations (extra keys, not the headline)."""
+    import ctypes as C
     import torch
+    import diffpiso._native as N
     res = {}
+
+    class cg_clock(object):
+        """us per pressure-CG iteration of what runs inside: HIP-event time of the persistent segments / the iterations they ran
+        (grids of the one-workgroup kernel have no segments: key absent)."""
+        def __init__(self, key):
+            self.key = key
+
+        def __enter__(self):
+            N.lib.piso_cg_profile_enable(1, 16)
+
+        def __exit__(self, *exc):
+            ms, cnt = (C.c_double * 4)(), (C.c_longlong * 4)()
+            torch.cuda.synchronize()
+            N.lib.piso_cg_profile_read(ms, cnt)
+            N.lib.piso_cg_profile_enable(0, 16)
+            if cnt[2] > 0:
+                res[self.key] = 1e3 * ms[2] / cnt[2]
+            return False
     try:                                                                # config 1: lid-driven cavity 64 x 64, Re 400, as the reference's script steps it
         sys.path.insert(0, os.path.join(ROOT, "examples"))
         import lid_driven_cavity_2d as ldc
@@ -1113,6 +1140,8 @@ def other_configs(device):
         run_unrolled(P2, 10, backward=False)
         torch.cuda.synchronize()
         res["config2_256x256_forward_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / 10
+        with cg_clock("config2_cg_us_per_iteration"):       # (a separate run: the event records are not in the timed one)
+            run_unrolled(P2, 2, backward=False)
     res["config2_last_cg_iterations"] = P2["ps"].last_iterations
     P3 = build_mixing_layer(256, 512, device, 1e-6, 10000, 1000)        # config 3: 512x256, fwd + adjoint, 4-step unroll
     run_unrolled(P3, 1)
@@ -1121,6 +1150,8 @@ def other_configs(device):
     run_unrolled(P3, 4)
     torch.cuda.synchronize()
     res["config3_512x256_fwd_adjoint_ms_per_step"] = 1e3 * (time.perf_counter() - t0) / 4
+    with cg_clock("config3_cg_us_per_iteration"):
+        run_unrolled(P3, 1)
     res["config3_last_cg_iterations_fwd_adjoint"] = [P3["ps"].last_iterations, P3["ps"].last_adjoint_iterations]
     try:                                                                # config 4: one training iteration with the CNN closure in the loop
         res["config4_1024x256_cnn_closure_16_step_unroll"] = config4_training_iteration(device)
