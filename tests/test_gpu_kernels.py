@@ -308,6 +308,7 @@ def test_bicgstab_matches_oracle(name, transpose, dtype, band):
 
 _FOLD_CASES = [(name, (40, 36), transpose, tol, max_it) for name in ("periodic", "cavity", "spatial_ml") for transpose in (False, True)
                for tol, max_it in ((1e-5, 200), (1e-30, 7), (1e-30, 1))]
+_FOLD_CASES += [("cavity", (40, 36), False, 1e-30, k) for k in (0, 2, 3, 4, 5)]      # (every chunk boundary of the host loop: looks after 2, 4, 6 ... iterations)
 _FOLD_CASES += [("periodic", (512, 520), False, 1e-5, 200), ("periodic", (512, 520), False, 1e-30, 1)]   # 261 partial records per component:
                                                                                                        # more than one pass of a block
 
