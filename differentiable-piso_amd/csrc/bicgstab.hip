@@ -180,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
         a.eval[base + q] = q < ne ? ev[q] : (T)0;
       }
     }
-    nan_seen |= is_nan(a.rhs[k]) | is_nan(x0[k]);
+    nan_seen = nan_seen || is_nan(a.rhs[k]) || is_nan(x0[k]);
     a.x[k] = x0[k];                                                     // cublas copy x_old -> x (:261)
   }
   if (bad) a.flags[0] = 1;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void bi_residual_init(BiArgs<T> a) {
   __shared__ T smem[16];
   const int c = blockIdx.y;
   if (a.sc[c].done) return;
-  const int n = a.g.n[c], r0 = a.g.r0[c];
+  const int r0 = a.g.r0[c];
   T acc[1] = {0};
   for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
     const int k = r0 + row;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kBlock) void bi_update_p(BiArgs<T> a) {
   const int c = blockIdx.y;
   const CompScalars<T> s = folded_scalars(a, c, smem);      // (folded: ||r|| test of the iteration before, then rho / beta)
   if (s.done) return;
-  const int n = a.g.n[c], r0 = a.g.r0[c];
+  const int r0 = a.g.r0[c];
   for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
     const int k = r0 + row;
     a.p[k] = (a.p[k] - s.omega * a.v[k]) * s.beta + a.r[k];
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void bi_update_xr(BiArgs<T> a) {
   const int c = blockIdx.y;
   const CompScalars<T> s = folded_scalars(a, c, smem);      // (folded: alpha / omega from the product's sums)
   if (s.done) return;
-  const int n = a.g.n[c], r0 = a.g.r0[c];
+  const int r0 = a.g.r0[c];
   const T coef = WHICH == 0 ? s.alpha : s.omega;
   const T* __restrict__ dir = WHICH == 0 ? a.ph : a.sh;
   const T* __restrict__ w = WHICH == 0 ? a.v : a.t;
@@ -571,7 +571,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void bi_zero_x(BiArgs<T> a, int comp_mask) {
   const int c = blockIdx.y;
   if (!((comp_mask >> c) & 1)) return;
-  const int n = a.g.n[c], r0 = a.g.r0[c];
+  const int r0 = a.g.r0[c];
   for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) a.x[r0 + row] = 0;
 }
 
