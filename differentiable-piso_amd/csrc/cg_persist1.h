@@ -176,7 +176,7 @@ __device__ __forceinline__ F karg(unsigned off) {
 #define PISO_PERSIST1_HALO_AT 0                 // 16-row regions: the U row step in front of which the neighbours' z' rows are requested (0: behind the exchange)
 #endif
 #ifndef PISO_PERSIST1_POLL_DELAY2
-#define PISO_PERSIST1_POLL_DELAY2 24            // s_sleep units in front of the first polling pass of the tree's second level
+#define PISO_PERSIST1_POLL_DELAY2 40            // s_sleep units in front of the first polling pass of the tree's second level (2048^2, behind the rows computed ahead: 24 -> 9.12, 32 / 40 -> 8.94 us per iteration, six processes each on one box)
 #endif
 #ifndef PISO_PERSIST1_POLL_DELAY2_NOAHEAD
 #define PISO_PERSIST1_POLL_DELAY2_NOAHEAD 8     // ... where no rows are computed ahead in front of it (small regions on mid-size grids: 24 -> 8: 4.27 -> 4.15 us at 512^2 / 1024 x 256, 0: 4.22)
