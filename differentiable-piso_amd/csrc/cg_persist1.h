@@ -181,6 +181,9 @@ __device__ __forceinline__ F karg(unsigned off) {
 #ifndef PISO_PERSIST1_POLL_DELAY2_NOAHEAD
 #define PISO_PERSIST1_POLL_DELAY2_NOAHEAD 8     // ... where no rows are computed ahead in front of it (small regions on mid-size grids: 24 -> 8: 4.27 -> 4.15 us at 512^2 / 1024 x 256, 0: 4.22)
 #endif
+#ifndef PISO_PERSIST1_LOCAL_DELAY
+#define PISO_PERSIST1_LOCAL_DELAY 8             // XCD-local exchange with one working wave per SIMD: s_sleep units in front of the first polling pass
+#endif
 #ifndef PISO_PERSIST1_POLL_SLEEP
 #define PISO_PERSIST1_POLL_SLEEP 1              // s_sleep units (64 cycles) between two polling passes
 #endif
@@ -572,6 +575,10 @@ __device__ __forceinline__ bool grid_exchange8_local(const PersistCtl& c, T (&v)
     u64 w[8];
     const int lim = nslots * kX1RecWords;
     unsigned spins = 0;
+    // (one working wave per SIMD - c.waves = 4: the record needs ~0.2 us to arrive and a first pass that misses it queues in front
+    // of the one that would find it: 256^2 3.33 -> 3.15 us per iteration with 8 units, 4: 3.21, 12: 3.23; with two working waves per
+    // SIMD - 512 x 256 - any delay loses: 3.84 / 3.83 / 3.92 / 4.00 / 4.10 with 0 / 4 / 8 / 12 / 16)
+    if (PISO_PERSIST1_LOCAL_DELAY > 0 && c.waves < kPersistWaves) __builtin_amdgcn_s_sleep(PISO_PERSIST1_LOCAL_DELAY);
     while (true) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(rec + lw + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
