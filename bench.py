@@ -1077,17 +1077,17 @@ def config4_training_iteration(device, steps=16):
             s_[k_] = 0
     import ctypes as C
     import diffpiso._native as N
-    N.lib.piso_cg_profile_enable(1, 16)              # (the warm-up iteration carries the event records of the CG clock, the timed one none)
     iteration()
     torch.cuda.synchronize()
-    ms_cg, cnt_cg = (C.c_double * 4)(), (C.c_longlong * 4)()
-    N.lib.piso_cg_profile_read(ms_cg, cnt_cg)
-    N.lib.piso_cg_profile_enable(0, 16)
     it0 = (psolver.stats["iterations"], psolver.stats["adjoint_iterations"])
+    N.lib.piso_cg_profile_enable(1, 16)              # (HIP-event pairs around the ~400 persistent launches of the iteration: microseconds in 0.9 s)
     t0 = time.perf_counter()
     loss, warn = iteration()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0)
+    ms_cg, cnt_cg = (C.c_double * 4)(), (C.c_longlong * 4)()
+    N.lib.piso_cg_profile_read(ms_cg, cnt_cg)
+    N.lib.piso_cg_profile_enable(0, 16)
     gnorm = float(torch.sqrt(sum((w.grad.double() ** 2).sum() for w in net.weights)))
     return {"ms_per_training_iteration": ms, "unrolled_steps": steps, "ms_per_unrolled_step": ms / steps,
             "cg_iterations_fwd_adjoint": [psolver.stats["iterations"] - it0[0], psolver.stats["adjoint_iterations"] - it0[1]],

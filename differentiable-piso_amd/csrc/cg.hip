@@ -224,7 +224,11 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     // the exchanges spin: EVERY workgroup must be resident at the same time.  What the occupancy calculator says one CU can
     // hold (LDS, registers) times the CUs of the device must cover the grid; what it cannot see (another process, a CU mask)
     // is caught by the spin bound -> restart on the two-kernel path (below).
-    constexpr bool kCanSymO = RECON && sizeof(CT) == 4;
+    // (the symmetric variant - S and W streamed, N and E taken from the neighbours' S and W - also serves systems whose diagonal cannot
+    // be rebuilt from the off-diagonals: open boundaries, where the diagonal carries the face to the outside - BASELINE config 4.  It
+    // then streams the diagonal beside S and W: 16 instead of 24 bytes per cell and pass.  fp64 state only: the fp32 instances keep
+    // their registers only with rebuilt diagonals.)
+    constexpr bool kCanSymO = sizeof(CT) == 4 && (RECON || sizeof(T) == 8);
     const void* kfn = persist_kernel<T, CT, RECON, false>(persist_R);
     if constexpr (kCanSymO) { if (symmetric) kfn = persist_kernel<T, CT, RECON, true>(persist_R, ragged); }
     int per_cu = 0, dev = 0, cus = 0;
@@ -278,7 +282,8 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
       else if (persist_R == 4) cg_persist1<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
       else cg_persist1<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);                      \
     } while (0)
-    if constexpr (kCanSym) {
+    constexpr bool kCanSymPlain = sizeof(CT) == 4 && (RECON || sizeof(T) == 8);     // (see kCanSymO above)
+    if constexpr (kCanSymPlain) {
       if (symmetric) {
         PISO_PERSIST_LAUNCH(true);
         PISO_LAUNCH_CHECK();

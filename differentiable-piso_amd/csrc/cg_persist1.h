@@ -1014,7 +1014,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // keep the round-2 depth, they spill otherwise)
   constexpr bool kDeep = NQ == 1 && NT == 16 && SYM && RECON && (!SLAB || PISO_PERSIST1_DEEP_SLAB != 0) && sizeof(T) == 8;
   constexpr int depth_max = kDeep ? PISO_PERSIST1_DEPTH : ((NQ == 1) ? 3 : kPersistMaxDepth);
-  constexpr int budget = kDeep ? 4 * PISO_PERSIST1_DEPTH : ((NQ == 1 || NT < 16) ? 16 : 8);
+  // (small regions whose rows carry the diagonal too - systems with open boundaries, BASELINE config 4: 8 registers per row - get the
+  // registers for FOUR rows in flight as well: with regions of 2 rows that is every row of the wave, i.e. the coefficients stay
+  // resident as they do with rebuilt diagonals; with two rows in flight both passes waited for L2: 1024 x 256 4.87 against 4.10 us)
+  constexpr int budget = kDeep ? 4 * PISO_PERSIST1_DEPTH : ((NQ == 1 || NT < 16) ? ((NT < 16 && !RECON && SYM) ? 32 : 16) : 8);
   constexpr int Dw = budget / coef_regs < 2 ? 2 : (budget / coef_regs > depth_max ? depth_max : budget / coef_regs);
   constexpr int D = (NT >= Dw) ? Dw : NT;
   constexpr int kBaseLoads = (SYM ? 2 : 4) + (RECON ? 0 : 1);          // vector loads every row issues (some rows one or two more)
