@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd")); sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import torch
 import diffpiso._native as N
-from diag_persist1 import case
+from tests.cases import pressure_system as case
 from diffpiso.solvers import cg_solve_native
 for nx, ny in ((256, 256), (512, 256), (512, 512), (1024, 256), (1024, 512), (1024, 1024)):
     L, b = case(nx, ny)

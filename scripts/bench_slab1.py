@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd")); sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import torch
 import diffpiso._native as N
-from diag_persist1 import case
+from tests.cases import pressure_system as case
 from diffpiso.distributed import SlabCommunicator, cg_solve_slab
 from diffpiso.solvers import cg_solve_native
 

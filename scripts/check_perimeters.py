@@ -6,7 +6,7 @@ import torch
 import diffpiso._native as N
 from diffpiso.solvers import cg_solve_native
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
-from diag_persist1 import case
+from tests.cases import pressure_system as case
 nx = ny = 2048
 n = nx * ny
 L, b = case(nx, ny)

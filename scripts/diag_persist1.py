@@ -6,20 +6,7 @@ import torch
 import diffpiso._native as N
 from diffpiso.solvers import cg_solve_native, laplace_matrix_native
 
-def case(nx, ny, walls=False, seed=11):
-    dev = torch.device("cuda")
-    g = torch.Generator(device="cpu"); g.manual_seed(seed)
-    a0 = 0.5 + torch.rand(nx * (ny + 1) + (nx + 1) * ny, generator=g)
-    a0v = a0[:nx * (ny + 1)].view(ny + 1, nx); a0u = a0[nx * (ny + 1):].view(ny, nx + 1)
-    a0v[ny] = a0v[0]; a0u[:, nx] = a0u[:, 0]
-    a0 = a0.to(dev)
-    act = torch.ones((ny + 2, nx + 2))
-    if walls:
-        act[0, :] = 0; act[-1, :] = 0; act[:, 0] = 0; act[:, -1] = 0
-    act = act.reshape(-1).to(dev)
-    L = laplace_matrix_native(nx, ny, act, act, a0, torch.float64)
-    b = torch.randn(nx * ny, generator=g, dtype=torch.float64).to(dev); b -= b.mean()
-    return L, b
+from tests.cases import pressure_system as case
 
 def main():
     for (nx, ny, rows) in [(2048, 2048, 16), (1024, 2048, 16), (2048, 512, 16), (1024, 1024, 2), (2048, 1024, 4), (512, 512, 2)]:

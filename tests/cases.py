@@ -133,3 +133,24 @@ def product_setup(c, lin_tol=1e-5, lin_max_it=2000, lin_double=False, p_tol=1e-5
     p_ext = dp.pressure_extrapolation(domain.boundaries)
     pressure = dp.CenteredGrid(torch.tensor(c["p"], device=dev)[None, :, :, None], box=domain.box, extrapolation=p_ext)
     return dict(domain=domain, sim=sim, velocity=velocity, pressure=pressure, lin=lin, ps=ps, vel_tensor=vel_t)
+
+
+def pressure_system(nx, ny, walls=False, seed=11):
+    """A doubly periodic (or, walls=True, wall-bounded) pressure system at any size for the kernel-level CG tests and benchmarks:
+    random A0 face weights in [0.5, 1.5) with consistent periodic duplicates (a symmetric matrix), the HIP Laplace matrix of it
+    [nx * ny, 5] float64 on the device and a zero-mean right-hand side.  (Was `case()` of scripts/diag_persist1.py.)"""
+    import torch
+    from diffpiso.solvers import laplace_matrix_native
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu"); g.manual_seed(seed)
+    a0 = 0.5 + torch.rand(nx * (ny + 1) + (nx + 1) * ny, generator=g)
+    a0v = a0[:nx * (ny + 1)].view(ny + 1, nx); a0u = a0[nx * (ny + 1):].view(ny, nx + 1)
+    a0v[ny] = a0v[0]; a0u[:, nx] = a0u[:, 0]
+    a0 = a0.to(dev)
+    act = torch.ones((ny + 2, nx + 2))
+    if walls:
+        act[0, :] = 0; act[-1, :] = 0; act[:, 0] = 0; act[:, -1] = 0
+    act = act.reshape(-1).to(dev)
+    L = laplace_matrix_native(nx, ny, act, act, a0, torch.float64)
+    b = torch.randn(nx * ny, generator=g, dtype=torch.float64).to(dev); b -= b.mean()
+    return L, b

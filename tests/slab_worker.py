@@ -13,7 +13,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 
 def main():
@@ -26,7 +25,7 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0 if share else rank)
     import diffpiso._native as N
-    from diag_persist1 import case
+    from tests.cases import pressure_system as case
     from diffpiso.distributed import SlabCommunicator, cg_solve_slab, slab_rows
     from diffpiso.solvers import cg_solve_native
     out = {"rank": rank, "world": world}

@@ -69,8 +69,7 @@ def test_persistent_cg_first_iterations_back_to_back_launches_2048(piso_option):
     (errors of 1e-12 after the third iteration, 1e-7 after the fourth - only when launches followed each other closely)."""
     from diffpiso.solvers import cg_solve_native
     import os, sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
-    from diag_persist1 import case
+    from tests.cases import pressure_system as case
     L, b = case(N, N)
     for nit in (3, 4, 6):
         piso_option("cg_persist", 0)
@@ -206,8 +205,7 @@ def test_persistent_solves_are_verified_against_the_true_residual(piso_option):
     import diffpiso._native as N
     from diffpiso.solvers import cg_solve_native
     import os, sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
-    from diag_persist1 import case
+    from tests.cases import pressure_system as case
     n = 1024
     L, b = case(n, n)
     runs0, fails0 = N.cg_verify_stats()

@@ -393,9 +393,8 @@ def test_cg_padded_grid_mode(shape, rank_deficient, reset, piso_option):
     short fixed runs must reproduce the unpadded two-kernel iteration to round-off (also under the rank-1 shift, which has to skip
     the padding), converged solves agree to the tolerance, the true-residual check of every such solve passes, and the oracle agrees."""
     import os, sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import diffpiso._native as N
-    from diag_persist1 import case
+    from tests.cases import pressure_system as case
     from diffpiso.solvers import cg_solve_native
     nx, ny = shape
     L, b = case(nx, ny, walls=True)

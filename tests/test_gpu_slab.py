@@ -75,8 +75,7 @@ def test_emulated_slabs_1024(slabs, walls):
     loopback all-reduce and halo exchange against the single-GPU solver - short fixed runs to round-off (only the grouping of the
     partial sums differs) and a converged solve to the tolerance."""
     import os, sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
-    from diag_persist1 import case
+    from tests.cases import pressure_system as case
     from diffpiso.distributed import cg_solve_slab_emulated
     from diffpiso.solvers import cg_solve_native
     n = 1024
@@ -101,8 +100,7 @@ def test_peer_transport_one_rank_persistent_slab_kernel(n, walls, piso_option):
     of the kernel runs, and the iterates must agree with the single-GPU solver to round-off (the two-kernel iterations around the
     segments group their partial sums differently).  Walls: no neighbours, the ring copies beyond the edges stay zero."""
     import os, sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
-    from diag_persist1 import case
+    from tests.cases import pressure_system as case
     from diffpiso.distributed import SlabCommunicator, cg_solve_slab
     from diffpiso.solvers import cg_solve_native
     L, b = case(n, n, walls=walls)
