@@ -21,16 +21,10 @@ struct AsmArgs {
   float area[2], spacing[2], beta;
   int n_u, n_v, nnz_u;
   FaceWin fw;                 // the rows this launch assembles (slab-decomposed step: this rank's face rows)
+  RowMap M;                   // where the rows of the arrays live (piso_common.h; one GPU: the identity)
+  int pattern_only;           // slab set-up: columns and row pointers of every STORED row, nothing else
+  int nnz_u_l;                // stored entries of the u matrix (= nnz_u on one GPU): where the v matrix starts in val / col
 };
-
-// closed-form CSR end offset of `row` (calcCsrRowPtrGpu, :472-505, 2-D branch)
-__device__ __forceinline__ int row_end(int row, int i, int j, int W, int H, int per_x, int per_y) {
-  int r = (row + 1) * 5;
-  r -= min(j, 1) * (W * (1 - per_y));
-  r -= ((1 - min(j, 1)) + (1 + max(j + 1 - H, -1))) * (i + 1) * (1 - per_y);
-  r -= (j * 2 + 1 + (1 + max(i + 1 - W, -1))) * (1 - per_x);
-  return r;
-}
 
 __global__ __launch_bounds__(kBlock) void assemble_kernel(AsmArgs a) {
   for (int w = blockIdx.x * kBlock + threadIdx.x; w < a.fw.count(); w += gridDim.x * kBlock) {
@@ -40,9 +34,10 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(AsmArgs a) {
     const int W = a.nx + (comp == 0), H = a.ny + (comp == 1);
     const int i = row % W, j = row / W;
     const int loc[2] = {i, j}, dims[2] = {W, H}, per[2] = {a.per_x, a.per_y}, stride[2] = {1, W};
-    float* val = a.val + (comp ? a.nnz_u : 0);
-    int* col = a.col + (comp ? a.nnz_u : 0);
-    int* rp = a.rowptr + (comp ? a.n_u + 1 : 0);
+    const RowMap& M = a.M;
+    float* val = a.val + (comp ? a.nnz_u_l : 0);
+    int* col = a.col + (comp ? a.nnz_u_l : 0);
+    int* rp = a.rowptr + (comp ? M.n_u + 1 : 0);          // (M.n_u: the STORED u faces)
 
     // neighbour existence and column, order: (low_x, high_x, low_y, high_y); wrap skips the duplicate face in the
     // component's own direction (:259-264, :281-286)
@@ -56,12 +51,14 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(AsmArgs a) {
       ncol[2 * d] = in_lo ? row - stride[d] : row + stride[d] * (dims[d] - 1 - own);
       ncol[2 * d + 1] = in_hi ? row + stride[d] : row - stride[d] * (dims[d] - 1 - own);
     }
-    const int end = row_end(row, i, j, W, H, a.per_x, a.per_y);
+    const int end_g = csr_row_end(row, i, j, W, H, a.per_x, a.per_y);
+    const int end = M.slot(comp, j, end_g);                // (whole-grid slot numbers -> stored ones; the identity on one GPU)
     const int start = end - (1 + exists[0] + exists[1] + exists[2] + exists[3]);
-    rp[row + 1] = end;
-    rp[row] = start;                                 // (the same value the row before writes: a windowed launch has no row before its first)
+    const int lrow = M.frow(comp, row);
+    rp[lrow + 1] = end;
+    rp[lrow] = start;                                // (the same value the row before writes: a windowed launch has no row before its first)
     // (a windowed launch may own neither first row: the two segment starts and the end of the u segment are closed forms)
-    if (w == 0) { a.rowptr[0] = 0; a.rowptr[a.n_u] = a.nnz_u; a.rowptr[a.n_u + 1] = 0; }
+    if (w == 0) { a.rowptr[0] = 0; a.rowptr[M.n_u] = a.nnz_u_l; a.rowptr[M.n_u + 1] = 0; }
     // slot of an entry = start + number of existing entries with a smaller column (rows are stored column-sorted,
     // which is what the slot arithmetic at :176-210 produces)
     int slot[5];
@@ -82,13 +79,15 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(AsmArgs a) {
     for (int e = 0; e < 4; ++e)
       if (exists[e]) { col[slot[e]] = ncol[e]; }
     col[slot[4]] = row;
+    if (a.pattern_only) continue;
 
-    if (a.dirichlet[g]) {                            // :214-238
+    const int gl = M.face(g);                        // this face in the stored face vectors
+    if (a.dirichlet[gl]) {                            // :214-238
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (exists[e]) val[slot[e]] = 0.f;
       val[slot[4]] = 1.f;
-      a.diag[g] = 0.f;
+      a.diag[gl] = 0.f;
       continue;
     }
 
@@ -100,14 +99,14 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(AsmArgs a) {
     for (int c = 0; c < 2; ++c) {
       int p = pad_offset[c] + (i + 1) + (j + 1) * pad_stride[c];
       const int back = (comp == 0) ? 1 : pad_stride[c];
-      float h = a.vel_pad[p];
-      flux[2 * c] = (float)(.5 * (h + a.vel_pad[p - back]) * a.area[c]);
+      float h = a.vel_pad[M.pad(p)];
+      flux[2 * c] = (float)(.5 * (h + a.vel_pad[M.pad(p - back)]) * a.area[c]);
       p += (c == 0) ? 1 : pad_stride[c];
-      h = a.vel_pad[p];
-      flux[2 * c + 1] = (float)(.5 * (h + a.vel_pad[p - back]) * a.area[c]);
+      h = a.vel_pad[M.pad(p)];
+      flux[2 * c + 1] = (float)(.5 * (h + a.vel_pad[M.pad(p - back)]) * a.area[c]);
     }
 
-    const float nu = a.viscosity[a.visc_is_field ? g : 0];
+    const float nu = a.viscosity[a.visc_is_field ? gl : 0];
     const int ms = a.nx + 2;
     float dv = 0.f;
 #pragma unroll
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(AsmArgs a) {
       {
         int off[2] = {0, 0};
         off[d] = -1;
-        const int nb = (i + 1 + off[0]) + (j + 1 + off[1]) * ms;
+        const int nb = M.mask((i + 1 + off[0]) + (j + 1 + off[1]) * ms);
         const int ns = a.no_slip ? a.no_slip[nb] : 0;
         const int open = (a.active[nb] == 1.0f) || ((loc[d] >= 1) && ns);
         const float v = (float)(flux[2 * d] * .5 + diff);
@@ -127,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(AsmArgs a) {
       {
         int off[2] = {0, 0};
         off[d] = 1 - own;
-        const int nb = (i + 1 + off[0]) + (j + 1 + off[1]) * ms;
+        const int nb = M.mask((i + 1 + off[0]) + (j + 1 + off[1]) * ms);
         const int ns = a.no_slip ? a.no_slip[nb] : 0;
         const int open = (a.active[nb] == 1.0f) || ((loc[d] <= dims[d] - 2) && ns);
         const float v = (float)(-flux[2 * d + 1] * .5 + diff);
@@ -136,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void assemble_kernel(AsmArgs a) {
       }
     }
     val[slot[4]] = dv - a.beta;                      // :294
-    a.diag[g] = dv;                                  // :296
+    a.diag[gl] = dv;                                 // :296
   }
 }
 
@@ -151,15 +150,17 @@ void piso_csr_nnz(int nx, int ny, int periodic_x, int periodic_y, int* nnz_u, in
   if (nnz_v) *nnz_v = 5 * nx * (ny + 1) - 2 * (ny + 1) * (1 - px) - 2 * nx * (1 - py);
 }
 
-int piso_assemble_csr(const float* vel_pad, float* csr_val, int* csr_col, int* csr_rowptr, float* diag,
-                      const uint8_t* dirichlet, const float* active, const float* viscosity, int viscosity_is_field,
-                      int nx, int ny, int periodic_x, int periodic_y, float cell_area_x, float cell_area_y,
-                      float spacing_x, float spacing_y, const uint8_t* no_slip, float beta, piso_stream_t stream) {
+static int assemble_impl(const float* vel_pad, float* csr_val, int* csr_col, int* csr_rowptr, float* diag,
+                         const uint8_t* dirichlet, const float* active, const float* viscosity, int viscosity_is_field,
+                         int nx, int ny, int periodic_x, int periodic_y, float cell_area_x, float cell_area_y,
+                         float spacing_x, float spacing_y, const uint8_t* no_slip, float beta, piso_stream_t stream,
+                         const piso_slab_t* slab, int pattern_only) {
   using namespace piso;
-  if (nx < 3 || ny < 3 || !vel_pad || !csr_val || !csr_col || !csr_rowptr || !diag || !dirichlet || !active || !viscosity) {
+  if (nx < 3 || ny < 3 || !csr_col || !csr_rowptr || (!pattern_only && (!vel_pad || !csr_val || !diag || !dirichlet || !active || !viscosity))) {
     set_error_msg("piso_assemble_csr: invalid argument (need nx, ny >= 3 and non-NULL arrays)");
     return PISO_ERR_INVALID_ARG;
   }
+  if (!slab_ok(slab, ny) || (pattern_only && !slab)) { set_error_msg("piso_assemble_csr_slab: invalid slab"); return PISO_ERR_INVALID_ARG; }
   AsmArgs a;
   a.vel_pad = vel_pad; a.val = csr_val; a.col = csr_col; a.rowptr = csr_rowptr; a.diag = diag;
   a.dirichlet = dirichlet; a.active = active; a.viscosity = viscosity; a.no_slip = no_slip;
@@ -169,10 +170,53 @@ int piso_assemble_csr(const float* vel_pad, float* csr_val, int* csr_col, int* c
   a.n_u = (nx + 1) * ny; a.n_v = nx * (ny + 1);
   int nnz_v;
   piso_csr_nnz(nx, ny, a.per_x, a.per_y, &a.nnz_u, &nnz_v);
-  a.fw = face_window(nx, ny);
+  a.M = make_row_map(slab, nx, ny, a.per_x, a.per_y);
+  a.nnz_u_l = a.M.nnz_l[0];
+  a.pattern_only = pattern_only ? 1 : 0;
+  a.fw = face_window(a.M);
+  if (pattern_only) {
+    // every STORED face row, walked in two or four whole-grid intervals (the ring's seam cuts an interval in two); the launch is
+    // a set-up step: one launch per interval pair keeps the kernel's window a FaceWin
+    const RowMap& M = a.M;
+    const int Wu = nx + 1, Wv = nx, Hu = ny, Hv = ny + 1;
+    const int u_first = M.cb, u_n1 = (M.cb + M.cr <= Hu) ? M.cr : Hu - M.cb, u_n2 = M.cr - u_n1;
+    const int v_first = M.vb, v_n1 = (M.vb + M.vr <= Hv) ? M.vr : Hv - M.vb, v_n2 = M.vr - v_n1;
+    const FaceWin w1{u_first * Wu, u_n1 * Wu, a.n_u + v_first * Wv, v_n1 * Wv}, w2{0, u_n2 * Wu, a.n_u, v_n2 * Wv};
+    for (const FaceWin& w : {w1, w2}) {
+      if (w.count() == 0) continue;
+      a.fw = w;
+      assemble_kernel<<<grid_for((long long)w.count(), kBlock, 8192), kBlock, 0, static_cast<hipStream_t>(stream)>>>(a);
+    }
+    PISO_LAUNCH_CHECK();
+    return PISO_OK;
+  }
   const int g = grid_for((long long)a.fw.count(), kBlock, 8192);
   assemble_kernel<<<g, kBlock, 0, static_cast<hipStream_t>(stream)>>>(a);
   PISO_LAUNCH_CHECK();
+  return PISO_OK;
+}
+
+int piso_assemble_csr(const float* vel_pad, float* csr_val, int* csr_col, int* csr_rowptr, float* diag,
+                      const uint8_t* dirichlet, const float* active, const float* viscosity, int viscosity_is_field,
+                      int nx, int ny, int periodic_x, int periodic_y, float cell_area_x, float cell_area_y,
+                      float spacing_x, float spacing_y, const uint8_t* no_slip, float beta, piso_stream_t stream) {
+  return assemble_impl(vel_pad, csr_val, csr_col, csr_rowptr, diag, dirichlet, active, viscosity, viscosity_is_field, nx, ny, periodic_x,
+                       periodic_y, cell_area_x, cell_area_y, spacing_x, spacing_y, no_slip, beta, stream, nullptr, 0);
+}
+int piso_assemble_csr_slab(const float* vel_pad, float* csr_val, int* csr_col, int* csr_rowptr, float* diag,
+                           const uint8_t* dirichlet, const float* active, const float* viscosity, int viscosity_is_field,
+                           int nx, int ny, int periodic_x, int periodic_y, float cell_area_x, float cell_area_y,
+                           float spacing_x, float spacing_y, const uint8_t* no_slip, float beta, piso_stream_t stream,
+                           const piso_slab_t* slab, int pattern_only) {
+  return assemble_impl(vel_pad, csr_val, csr_col, csr_rowptr, diag, dirichlet, active, viscosity, viscosity_is_field, nx, ny, periodic_x,
+                       periodic_y, cell_area_x, cell_area_y, spacing_x, spacing_y, no_slip, beta, stream, slab, pattern_only);
+}
+int piso_slab_sizes(const piso_slab_t* slab, int nx, int ny, int periodic_x, int periodic_y, int* out8) {
+  using namespace piso;
+  if (!out8 || nx < 3 || ny < 3 || !slab_ok(slab, ny)) { set_error_msg("piso_slab_sizes: invalid argument"); return PISO_ERR_INVALID_ARG; }
+  const RowMap M = make_row_map(slab, nx, ny, periodic_x ? 1 : 0, periodic_y ? 1 : 0);
+  out8[0] = M.cr; out8[1] = M.vr; out8[2] = M.n_u; out8[3] = M.n_v; out8[4] = M.nnz_l[0]; out8[5] = M.nnz_l[1]; out8[6] = M.mr;
+  out8[7] = M.pur * (nx + 3) + M.pvr * (nx + 2);
   return PISO_OK;
 }
 }

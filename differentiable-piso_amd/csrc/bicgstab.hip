@@ -84,6 +84,12 @@ struct BiArgs {
   // All arrays stay globally indexed; rows outside the range are never written (the SpMV inputs receive their neighbours' edge
   // rows before every product), so slabs cut at band edges reproduce the single-GPU preconditioner exactly.
   int rb[2], re[2], bb[2], be[2];
+  // where row `row` (component-local, whole-grid numbering) of component c lives in the concatenated vectors and coefficient arrays:
+  // r0[c] + row when the arrays are the whole grid's (one GPU; slab solver on full arrays), the rank's stored rows otherwise
+  // (slab-decomposed step, local storage: piso_common.h RowMap)
+  RowMap M;
+  __device__ __forceinline__ int kx(int c, int row) const { return M.on ? (c ? M.n_u : 0) + M.frow(c, row) : g.r0[c] + row; }
+  __device__ __forceinline__ int rpx(int c, int row) const { return M.frow(c, row); }      // place of a row in the component's row pointers
 };
 // cross-rank part of a scalar kernel (peer transport): the two component blocks add their four partial sums over the ranks
 struct BiPeer {
@@ -103,8 +109,9 @@ __device__ __forceinline__ bool is_nan(double v) { return v != v; }
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ bool csr_find(const int* __restrict__ rp, const int* __restrict__ col,
-                                         const T* __restrict__ val, int m, int k, T* out) {
-  for (int q = rp[m]; q < rp[m + 1]; ++q)
+                                         const T* __restrict__ val, int m, int k, T* out, const RowMap& M, int c) {
+  const int ml = M.frow(c, m);                               // (row pointers follow the STORED rows; columns keep the whole grid's numbers)
+  for (int q = rp[ml]; q < rp[ml + 1]; ++q)
     if (col[q] == k) { *out = val[q]; return true; }
   return false;
 }
@@ -115,10 +122,12 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
                                                      const T* __restrict__ x0, int transpose) {
   const int c = blockIdx.y;
   const Geo& g = a.g;
-  const int W = g.W[c], H = g.H[c], n = g.n[c], r0 = g.r0[c];
-  const int* rp = rp_all + (c ? g.n[0] + 1 : 0);
+  const int W = g.W[c], H = g.H[c], n = g.n[c];
+  const RowMap& M = a.M;
+  const int nu_st = M.on ? M.n_u : g.n[0];                   // u rows the row pointers hold
+  const int* rp = rp_all + (c ? nu_st + 1 : 0);
   // the nnz offset of component 1 is the last row pointer of component 0
-  const int k0 = c ? rp_all[g.n[0]] : 0;
+  const int k0 = c ? rp_all[nu_st] : 0;
   const T* val = val_all + k0;
   const int* col = col_all + k0;
   bool nan_seen = false, bad = false;
@@ -130,7 +139,8 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
     int ec[kExcSlots];
     T ev[kExcSlots];
     // classify the entries of A's own row (also validates the pattern in transpose mode)
-    for (int q = rp[row]; q < rp[row + 1]; ++q) {
+    const int rl = a.rpx(c, row);
+    for (int q = rp[rl]; q < rp[rl + 1]; ++q) {
       const int cq = col[q];
       const T vq = val[q];
       nan_seen |= is_nan(vq);
@@ -155,23 +165,23 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
     }
     if (transpose) {
       T vq;
-      if (i >= 1 && csr_find(rp, col, val, row - 1, row, &vq)) w = vq;            // A(k-1, k)
-      if (i <= W - 2 && csr_find(rp, col, val, row + 1, row, &vq)) e = vq;        // A(k+1, k)
-      if (j >= 1 && csr_find(rp, col, val, row - W, row, &vq)) s = vq;            // A(k-W, k)
-      if (j <= H - 2 && csr_find(rp, col, val, row + W, row, &vq)) nn = vq;       // A(k+W, k)
+      if (i >= 1 && csr_find(rp, col, val, row - 1, row, &vq, M, c)) w = vq;            // A(k-1, k)
+      if (i <= W - 2 && csr_find(rp, col, val, row + 1, row, &vq, M, c)) e = vq;        // A(k+1, k)
+      if (j >= 1 && csr_find(rp, col, val, row - W, row, &vq, M, c)) s = vq;            // A(k-W, k)
+      if (j <= H - 2 && csr_find(rp, col, val, row + W, row, &vq, M, c)) nn = vq;       // A(k+W, k)
       if (fo >= 0) {
         const int cand[4] = {row - g.xw[c], row + g.xw[c], row - g.yw[c], row + g.yw[c]};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int m = cand[q];
           if (m < 0 || m >= n || m == row - 1 || m == row + 1 || m == row - W || m == row + W || m == row) continue;
-          if (csr_find(rp, col, val, m, row, &vq)) {
+          if (csr_find(rp, col, val, m, row, &vq, M, c)) {
             if (ne < kExcSlots) { ec[ne] = m; ev[ne] = vq; ++ne; } else bad = true;
           }
         }
       }
     }
-    const int k = r0 + row;
+    const int k = a.kx(c, row);
     a.cS[k] = s; a.cW[k] = w; a.cC[k] = cc; a.cE[k] = e; a.cN[k] = nn;
     if (fo >= 0) {
       const int base = (g.f0[c] + fo) * kExcSlots;
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void bi_factor(BiArgs<T> a) {
   const Geo& g = a.g;
   const int band = a.bb[c] + blockIdx.x;
   if (band >= a.be[c]) return;
-  const int W = g.W[c], H = g.H[c], r0 = g.r0[c];
+  const int W = g.W[c], H = g.H[c];
   const int j0 = band * g.R, j1 = min(j0 + g.R, H);
   const int i0 = threadIdx.x * E;
   T d_prev_row[E];          // pivots of the previous row at my columns
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void bi_factor(BiArgs<T> a) {
 #pragma unroll
   for (int e = 0; e < E; ++e) { d_prev_row[e] = 1; cN_prev_row[e] = 0; }
   for (int j = j0; j < j1; ++j) {
-    const int kb = r0 + j * W;
+    const int kb = a.kx(c, j * W);
     T A[E], B[E], cw[E], cs[E], ce[E], cn[E];
     Moebius<T> f = Moebius<T>::identity();
 #pragma unroll
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
   if (folded_scalars(a, c, smem_fold).done) return;         // (folded, forward sweep of s: the ||s|| test)
   const int band = a.bb[c] + blockIdx.x;
   if (band >= a.be[c]) return;
-  const int W = g.W[c], H = g.H[c], r0 = g.r0[c];
+  const int W = g.W[c], H = g.H[c];
   const int j0 = band * g.R, j1 = min(j0 + g.R, H);
   const T* __restrict__ ca = FWD ? a.LW : a.UE;
   const T* __restrict__ cb = FWD ? a.LS : a.UN;
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
   T nv[E], na[E], nb[E];
   auto load_row = [&](int jj) __attribute__((always_inline)) {
     const int j = FWD ? j0 + jj : j1 - 1 - jj;
-    const int kb = r0 + j * W;
+    const int kb = a.kx(c, j * W);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int s = i0 + e;
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
   load_row(0);
   for (int jj = 0; jj < j1 - j0; ++jj) {
     const int j = FWD ? j0 + jj : j1 - 1 - jj;
-    const int kb = r0 + j * W;
+    const int kb = a.kx(c, j * W);
     T m[E], cst[E];
     Affine<T> f = Affine<T>::identity();
 #pragma unroll
@@ -391,8 +401,8 @@ __device__ __forceinline__ void store_partials(BiArgs<T>& a, int c, T* vals, int
 template <typename T>
 __device__ __forceinline__ T stencil_row(const BiArgs<T>& a, int c, int row, const T* __restrict__ x) {
   const Geo& g = a.g;
-  const int W = g.W[c], H = g.H[c], r0 = g.r0[c];
-  const int i = row % W, j = row / W, k = r0 + row;
+  const int W = g.W[c], H = g.H[c];
+  const int i = row % W, j = row / W, k = a.kx(c, row);
   T acc = 0;
   if (j >= 1) acc = fma(a.cS[k], x[k - W], acc);
   if (i >= 1) acc = fma(a.cW[k], x[k - 1], acc);
@@ -405,7 +415,7 @@ __device__ __forceinline__ T stencil_row(const BiArgs<T>& a, int c, int row, con
 #pragma unroll
     for (int q = 0; q < kExcSlots; ++q) {
       const int ec = a.ecol[base + q];
-      if (ec >= 0) acc = fma(a.eval[base + q], x[r0 + ec], acc);
+      if (ec >= 0) acc = fma(a.eval[base + q], x[a.kx(c, ec)], acc);
     }
   }
   return acc;
@@ -493,10 +503,9 @@ __global__ __launch_bounds__(kBlock) void bi_residual_init(BiArgs<T> a) {
   __shared__ T smem[16];
   const int c = blockIdx.y;
   if (a.sc[c].done) return;
-  const int r0 = a.g.r0[c];
   T acc[1] = {0};
   for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
-    const int k = r0 + row;
+    const int k = a.kx(c, row);
     const T r = a.rhs[k] - stencil_row(a, c, row, a.x);
     a.r[k] = r; a.rh[k] = r; a.p[k] = 0; a.v[k] = 0;
     acc[0] = fma(r, r, acc[0]);
@@ -511,9 +520,8 @@ __global__ __launch_bounds__(kBlock) void bi_update_p(BiArgs<T> a) {
   const int c = blockIdx.y;
   const CompScalars<T> s = folded_scalars(a, c, smem);      // (folded: ||r|| test of the iteration before, then rho / beta)
   if (s.done) return;
-  const int r0 = a.g.r0[c];
   for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
-    const int k = r0 + row;
+    const int k = a.kx(c, row);
     a.p[k] = (a.p[k] - s.omega * a.v[k]) * s.beta + a.r[k];
   }
 }
@@ -528,14 +536,14 @@ __global__ __launch_bounds__(kBlock) void bi_spmv(BiArgs<T> a, const T* __restri
   __shared__ T smem[16];
   const int c = blockIdx.y;
   if (a.sc[c].done) return;
-  const int r0 = a.g.r0[c], W = a.g.W[c];
+  const int W = a.g.W[c];
   const int eb = kEdgeRows * W;                             // elements of one edge
   const int begin = part == 1 ? a.rb[c] + eb : (part == 2 ? 0 : a.rb[c]);
   const int end = part == 1 ? a.re[c] - eb : (part == 2 ? 2 * eb : a.re[c]);
   T acc[2] = {0, 0};
   for (int idx = begin + blockIdx.x * kBlock + threadIdx.x; idx < end; idx += gridDim.x * kBlock) {
     const int row = part == 2 ? (idx < eb ? a.rb[c] + idx : a.re[c] - 2 * eb + idx) : idx;
-    const int k = r0 + row;
+    const int k = a.kx(c, row);
     const T o = stencil_row(a, c, row, in);
     out[k] = o;
     if (WHICH == 0) acc[0] = fma(a.rh[k], o, acc[0]);
@@ -551,13 +559,12 @@ __global__ __launch_bounds__(kBlock) void bi_update_xr(BiArgs<T> a) {
   const int c = blockIdx.y;
   const CompScalars<T> s = folded_scalars(a, c, smem);      // (folded: alpha / omega from the product's sums)
   if (s.done) return;
-  const int r0 = a.g.r0[c];
   const T coef = WHICH == 0 ? s.alpha : s.omega;
   const T* __restrict__ dir = WHICH == 0 ? a.ph : a.sh;
   const T* __restrict__ w = WHICH == 0 ? a.v : a.t;
   T acc[2] = {0, 0};
   for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
-    const int k = r0 + row;
+    const int k = a.kx(c, row);
     a.x[k] = a.x[k] + coef * dir[k];
     const T r = a.r[k] - coef * w[k];
     a.r[k] = r;
@@ -571,8 +578,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void bi_zero_x(BiArgs<T> a, int comp_mask) {
   const int c = blockIdx.y;
   if (!((comp_mask >> c) & 1)) return;
-  const int r0 = a.g.r0[c];
-  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) a.x[r0 + row] = 0;
+  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) a.x[a.kx(c, row)] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -670,9 +676,10 @@ static Geo make_geo(int nx, int ny, int band_rows) {
 }
 
 template <typename T>
-static size_t bi_workspace_bytes(int nx, int ny) {
+static size_t bi_workspace_bytes(int nx, int ny, const piso_slab_t* slab = nullptr) {
   const Geo g = make_geo(nx, ny, 8);
-  const size_t ntot = (size_t)g.n[0] + g.n[1];
+  size_t ntot = (size_t)g.n[0] + g.n[1];
+  if (slab) { const RowMap M = make_row_map(slab, nx, ny); ntot = (size_t)M.n_u + M.n_v; }      // (local storage: the rank's stored rows)
   size_t b = 0;
   b += 18 * align_up(ntot * sizeof(T), 256);
   b += align_up((size_t)(g.F[0] + g.F[1]) * kExcSlots * sizeof(int), 256);
@@ -704,25 +711,28 @@ static void launch_sweeps(const BiArgs<T>& aL, const BiArgs<T>& aU, dim3 gb, con
   bi_sweep<T, E, false><<<gb, kBlock, 0, s>>>(aU, aU.y, out);
 }
 
-// pc = NULL: one GPU.  Else (peer transport): this rank works on the face rows of its y-slab of cell rows; val / rowptr / col /
-// rhs / x0 are the FULL arrays on every rank (the caller's assembly is replicated), x_out is valid on the owned rows only.
+// pc = NULL: one GPU.  Else: this rank works on the face rows of its y-slab of cell rows.  slab = NULL: val / rowptr / col / rhs / x0
+// are the FULL arrays on every rank (a replicated assembly), x_out is valid on the owned rows only.  slab != NULL (the slab-decomposed
+// step, round 5): every array - the caller's and the workspace - holds the rank's STORED rows (piso_slab_t), 1 / ranks of the grid.
 template <typename T>
 static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rhs, const T* x0, T* x_out, int nx,
                     int ny, float tol, int max_it, int transpose, int band_rows, uint8_t* warning,
-                    int* iterations_out, void* ws, size_t ws_bytes, piso_stream_t stream_, PisoComm* pc = nullptr) {
-  if (nx < 4 || ny < 4 || !val || !rowptr || !col || !rhs || !x0 || !x_out || !ws || max_it < 0) {
+                    int* iterations_out, void* ws, size_t ws_bytes, piso_stream_t stream_, PisoComm* pc = nullptr,
+                    const piso_slab_t* slab_rows = nullptr, int per_x = 0, int per_y = 0) {
+  if (nx < 4 || ny < 4 || !val || !rowptr || !col || !rhs || !x0 || !x_out || !ws || max_it < 0 || !slab_ok(slab_rows, ny) || (slab_rows && !pc)) {
     set_error_msg("piso_multi_bicgstab_ilu: invalid argument (need nx, ny >= 4 and non-NULL arrays)");
     return PISO_ERR_INVALID_ARG;
   }
-  if (ws_bytes < bi_workspace_bytes<T>(nx, ny)) {
+  if (ws_bytes < bi_workspace_bytes<T>(nx, ny, slab_rows)) {
     set_error_msg("piso_multi_bicgstab_ilu: workspace too small");
     return PISO_ERR_INVALID_ARG;
   }
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   BiArgs<T> a;
   a.g = make_geo(nx, ny, band_rows);
+  a.M = make_row_map(slab_rows, nx, ny, per_x, per_y);
   const Geo& g = a.g;
-  const size_t ntot = (size_t)g.n[0] + g.n[1];
+  const size_t ntot = slab_rows ? (size_t)a.M.n_u + a.M.n_v : (size_t)g.n[0] + g.n[1];
   Arena ar(ws, ws_bytes);
   a.cS = ar.take<T>(ntot); a.cW = ar.take<T>(ntot); a.cC = ar.take<T>(ntot); a.cE = ar.take<T>(ntot); a.cN = ar.take<T>(ntot);
   a.dinv = ar.take<T>(ntot); a.LW = ar.take<T>(ntot); a.LS = ar.take<T>(ntot); a.UE = ar.take<T>(ntot); a.UN = ar.take<T>(ntot);
@@ -755,6 +765,10 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
     if (!rccl && (size_t)(3 * nx + 1) > pc->row_cap) { set_error_msg("piso_multi_bicgstab_ilu_slab: communicator row_capacity < 3 nx + 1"); return PISO_ERR_INVALID_ARG; }
     const int nyl = ny / world, jb = rank * nyl, jt = jb + nyl - 1;
     const bool last = rank == world - 1;
+    if (slab_rows && (slab_rows->row_begin != jb || slab_rows->row_end != jb + nyl || (slab_rows->owns_last_face_row != 0) != last)) {
+      set_error_msg("piso_multi_bicgstab_ilu_slab: the slab does not match the communicator's rank");
+      return PISO_ERR_INVALID_ARG;
+    }
     a.rb[0] = jb * g.W[0]; a.re[0] = (jb + nyl) * g.W[0];
     a.rb[1] = jb * g.W[1]; a.re[1] = (jb + nyl + (last ? 1 : 0)) * g.W[1];      // (the duplicate face row v[ny] lives on the last slab)
     a.bb[0] = a.bb[1] = jb / g.R;
@@ -769,10 +783,13 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
     // reads v[ny] and v[ny - 1] that reads v[0].
     const int lo = bp.pv.lower, up = bp.pv.upper;
     const int jt_lo = lo * nyl + nyl - 1, jb_up = up * nyl;
-    to_lower = {2, {jb * g.W[0], g.n[0] + jb * g.W[1], 0}, {g.W[0], 2 * g.W[1], 0}};
-    to_upper = {2, {jt * g.W[0], g.n[0] + jt * g.W[1], 0}, {g.W[0], (last ? 2 : 1) * g.W[1], 0}};
-    from_lower = {2, {jt_lo * g.W[0], g.n[0] + jt_lo * g.W[1], 0}, {g.W[0], (lo == world - 1 ? 2 : 1) * g.W[1], 0}};
-    from_upper = {2, {jb_up * g.W[0], g.n[0] + jb_up * g.W[1], 0}, {g.W[0], 2 * g.W[1], 0}};
+    // (where a row starts in the concatenated vectors: the whole grid's offsets, or the stored rows' - rows that follow each other
+    // around the ring - v[ny - 1], v[ny], v[0], v[1] - are neighbours in the stored arrays as well)
+    auto at = [&](int c, int j) -> int { return a.M.on ? (c ? a.M.n_u : 0) + a.M.frow(c, j * g.W[c]) : g.r0[c] + j * g.W[c]; };
+    to_lower = {2, {at(0, jb), at(1, jb), 0}, {g.W[0], 2 * g.W[1], 0}};
+    to_upper = {2, {at(0, jt), at(1, jt), 0}, {g.W[0], (last ? 2 : 1) * g.W[1], 0}};
+    from_lower = {2, {at(0, jt_lo), at(1, jt_lo), 0}, {g.W[0], (lo == world - 1 ? 2 : 1) * g.W[1], 0}};
+    from_upper = {2, {at(0, jb_up), at(1, jb_up), 0}, {g.W[0], 2 * g.W[1], 0}};
   }
   auto next_seq = [&]() -> BiPeer { BiPeer b = bp; if (slab) b.seq = ++pc->seq_ar; return b; };
   const HaloMsg msgs[4] = {to_upper, to_lower, from_lower, from_upper};
@@ -986,18 +1003,21 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
 // y = A x or A^T x on the concatenated CSR (second-corrector H product and its adjoint)
 __global__ __launch_bounds__(kBlock) void csr_matvec_kernel(const float* __restrict__ val_all, const int* __restrict__ rp_all,
                                                             const int* __restrict__ col_all, const float* __restrict__ x,
-                                                            float* __restrict__ y, Geo g, int transpose, int lo0, int hi0, int lo1, int hi1) {
+                                                            float* __restrict__ y, Geo g, int transpose, int lo0, int hi0, int lo1, int hi1, RowMap M) {
   const int c = blockIdx.y;
-  const int n = g.n[c], r0 = g.r0[c], W = g.W[c];
+  const int n = g.n[c], W = g.W[c];
   const int row_lo = c ? lo1 : lo0, row_hi = c ? hi1 : hi0;     // (slab-decomposed step: this rank's face rows)
-  const int* rp = rp_all + (c ? g.n[0] + 1 : 0);
-  const int k0 = c ? rp_all[g.n[0]] : 0;
+  const int nu_st = M.on ? M.n_u : g.n[0];
+  const int* rp = rp_all + (c ? nu_st + 1 : 0);
+  const int k0 = c ? rp_all[nu_st] : 0;
   const float* val = val_all + k0;
   const int* col = col_all + k0;
+  auto kx = [&](int row) { return M.on ? (c ? M.n_u : 0) + M.frow(c, row) : g.r0[c] + row; };
   for (int row = row_lo + blockIdx.x * kBlock + threadIdx.x; row < row_hi; row += gridDim.x * kBlock) {
     float acc = 0.f;
     if (!transpose) {
-      for (int q = rp[row]; q < rp[row + 1]; ++q) acc = fmaf(val[q], x[r0 + col[q]], acc);
+      const int rl = M.frow(c, row);
+      for (int q = rp[rl]; q < rp[rl + 1]; ++q) acc = fmaf(val[q], x[kx(col[q])], acc);
     } else {
       // gather over every row that can hold an entry in column `row` (ascending row order = csr2csc order)
       const int cand[9] = {row - g.yw[c], row - W, row - g.xw[c], row - 1, row, row + 1, row + g.xw[c], row + W, row + g.yw[c]};
@@ -1008,10 +1028,10 @@ __global__ __launch_bounds__(kBlock) void csr_matvec_kernel(const float* __restr
         if (m < 0 || m >= n || m <= last) continue;
         last = m;
         float v;
-        if (csr_find<float>(rp, col, val, m, row, &v)) acc = fmaf(v, x[r0 + m], acc);
+        if (csr_find<float>(rp, col, val, m, row, &v, M, c)) acc = fmaf(v, x[kx(m)], acc);
       }
     }
-    y[r0 + row] = acc;
+    y[kx(row)] = acc;
   }
 }
 
@@ -1059,22 +1079,52 @@ int piso_multi_bicgstab_ilu_slab_f64(void* comm, const double* csr_val, const in
                           workspace, workspace_bytes, stream, static_cast<PisoComm*>(comm));
 }
 
-int piso_csr_matvec_f32(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* x, float* y,
-                        int nx, int ny, int transpose, piso_stream_t stream) {
-  if (nx < 4 || ny < 4 || !csr_val || !csr_rowptr || !csr_col || !x || !y) {
+size_t piso_bicgstab_slab_workspace_bytes(int nx, int ny, int elem_size, const piso_slab_t* slab) {
+  if (!slab_ok(slab, ny)) return 0;
+  return elem_size == 8 ? bi_workspace_bytes<double>(nx, ny, slab) : bi_workspace_bytes<float>(nx, ny, slab);
+}
+int piso_multi_bicgstab_ilu_slab_local_f32(void* comm, const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* rhs,
+                                           const float* x0, float* x_out, int nx, int ny, int periodic_x, int periodic_y, float tol, int max_it,
+                                           int transpose, int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
+                                           size_t workspace_bytes, piso_stream_t stream, const piso_slab_t* slab) {
+  if (!comm || !slab) { set_error_msg("piso_multi_bicgstab_ilu_slab_local_f32: NULL communicator / slab"); return PISO_ERR_INVALID_ARG; }
+  return bi_solve<float>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning, iterations_out,
+                         workspace, workspace_bytes, stream, static_cast<PisoComm*>(comm), slab, periodic_x ? 1 : 0, periodic_y ? 1 : 0);
+}
+int piso_multi_bicgstab_ilu_slab_local_f64(void* comm, const double* csr_val, const int* csr_rowptr, const int* csr_col, const double* rhs,
+                                           const double* x0, double* x_out, int nx, int ny, int periodic_x, int periodic_y, float tol, int max_it,
+                                           int transpose, int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
+                                           size_t workspace_bytes, piso_stream_t stream, const piso_slab_t* slab) {
+  if (!comm || !slab) { set_error_msg("piso_multi_bicgstab_ilu_slab_local_f64: NULL communicator / slab"); return PISO_ERR_INVALID_ARG; }
+  return bi_solve<double>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning, iterations_out,
+                          workspace, workspace_bytes, stream, static_cast<PisoComm*>(comm), slab, periodic_x ? 1 : 0, periodic_y ? 1 : 0);
+}
+
+static int csr_matvec_impl(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* x, float* y,
+                           int nx, int ny, int periodic_x, int periodic_y, int transpose, piso_stream_t stream, const piso_slab_t* slab) {
+  if (nx < 4 || ny < 4 || !csr_val || !csr_rowptr || !csr_col || !x || !y || !slab_ok(slab, ny)) {
     set_error_msg("piso_csr_matvec_f32: invalid argument");
     return PISO_ERR_INVALID_ARG;
   }
   const Geo g = make_geo(nx, ny, 8);
-  const FaceWin fw = face_window(nx, ny);                  // component-local row ranges (whole components on one GPU)
+  const RowMap M = make_row_map(slab, nx, ny, periodic_x ? 1 : 0, periodic_y ? 1 : 0);
+  const FaceWin fw = face_window(M);                       // component-local row ranges (whole components on one GPU)
   const int lo0 = fw.u_lo, hi0 = fw.u_lo + fw.cu, lo1 = fw.v_lo - g.n[0], hi1 = lo1 + fw.cv;
   const int nmax = fw.cu > fw.cv ? fw.cu : fw.cv;
   int gv = (nmax + kBlock * 2 - 1) / (kBlock * 2);
   if (gv > 4096) gv = 4096;
   if (gv < 1) gv = 1;
   csr_matvec_kernel<<<dim3(gv, 2), kBlock, 0, static_cast<hipStream_t>(stream)>>>(csr_val, csr_rowptr, csr_col, x, y, g,
-                                                                                  transpose ? 1 : 0, lo0, hi0, lo1, hi1);
+                                                                                  transpose ? 1 : 0, lo0, hi0, lo1, hi1, M);
   PISO_LAUNCH_CHECK();
   return PISO_OK;
+}
+int piso_csr_matvec_f32(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* x, float* y,
+                        int nx, int ny, int transpose, piso_stream_t stream) {
+  return csr_matvec_impl(csr_val, csr_rowptr, csr_col, x, y, nx, ny, 0, 0, transpose, stream, nullptr);
+}
+int piso_csr_matvec_f32_slab(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* x, float* y,
+                             int nx, int ny, int periodic_x, int periodic_y, int transpose, piso_stream_t stream, const piso_slab_t* slab) {
+  return csr_matvec_impl(csr_val, csr_rowptr, csr_col, x, y, nx, ny, periodic_x, periodic_y, transpose, stream, slab);
 }
 }

@@ -597,15 +597,6 @@ static int cg_solve(int nx, int ny, int per_x, int per_y, const T* L, const T* b
   rc = cg_run<T, CT, V, RECON>(a, persist_ws, symmetric, accuracy, max_iterations, rank_deficient, reset, fixed, iterations_out, kernel_ms_out, stream)
   if (!hflags[0]) {                                         // (fp32 state: trivially exact - the same path, so that the diagonal can be rebuilt there too)
     a.oS = oF; a.oW = oF + n; a.oE = oF + 2 * n; a.oN = oF + 3 * n;
-#ifdef PISO_EXP_SKEW      // experiment: the W array at another offset from the S array than a power of two (channel / bank conflicts?)
-    {
-      static float* skew = nullptr;
-      static size_t skew_n = 0;
-      if (skew_n < n) { if (skew) (void)hipFree(skew); PISO_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&skew), (n + (1u << 20)) * sizeof(float))); skew_n = n; }
-      PISO_HIP_CHECK(hipMemcpyAsync(skew + PISO_EXP_SKEW, oF + n, n * sizeof(float), hipMemcpyDeviceToDevice, stream));
-      a.oW = skew + PISO_EXP_SKEW;
-    }
-#endif
     if (!hflags[1]) { if (vec) PISO_CG_RUN(float, VMID, true); else PISO_CG_RUN(float, 1, true); }
     else if (vec) PISO_CG_RUN(float, VMID, false);
     else PISO_CG_RUN(float, 1, false);

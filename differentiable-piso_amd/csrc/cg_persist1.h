@@ -43,8 +43,9 @@ namespace piso {
 //     ALSO into that neighbour's mailbox (peer-mapped memory, system-scope stores over xGMI) and read the neighbour's row from
 //     their own mailbox; r, p[] and x carry one halo row below (row -1) and above (row ny) as in the two-kernel slab path - the
 //     ring copies start from them and are written back to them when the segment ends;
-//   * the exchange has a second level: workgroup 0 publishes the GPU's totals to every peer's mailbox, every workgroup adds the
-//     GPUs' records in rank order (bitwise the same totals on every GPU, so every GPU takes the same decisions);
+//   * the exchange's second level crosses the node: the XCD leaders store their records into every rank's mailbox, wave w of every
+//     workgroup adds rank w's records, the rank totals meet in LDS (bitwise the same totals on every GPU, so every GPU takes the
+//     same decisions; grid_exchange8_hier<..., XG>);
 //   * N of the slab's last row comes from the N array (its S twin lives on the neighbour), sums of the previous K2 from a.gB.
 struct NoSlab {};
 // region shape of the persistent kernels for an nx x ny grid (V cells per lane, `cus` compute units): one region of 16 rows per
@@ -79,6 +80,7 @@ struct SlabCtl {
   PeerView pv;
   double ncells;           // cells of the GLOBAL grid
   char *rows_own, *rows_lo, *rows_hi;   // the row areas (PeerLayout::kRows) of my mailbox and of the lower / upper neighbour's
+  unsigned hop_ticks;      // measurements only (option slab_hop_ticks): the XCD leaders' records leave this many 10 ns ticks late
 };
 // A kernel argument read AGAIN from the kernarg segment (scalar loads through a pointer the optimiser cannot see through).  The
 // row loops of the persistent kernels are bound by VALU issue and short of scalar registers: whatever only the rare paths need -
@@ -142,9 +144,6 @@ __device__ __forceinline__ F karg(unsigned off) {
 #ifndef PISO_PERSIST1_EXIT_KARGS
 #define PISO_PERSIST1_EXIT_KARGS 1            // the exit block reads its pointers again from the kernarg segment
 #endif
-#ifndef PISO_PERSIST1_PREFETCH_BEHIND_DRAIN
-#define PISO_PERSIST1_PREFETCH_BEHIND_DRAIN 0    // (measured: no gain - the first barrier of the exchange waits for the slowest wave, not for the drain)
-#endif
 #ifndef PISO_PERSIST1_POLL_DELAY
 #define PISO_PERSIST1_POLL_DELAY 24             // s_sleep units (64 cycles) between publishing a record and the first polling pass
 #endif
@@ -163,17 +162,14 @@ __device__ __forceinline__ F karg(unsigned off) {
 #ifndef PISO_PERSIST1_AHEAD
 #define PISO_PERSIST1_AHEAD 2                   // rows of z' = L p that the U pass finds precomputed (see kAhead)
 #endif
+#ifndef PISO_PERSIST1_KEEP_Z
+#define PISO_PERSIST1_KEEP_Z 1                  // small regions: U reuses D's z' instead of computing it again (see kKeepZ)
+#endif
+#ifndef PISO_PERSIST1_KEEP_Z_REGS
+#define PISO_PERSIST1_KEEP_Z_REGS 32            // ... where z' of all rows of a wave fits this many registers
+#endif
 #ifndef PISO_PERSIST1_PACK
 #define PISO_PERSIST1_PACK 1                    // end cells of a region's rows published as one packed block per region (see kPack)
-#endif
-#ifndef PISO_PERSIST1_NT_PUB
-#define PISO_PERSIST1_NT_PUB 0
-#endif
-#ifndef PISO_PERSIST1_NT_HALO
-#define PISO_PERSIST1_NT_HALO 0
-#endif
-#ifndef PISO_PERSIST1_HALO_AT
-#define PISO_PERSIST1_HALO_AT 0                 // 16-row regions: the U row step in front of which the neighbours' z' rows are requested (0: behind the exchange)
 #endif
 #ifndef PISO_PERSIST1_POLL_DELAY2
 #define PISO_PERSIST1_POLL_DELAY2 40            // s_sleep units in front of the first polling pass of the tree's second level (2048^2, behind the rows computed ahead: 24 -> 9.12, 32 / 40 -> 8.94 us per iteration, six processes each on one box)
@@ -421,9 +417,21 @@ __device__ __forceinline__ unsigned hier_enter(const PersistCtl& c, int* lds2) {
   __syncthreads();
   return (unsigned)__builtin_amdgcn_readfirstlane(lds2[0]);
 }
-template <typename T, int DELAY2, typename F = NoPrefetch>
+// XG (slab instance, round 5): the node's level of the exchange rides on the tree's second level instead of following it.  The XCD
+// leaders store their XCD's record straight into EVERY rank's mailbox (system-scope stores over xGMI; the own mailbox included);
+// wave w of every workgroup polls the eight XCD records of RANK w in its own mailbox and adds them in XCD order, the rank totals
+// meet in LDS behind one barrier and every wave adds them by the same butterfly over the rank index - bitwise the same totals in
+// every wave of every GPU.  (Round 4 had a serial level here: workgroup 0 waited for the chip's totals, wrote them to the peers,
+// and wave 0 of every workgroup polled again - one more uncached round trip per iteration.)  All eight records of a rank also
+// certify that every row this rank stored into a peer's mailbox has completed: its workgroups drained their stores before they
+// published, and a leader publishes only after it has seen all workgroups of its XCD.  An XCD that holds no workgroups (small
+// grids) is published with zero sums by the leader of the rank's lowest XCD in play.  sl_off: where the SlabCtl sits in the
+// kernarg segment - mailbox addresses, rank and world are fetched where they are used (karg), not held in SGPRs across the loops.
+constexpr int kX1SmX = 80;                        // LDS words of the node level per parity: [8 ranks][8 sums], 8 flags
+template <typename T, int DELAY2, bool XG = false, typename F = NoPrefetch>
 __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[kX1Values], unsigned epoch, T* smem, unsigned hx, int* flag,
-                                                    F while_records_travel = F(), unsigned long long* tsub = nullptr) {
+                                                    F while_records_travel = F(), unsigned long long* tsub = nullptr, unsigned sl_off = 0,
+                                                    T* smx2 = nullptr) {
   unsigned long long t0 = (kPersistDiag && tsub) ? wall_clock64() : 0;
   auto tsplit = [&](int q) __attribute__((always_inline)) {
     if (kPersistDiag && tsub) { const unsigned long long t = wall_clock64(); tsub[q] += t - t0; t0 = t; }
@@ -443,7 +451,12 @@ __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[
   tsplit(0);
   __syncthreads();
   tsplit(1);
-  const bool good = __builtin_amdgcn_readfirstlane(*flag) == 0;   // (a polling pass of an EARLIER exchange gave up somewhere in this workgroup)
+  // A polling pass of an EARLIER exchange gave up somewhere in this workgroup: the flag is sticky, every wave reads it here behind the
+  // barrier and all of them leave together at the end of this exchange - the wave that gave up included: it returned "healthy" like
+  // its siblings.  (No return from here: an exit in the middle of the iteration loop turns its control flow into exec-mask flow and
+  // the iteration counter into a vector register.  The polling loops below give up at once instead: spin0.)
+  const bool good = __builtin_amdgcn_readfirstlane(*flag) == 0;
+  const unsigned spin0 = good ? 0u : (1u << 30);
   const int xcc = (int)(hx & 7u), rank = (int)((hx >> 3) & 63u), nmine = (int)((hx >> 9) & 63u);
   const unsigned present = (hx >> 15) & 0xffu;
   u64* rec1 = c.rec + (size_t)(epoch & 1) * kPersistMaxGrid * kX1RecWords + (size_t)xcc * 32 * kX1RecWords;
@@ -468,7 +481,7 @@ __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[
       // per-record arrival flags are eight lane masks = sixteen SGPRs the row loops then spill)
       u64 w[8];
       const int lim = nmine * kX1RecWords;                    // words of the XCD's block that belong to records in play
-      unsigned spins = 0;
+      unsigned spins = spin0;
       while (true) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(rec1 + lw + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -490,16 +503,35 @@ __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[
       const double other = dpp_move<0xB1>(acc);              // odd lanes: the even neighbour's sum
       const u64 bits = (u64)__double_as_longlong((lane & 1) ? other : acc);
       const u64 word = (lane & 1) ? ((bits & 0xffffffff00000000ull) | epoch) : (((bits & 0xffffffffull) << 32) | epoch);
-      if (lane < kX1RecWords) __hip_atomic_store(rec2 + (size_t)xcc * kX1RecWords + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if constexpr (!XG) {
+        if (lane < kX1RecWords) __hip_atomic_store(rec2 + (size_t)xcc * kX1RecWords + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        constexpr unsigned pvo = (unsigned)offsetof(SlabCtl, pv);
+        const int world = karg<int>(sl_off + pvo + (unsigned)offsetof(PeerView, world));
+        const int myrank = karg<int>(sl_off + pvo + (unsigned)offsetof(PeerView, rank));
+        // (measurements only - SlabCtl::hop_ticks > 0: the records leave this many 10 ns ticks late, as if the link had that latency)
+        const unsigned hop = karg<unsigned>(sl_off + (unsigned)offsetof(SlabCtl, hop_ticks));
+        if (hop) { const unsigned long long t_go = wall_clock64() + hop; while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(1); }
+        const bool lowest = (present & ((1u << xcc) - 1u)) == 0;     // (scalar) the leader that also speaks for the XCDs without workgroups
+        for (int p = 0; p < world; ++p) {
+          char* mb = karg<char*>(sl_off + pvo + (unsigned)offsetof(PeerView, mbox) + 8u * (unsigned)p);
+          if (lane < kX1RecWords) peer_store(reinterpret_cast<peer_u64*>(mb + PeerLayout::xcd_rec(epoch & 1, myrank, xcc)) + lane, word);
+          if (lowest && present != 0xffu) {
+            for (int x = 0; x < kXcds; ++x)
+              if (!((present >> x) & 1u) && lane < kX1RecWords)
+                peer_store(reinterpret_cast<peer_u64*>(mb + PeerLayout::xcd_rec(epoch & 1, myrank, x)) + lane, (peer_u64)epoch);
+          }
+        }
+      }
     }
   }
   // the records need a microsecond or two to make their way: work that does not depend on the sums goes here (the row loops
   // are bound by VALU issue, and the SIMDs idle while the exchange is in flight)
   while_records_travel();
-  {
+  if constexpr (!XG) {
     // every wave: the eight XCD records (lane l: word l % 16 of record 4 i + l / 16), added in XCD order
     u64 w[2];
-    unsigned spins = 0;
+    unsigned spins = spin0;
     if (DELAY2 > 0) __builtin_amdgcn_s_sleep(DELAY2);
     while (true) {
 #pragma unroll
@@ -524,12 +556,60 @@ __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[
     acc = sum_xor32(acc);                                  // lane 2 q: the total of value q - the same bits in every wave of the chip
 #pragma unroll
     for (int q = 0; q < NV; ++q) v[q] = (T)read_lane_c(acc, 2 * q);
+    if (!mygood) {                                              // (wave-uniform)
+      if (lane == 0) { *flag = 1; *c.err = 1; }
+    }
+    tsplit(3);
+    return good;
+  } else {
+    // wave w: the eight XCD records of rank w in MY mailbox (every XCD slot of a rank in play is published, see above)
+    T* smx = smx2 + (epoch & 1) * kX1SmX;
+    constexpr unsigned pvo = (unsigned)offsetof(SlabCtl, pv);
+    const int world = karg<int>(sl_off + pvo + (unsigned)offsetof(PeerView, world));
+    double acc = 0;
+    if (wave < world) {
+      const char* own = karg<char*>(sl_off + (unsigned)offsetof(SlabCtl, rows_own)) - PeerLayout::kRows;
+      const peer_u64* recs = reinterpret_cast<const peer_u64*>(own + PeerLayout::xcd_rec(epoch & 1, wave, 0));
+      peer_u64 w[2];
+      unsigned spins = spin0;
+      if (DELAY2 > 0) __builtin_amdgcn_s_sleep(DELAY2);
+      while (true) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) w[i] = peer_load(recs + lw + i * 64);
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bad |= (unsigned)(w[i] & 0xffffffffull) ^ epoch;
+        if (__all(bad == 0)) break;
+        if (++spins > kPeerSpinLimit) { mygood = false; break; }      // (kPeerSpinLimit < spin0)
+        __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_SLEEP);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned hi_other = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(w[i] >> 32), 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+        acc += __longlong_as_double((long long)((w[i] >> 32) | ((peer_u64)hi_other << 32)));
+      }
+      acc = sum_xor16(acc);
+      acc = sum_xor32(acc);                                // lane 2 q: rank w's total of value q (XCD order)
+    }
+    tsplit(2);
+    if (lane < 2 * NV && !(lane & 1)) smx[wave * NV + (lane >> 1)] = (T)acc;       // (a wave without a rank: zeros)
+    if (!mygood) {
+      if (lane == 0) { *flag = 1; *c.err = 1; }
+    }
+    __syncthreads();
+    {
+      // one read fetches the 8 x 8 rank totals (lane l: rank l / 8, value l % 8); the butterfly over the rank index leaves every
+      // lane with the node's total of value l % 8 - the same order of additions in every wave of every GPU
+      double t = (double)smx[lane];
+      t += lanes_xor8(t);
+      t = sum_xor16(t);
+      t = sum_xor32(t);
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v[q] = (T)read_lane_c(t, q);
+    }
+    tsplit(3);
+    return good && __builtin_amdgcn_readfirstlane(*flag) == 0;
   }
-  if (!mygood) {                                              // (wave-uniform)
-    if (lane == 0) { *flag = 1; *c.err = 1; }
-  }
-  tsplit(3);
-  return good && mygood;
 }
 
 // ---- XCD-local launches (LOCAL, at most 32 workgroups, all on one XCD): the same idea in one level.  Wave 0 publishes the workgroup's
@@ -558,7 +638,8 @@ __device__ __forceinline__ bool grid_exchange8_local(const PersistCtl& c, T (&v)
   tsplit(0);
   __syncthreads();
   tsplit(1);
-  const bool good = __builtin_amdgcn_readfirstlane(*flag) == 0;
+  const bool good = __builtin_amdgcn_readfirstlane(*flag) == 0;      // (sticky, read behind the barrier: all waves leave together, see grid_exchange8_hier)
+  const unsigned spin0 = good ? 0u : (1u << 30);
   u64* rec = c.rec + (size_t)(epoch & 1) * kPersistMaxGrid * kX1RecWords;
   int lw = lane;
   asm volatile("" : "+v"(lw));
@@ -574,7 +655,7 @@ __device__ __forceinline__ bool grid_exchange8_local(const PersistCtl& c, T (&v)
   {
     u64 w[8];
     const int lim = nslots * kX1RecWords;
-    unsigned spins = 0;
+    unsigned spins = spin0;
     // (one working wave per SIMD - c.waves = 4: the record needs ~0.2 us to arrive and a first pass that misses it queues in front
     // of the one that would find it: 256^2 3.33 -> 3.15 us per iteration with 8 units, 4: 3.21, 12: 3.23; with two working waves per
     // SIMD - 512 x 256 - any delay loses: 3.84 / 3.83 / 3.92 / 4.00 / 4.10 with 0 / 4 / 8 / 12 / 16)
@@ -606,75 +687,7 @@ __device__ __forceinline__ bool grid_exchange8_local(const PersistCtl& c, T (&v)
     if (lane == 0) { *flag = 1; *c.err = 1; }
   }
   tsplit(3);
-  return good && mygood;
-}
-
-// Second level of the exchange (SLAB): the GPU's totals (bitwise the same in all of its workgroups after grid_exchange8) go to
-// every peer's mailbox as one tagged record, written by workgroup 0; wave 0 of EVERY workgroup polls the `world` records of its
-// own mailbox (lane l: word l % 16 of rank l / 16 [+ 4]) and adds them in a fixed order.  A record that carries the tag also says
-// "every perimeter row this GPU stored into a peer's mailbox has completed": the workgroups drained their stores (vmcnt(0))
-// before they published their local records, and workgroup 0 saw all of those before it wrote this one.
-constexpr int kX1SmX = 16;                        // LDS words of the second level: 8 totals, 1 flag
-template <typename T>
-__device__ __forceinline__ bool xgpu_exchange8(unsigned sl_off, T (&v)[kX1Values], unsigned epoch, T* smx2) {
-  // (sl_off: where the SlabCtl sits in the kernarg segment - mailbox addresses, rank and world are fetched here, by wave 0 only,
-  // instead of occupying ~24 SGPRs across the row loops of every wave)
-  T* smx = smx2 + (epoch & 1) * kX1SmX;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  bool good = true;
-  if (wave == 0) {
-    constexpr unsigned pv_off = (unsigned)offsetof(SlabCtl, pv);
-    const int world = karg<int>(sl_off + pv_off + (unsigned)offsetof(PeerView, world));
-    const int rank = karg<int>(sl_off + pv_off + (unsigned)offsetof(PeerView, rank));
-    if (blockIdx.x == 0 && lane < kPeerRecWords) {
-      double mine = 0;
-      int sel = lane >> 1;
-      asm volatile("" : "+v"(sel));                           // (opaque: the eight lane masks are not hoisted out of the iteration loop into SGPRs)
-#pragma unroll
-      for (int q = 0; q < kX1Values; ++q) mine = (sel == q) ? (double)v[q] : mine;
-      const peer_u64 word = peer_tagged(mine, lane & 1, epoch);
-      for (int p = 0; p < world; ++p) {
-        char* mb = karg<char*>(sl_off + pv_off + (unsigned)offsetof(PeerView, mbox) + 8u * (unsigned)p);
-        peer_store(reinterpret_cast<peer_u64*>(mb + PeerLayout::x_rec(epoch & 1, rank)) + lane, word);
-      }
-    }
-    const char* own = karg<char*>(sl_off + (unsigned)offsetof(SlabCtl, rows_own)) - PeerLayout::kRows;
-    const int wd = lane & 15, sub = lane >> 4;
-    peer_u64 w[2] = {0, 0};
-    bool okl[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) okl[i] = (i * 4 + sub) >= world;     // absent ranks count as arrived (payload 0)
-    unsigned spins = 0;
-    while (true) {
-      bool ok = true;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        if (!okl[i]) w[i] = peer_load(reinterpret_cast<const peer_u64*>(own + PeerLayout::x_rec(epoch & 1, i * 4 + sub)) + wd);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (!okl[i]) okl[i] = (unsigned)(w[i] & 0xffffffffull) == epoch;
-        ok = ok && okl[i];
-      }
-      if (__all(ok)) break;
-      if (++spins > kPeerSpinLimit) { good = false; break; }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    double acc = 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const unsigned hi_other = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(w[i] >> 32), 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-      acc += __longlong_as_double((long long)((w[i] >> 32) | ((peer_u64)hi_other << 32)));   // (odd lanes: garbage nobody reads)
-    }
-    acc = sum_xor16(acc);                                 // ranks r, r + 1, r + 2, r + 3 (+ 4) sit in the four rows of lanes
-    acc = sum_xor32(acc);
-    if (lane < 2 * kX1Values && !(lane & 1)) smx[lane >> 1] = (T)acc;
-    if (lane == 0) smx[kX1Values] = good ? (T)0 : (T)1;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < kX1Values; ++q) v[q] = uniform(smx[q]);
-  good = uniform(smx[kX1Values]) == (T)0;
-  return good;       // (smx alternates by epoch parity: the barriers of the next exchange separate these reads from the next writes)
+  return good;
 }
 
 // x-neighbours across the lanes of a wave.  The values beyond the two ends of the strip (`ring`: the left neighbour of row j in
@@ -742,10 +755,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
                                                                std::conditional_t<SLAB, SlabCtl, NoSlab> sl = {}) {
   static_assert(!(SLAB && RAGGED), "a slab is never padded");
   static_assert(!(SLAB && LOCAL), "a slab's neighbours are other GPUs");
-  // cache policy of what other workgroups read inside the launch; PISO_PERSIST1_NT_PUB / _NT_HALO add the non-temporal hint (aux
-  // bit 1): a published row is never read again by its writer and read once by its reader - it need not stay in either L2
-  constexpr int kPub = (LOCAL ? kPlain : kAgent) | (PISO_PERSIST1_NT_PUB != 0 && !LOCAL ? 2 : 0);
-  constexpr int kHalo = kAgent | (PISO_PERSIST1_NT_HALO != 0 && !LOCAL ? 2 : 0);
+  // cache policy of what other workgroups read inside the launch (non-temporal hints on the published rows / the halo loads were
+  // measured and lose: the publish -> read path lives on the caches)
+  constexpr int kPub = LOCAL ? kPlain : kAgent;
+  constexpr int kHalo = kAgent;
   constexpr int V = 16 / sizeof(T);                        // 16-byte lane accesses
   static_assert(R * NQ <= 16 && 2 * R <= 64, "at most 16 rows per wave; the edge columns of a region fit one wave-wide load");
   static_assert(!SLAB || sizeof(T) == 8, "mailbox rows hold 8-byte elements");
@@ -774,9 +787,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: scalar branches, SGPRs
   int wg = blockIdx.x;                                     // XCD-contiguous bands (block b is observed on XCD b % 8)
   if (gridDim.x % kXcds == 0) wg = (blockIdx.x % kXcds) * (gridDim.x / kXcds) + blockIdx.x / kXcds;
-#ifdef PISO_EXP_ROT       // experiment: the bands of regions rotated against the XCDs (does a slow band follow its addresses or its XCD?)
-  wg = (wg + PISO_EXP_ROT) % (int)gridDim.x;
-#endif
   int nslots = (int)gridDim.x;                             // workgroups that take part in the exchanges
   if constexpr (LOCAL) {
     __shared__ int local_rank_s;
@@ -801,13 +811,15 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       local_rank_s = rank;
     }
     __syncthreads();
-    wg = local_rank_s;
+    wg = __builtin_amdgcn_readfirstlane(local_rank_s);     // (wave-uniform BY CONSTRUCTION: an LDS read is a vector value to the compiler - every offset derived
+                                                           //  from it became per-lane arithmetic, and the halo loads' resources were built in waterfall loops)
     if (wg < 0) return;                                    // not in the group that runs the solve
     nslots = c.local_n;
   }
   const int slot = LOCAL ? wg : (int)blockIdx.x;           // my exchange record
   // chip-wide launches: the exchange is a tree over the XCDs (grid_exchange8_hier); where am I in it?
   constexpr bool kHier = !LOCAL && PISO_PERSIST1_HIER != 0;
+  static_assert(!SLAB || kHier, "the node level of the slab instance rides on the tree exchange");
   unsigned hx = 0;
   constexpr bool kLocalAll = LOCAL && PISO_PERSIST1_LOCAL_ALL != 0;     // XCD-local launches: every wave polls the group's records itself
   __shared__ int hier_s[(kHier || kLocalAll) ? 4 : 1];
@@ -901,7 +913,13 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // copies of r (registers) and of the direction (LDS / registers, `edge`) on the ring around my regions
   Vec<T, V> rhb[NQ], rha[NQ], pnb[NQ], pna[NQ];
   T eR[NQ], edge[NQ];
-  bool vb[NQ], va[NQ], vl[NQ], vr[NQ];                      // is there a cell below / above / left / right of region q at all?
+  bool vb[NQ], va[NQ], vl[NQ], vr[NQ];                      // is there a cell below / above / left / right of region q at all? (entry only)
+  unsigned nbits[NQ];                                       // ... the same four as bits of one scalar (the loop's copy)
+  auto nbit = [&](int q, unsigned bit) __attribute__((always_inline)) -> bool {
+    unsigned b = nbits[q];
+    asm volatile("" : "+s"(b));
+    return (b & bit) != 0;
+  };
   {
     const rsrc_t Rr = make_rsrc(a.r, nbytesT), Rx = make_rsrc(a.x, nbytesT), Rp = make_rsrc(a.p[k_begin & 1], nbytesT);
 #pragma unroll
@@ -958,6 +976,13 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       int cc = (side == 0) ? tx0[q] * 64 * V - 1 : (tx0[q] + 1) * 64 * V;
       vl[q] = tx0[q] > 0 || a.per_x;
       vr[q] = tx0[q] + 1 < c.ntx || a.per_x;
+      // ONE scalar of neighbour bits per region for the loop (bit 0 / 1: cells below / above, bit 2 / 3: left / right, bits 8.. / 16..:
+      // the rows the halo loads read), opaque to the optimiser and made opaque again at every use: as four booleans per region
+      // they lived in eight SGPR pairs across the row loops (spilled), and the selects "resource of no bytes beyond a wall" were
+      // hoisted out of the loop as VECTOR values - the halo loads' resources were then rebuilt in four waterfall loops per iteration
+      nbits[q] = (vb[q] ? 1u : 0u) | (va[q] ? 2u : 0u) | (vl[q] ? 4u : 0u) | (vr[q] ? 8u : 0u);
+      nbits[q] = (unsigned)__builtin_amdgcn_readfirstlane((int)nbits[q]);
+      asm volatile("" : "+s"(nbits[q]));
       if (cc < 0) cc = a.per_x ? nx - 1 : -1;
       else if (cc >= nx) cc = a.per_x ? 0 : -1;
       const unsigned vo = (has[q] && side < 2 && cc >= 0) ? (unsigned)(j0[q] + er) * rowT + (unsigned)(cc * sizeof(T)) : 0xffffffffu;
@@ -1028,12 +1053,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // byte offset of row j0[q] + jj: recomputed at every use (two scalar instructions) from a value the optimiser cannot see
   // through - hoisted out of the unrolled row loops the 2 x 16 products live in SGPRs that spill, and a spilled SGPR comes back
   // through v_readlane, a VALU slot of a loop that is bound by VALU issue
-  auto row_base = [&](int q, int jj, unsigned row_bytes, bool coef = false) __attribute__((always_inline)) -> unsigned {
+  auto row_base = [&](int q, int jj, unsigned row_bytes) __attribute__((always_inline)) -> unsigned {
     unsigned j = (unsigned)j0[q];
     asm volatile("" : "+s"(j));
-#ifdef PISO_EXP_ONEROW    // experiment (wrong results): every row of a region reads [1: and publishes to] the region's first row - all loads hit cache
-    if (PISO_EXP_ONEROW == 1 || coef) return j * row_bytes;
-#endif
     return (j + (unsigned)jj) * row_bytes;
   };
   auto coef_offset = [&](int q) __attribute__((always_inline)) -> unsigned {
@@ -1051,7 +1073,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // a back-and-forth sweep misses only what does not fit.  (Measured before: both row loops ran at the speed of the memory
   // fabric, ~6 TB/s of coefficient rows, not at the speed of their arithmetic.)
   constexpr bool kZigZag = PISO_PERSIST1_ZIGZAG != 0 && (!SLAB || PISO_PERSIST1_ZIGZAG_SLAB != 0) && (NQ == 1 || PISO_PERSIST1_ZIGZAG_SMALL != 0);
-  constexpr bool kPrefetchBehindDrain = PISO_PERSIST1_PREFETCH_BEHIND_DRAIN != 0 && !kZigZag;
   // kAhead: z' = L p of the first rows of the U pass does not depend on alpha - it is computed WHILE the exchange's records travel
   // (behind the publish, in front of the polling: the SIMDs have nothing else to do for a microsecond or two) and kept in
   // registers; U then skips the stencil of those rows.  With the back-and-forth order these are the rows D ended with: their
@@ -1059,12 +1080,15 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   constexpr int kAhead = (kHier && kZigZag && NQ == 1 && NT == 16 && SYM && RECON && sizeof(T) == 8 && sizeof(CT) == 4) ? PISO_PERSIST1_AHEAD : 0;
   static_assert(kAhead <= Dw || kAhead == 0, "the rows computed ahead are rows whose coefficients D left in registers");
   constexpr bool kShLate = kAhead > 0 && !SLAB && NQ == 1 && SYM && PISO_PERSIST1_SH_LATE != 0;
+  // kKeepZ (small regions: a wave's rows are few): z' of D stays in registers until U has used it - U runs no stencil at all (the
+  // 16-row instances have no registers for it: they compute z' twice, bitwise the same, and kAhead moves part of that off the path)
+  constexpr bool kKeepZ = PISO_PERSIST1_KEEP_Z != 0 && NT * (int)sizeof(T) * V / 4 <= PISO_PERSIST1_KEEP_Z_REGS;
   constexpr int kRes = (NQ == 1 && NT == 16 && SYM && RECON) ? PISO_PERSIST1_RESIDENT : 0;
   auto issue_coef = [&](int t) __attribute__((always_inline)) {
     if (t < kRes && !first_fill) return;
     const int q = t / R, jj = t - q * R;
     const unsigned vCq = coef_offset(q);
-    const unsigned sT = row_base(q, jj, rowT, true), sC = row_base(q, jj, rowC, true);
+    const unsigned sT = row_base(q, jj, rowT), sC = row_base(q, jj, rowC);
     cS[t] = bld<CT, V>(RoS, vCq, sC); cW[t] = bld<CT, V>(RoW, vCq, sC);
     if constexpr (!SYM) { cE[t] = bld<CT, V>(RoE, vCq, sC); cN[t] = bld<CT, V>(RoN, vCq, sC); }
     if constexpr (!RECON) cD[t] = bld<T, V>(RcC, vT[q], sT);
@@ -1172,6 +1196,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     }
     return z;
   };
+  Vec<T, V> zk[kKeepZ ? NT : 1];                             // kKeepZ: z' of my rows from D to U
   int k = k_begin;                                           // the iteration (SLAB: its parity picks the mailbox rows)
   // perimeter of row jj of region q (what neighbouring regions read): the whole first / last row, else the two end cells
   auto publish = [&](rsrc_t Rd, int q, int jj, const Vec<T, V>& val) __attribute__((always_inline)) {
@@ -1230,8 +1255,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         vo = (side < 2 && cc >= 0) ? (unsigned)(j0[q] + 1) * rowT + (unsigned)(strip * 64 * V * (int)sizeof(T)) + ent : 0xffffffffu;
       }
       eZ[q] = bld1<T, kHalo>(Rz, vo, 0);
-      bool vbq, vaq;
-      const int jb = row_wrap(j0[q] - 1, vbq), ja = row_wrap(j0[q] + R, vaq);
+      bool vbq_unused, vaq_unused;
+      const int jb = row_wrap(j0[q] - 1, vbq_unused), ja = row_wrap(j0[q] + R, vaq_unused);
+      const bool vbq = nbit(q, 1u), vaq = nbit(q, 2u);
       if constexpr (SLAB) {                                  // (wave-uniform branches: no per-lane offset registers to keep)
         if (!(ef[q] & 4u)) hbZ[q] = bld<T, V, kHalo>(Rz, vT[q], (unsigned)(j0[q] - 1) * rowT);
         else if (ef[q] & 1u) {
@@ -1254,8 +1280,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       } else {
       // (beyond a wall: a resource of no bytes - the load is dropped by the range check and returns 0; a per-lane offset that says
       // the same is one more vector register across the row loops)
-      hbZ[q] = bld<T, V, kHalo>(make_rsrc(a.zp[k & 1], vbq ? nbytesT : 0u), vT[q], (unsigned)jb * rowT);
-      haZ[q] = bld<T, V, kHalo>(make_rsrc(a.zp[k & 1], vaq ? nbytesT : 0u), vT[q], (unsigned)ja * rowT);
+      hbZ[q] = bld<T, V, kHalo>(make_rsrc(a.zp[k & 1], (unsigned)__builtin_amdgcn_readfirstlane((int)(vbq ? nbytesT : 0u))), vT[q], (unsigned)jb * rowT);
+      haZ[q] = bld<T, V, kHalo>(make_rsrc(a.zp[k & 1], (unsigned)__builtin_amdgcn_readfirstlane((int)(vaq ? nbytesT : 0u))), vT[q], (unsigned)ja * rowT);
       }
     }
   };
@@ -1281,11 +1307,13 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   T rz_next = tB[0], sumr = tB[1], cnt_last = tB[2];          // r_k.z'_{k-1}, sum r_k, #{|r_k| >= accuracy} for the current k
   T lU[2] = {0, 0};                                           // local sum r, count from the last U (for the next exchange)
   const T accuracy = uniform((T)a.accuracy);
+  // beta of iteration k needs nothing but the sums of exchange k - 1: it is computed right behind them, in the shadow of U's wait for
+  // the neighbours' rows, instead of as a dependent chain of ~25 instructions in front of D (same expression, same operands)
+  T beta = uniform(-(rz_next + vs * sumr) / pz);              // (:351-352), unguarded as coded
   for (; k < k_end && healthy && !st.done; ++k) {
     // consecutive iterations alternate buffers: a neighbour's loads of z'_k are consumed before it publishes its record k + 1,
     // which everybody needs before writing the same buffer again in iteration k + 2
     const rsrc_t Rz = (k & 1) ? Rz1 : Rz0;
-    const T beta = uniform(-(rz_next + vs * sumr) / pz);     // (:351-352), unguarded as coded
     // ---- D(k): p = r + beta p on my cells and on the ring; z' = L p; sums; the perimeter of z' goes out
     T sD[kX1Values] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (has[0]) {
@@ -1325,6 +1353,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         const int q = t / R, jj = t - q * R;
         if (t + 1 < NT) ring_issue(t + 1);
         const Vec<T, V> z = zrow(t);
+        if constexpr (kKeepZ) zk[t] = z;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           sD[0] += pp[q][jj].v[e];
@@ -1338,7 +1367,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         PISO_SB_A1;
         // (rows 0 .. D-1 of the U pass are issued behind the drain of the perimeter stores, see the exchange: issued here they would
         // be in flight when the wave waits for vmcnt(0), and the wait would cover their trip as well)
-        if constexpr (D < NT) { if (t + D < NT || !(kPrefetchBehindDrain || kZigZag)) issue_coef(t + D < NT ? t + D : t + D - NT); }
+        if constexpr (D < NT) { if (t + D < NT || !kZigZag) issue_coef(t + D < NT ? t + D : t + D - NT); }
         if constexpr (kShLate) { if (t + D == NT - 1) reload_csh(); }
         PISO_SB_A2;
       }
@@ -1346,14 +1375,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     sD[6] = lU[0]; sD[7] = lU[1];
     ++epoch;
     tick(0);
-    auto prefetch_u = [&]() __attribute__((always_inline)) {
-      if constexpr (kPrefetchBehindDrain && D < NT) {
-        if (has[0]) {
-#pragma unroll
-          for (int t = 0; t < D; ++t) issue_coef(t);
-        }
-      }
-    };
     Vec<T, V> zs[kAhead > 0 ? kAhead : 1];
     auto z_ahead = [&]() __attribute__((always_inline)) {
       if constexpr (kAhead > 0) {
@@ -1367,10 +1388,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         }
       }
     };
-    if constexpr (kHier) healthy = grid_exchange8_hier<T, (kAhead > 0 ? PISO_PERSIST1_POLL_DELAY2 : PISO_PERSIST1_POLL_DELAY2_NOAHEAD)>(c, sD, epoch, smem, hx, hier_s + 2, z_ahead, (kPersistDiag && c.timing) ? tsub : nullptr);
+    if constexpr (kHier) healthy = grid_exchange8_hier<T, (kAhead > 0 ? PISO_PERSIST1_POLL_DELAY2 : PISO_PERSIST1_POLL_DELAY2_NOAHEAD), SLAB>(c, sD, epoch, smem, hx, hier_s + 2, z_ahead, (kPersistDiag && c.timing) ? tsub : nullptr, sl_off, smem + 2 * kX1Sm);
     else if constexpr (kLocalAll) healthy = grid_exchange8_local<T>(c, sD, epoch, smem, slot, nslots, hier_s + 2, (kPersistDiag && c.timing) ? tsub : nullptr);
-    else healthy = grid_exchange8<T, LOCAL>(c, sD, epoch, smem, slot, nslots, prefetch_u, (kPersistDiag && c.timing) ? tsub : nullptr);
-    if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl_off, sD, epoch, smem + 2 * kX1Sm); }
+    else healthy = grid_exchange8<T, LOCAL>(c, sD, epoch, smem, slot, nslots, NoPrefetch(), (kPersistDiag && c.timing) ? tsub : nullptr);
     tick(1);
     if (!healthy) break;
     // ---- the stopping test of iteration k, one exchange late but before anything moves (x = x_k): (:312-335)
@@ -1390,22 +1410,23 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     alpha = uniform((absval(pz) > 0) ? sD[1] / pz : (T)0);
     rz_next = uniform(sD[3] - alpha * (sD[4] + vs * sD[5]));
     sumr = uniform(sumr - alpha * (sD[5] + ncells * vs));
+    beta = uniform(-(rz_next + vs * sumr) / pz);             // ... of iteration k + 1 (see above)
     // ---- U(k): z' again, x += alpha p, r -= alpha (z' + vs) on my cells and on the ring
     lU[0] = 0; lU[1] = 0;
     int cnt_wave = 0;                                        // #{|r_{k+1}| >= accuracy} of the whole wave, counted on the scalar unit
     if (has[0]) {
-      constexpr int kHaloAt = (NT == 16) ? PISO_PERSIST1_HALO_AT : 0;     // the row step of U in front of which the neighbours' z' is requested
-      if constexpr (kHaloAt == 0) issue_halos(Rz);
-      if constexpr (kAhead < NT) ring_issue(kZigZag ? NT - 1 - kAhead : 0);
+      issue_halos(Rz);                                       // (requested later in U, the stall moves into D: measured)
+      if constexpr (kAhead < NT && !kKeepZ) ring_issue(kZigZag ? NT - 1 - kAhead : 0);
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
         const int t = kZigZag ? NT - 1 - tt : tt;
         const int q = t / R, jj = t - q * R;
-        if constexpr (kHaloAt > 0) { if (tt == kHaloAt) issue_halos(Rz); }
-        if (tt + 1 < NT && tt + 1 > kAhead) ring_issue(kZigZag ? t - 1 : t + 1);      // (row kAhead's values were requested in front of the loop)
+        if constexpr (!kKeepZ) { if (tt + 1 < NT && tt + 1 > kAhead) ring_issue(kZigZag ? t - 1 : t + 1); }     // (row kAhead's values were requested in front of the loop)
         T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V + jj * 64 * V;
         Vec<T, V> xv = ldv<T, V>(xl);                        // x += alpha p (:303); the LDS latency hides under the stencil
-        const Vec<T, V> z = (tt < kAhead) ? zs[tt < kAhead ? tt : 0] : zrow(t);
+        Vec<T, V> z;
+        if constexpr (kKeepZ) z = zk[t];
+        else z = (tt < kAhead) ? zs[tt < kAhead ? tt : 0] : zrow(t);
 #pragma unroll
         for (int e = 0; e < V; ++e) xv.v[e] = fma(alpha, pp[q][jj].v[e], xv.v[e]);
         stv<T, V>(xl, xv);
@@ -1439,7 +1460,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       // the ring: the same update with the neighbours' z' (beyond a wall there is no cell: the copies stay 0)
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        T vsb = vb[q] ? vs : (T)0, vsa = va[q] ? vs : (T)0;
+        T vsb = nbit(q, 1u) ? vs : (T)0, vsa = nbit(q, 2u) ? vs : (T)0;
         if constexpr (RAGGED) {
           if (!(col_ok[q] && j0[q] - 1 < a.ny_true)) vsb = 0;
           if (!(col_ok[q] && j0[q] + R < a.ny_true)) vsa = 0;
@@ -1452,7 +1473,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         int side, er_unused, lane_now = lane;
         if constexpr (SLAB) asm volatile("" : "+v"(lane_now));   // (slab variant: recomputed here instead of a register held across the loop)
         ring_lane(lane_now, R, side, er_unused);
-        T vse = (side == 0) ? (vl[q] ? vs : (T)0) : ((side == 1) ? (vr[q] ? vs : (T)0) : (T)0);
+        T vse = (side == 0) ? (nbit(q, 4u) ? vs : (T)0) : ((side == 1) ? (nbit(q, 8u) ? vs : (T)0) : (T)0);
         if constexpr (RAGGED) {
           const bool ok = (side == 0 ? lcol_ok[q] : rcol_ok[q]) && j0[q] + er_unused < a.ny_true;
           if (!ok) vse = 0;
@@ -1481,10 +1502,9 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   if (!first && healthy && !st.done) {
     T sX[kX1Values] = {0, 0, 0, 0, 0, 0, lU[0], lU[1]};
     ++epoch;
-    if constexpr (kHier) healthy = grid_exchange8_hier<T, PISO_PERSIST1_POLL_DELAY2_NOAHEAD>(c, sX, epoch, smem, hx, hier_s + 2);     // (nothing to compute ahead)
+    if constexpr (kHier) healthy = grid_exchange8_hier<T, PISO_PERSIST1_POLL_DELAY2_NOAHEAD, SLAB>(c, sX, epoch, smem, hx, hier_s + 2, NoPrefetch(), nullptr, sl_off, smem + 2 * kX1Sm);     // (nothing to compute ahead)
     else if constexpr (kLocalAll) healthy = grid_exchange8_local<T>(c, sX, epoch, smem, slot, nslots, hier_s + 2);
     else healthy = grid_exchange8<T, LOCAL>(c, sX, epoch, smem, slot, nslots);
-    if constexpr (SLAB) { if (healthy) healthy = xgpu_exchange8<T>(sl_off, sX, epoch, smem + 2 * kX1Sm); }
     tOut[1] = sX[6]; tOut[2] = sX[7];
   }
 

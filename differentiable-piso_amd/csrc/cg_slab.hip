@@ -381,6 +381,7 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
       sl.rows_own = sl.pv.mbox[sl.pv.rank] + PeerLayout::kRows;
       sl.rows_lo = sl.pv.mbox[sl.pv.lower >= 0 ? sl.pv.lower : sl.pv.rank] + PeerLayout::kRows;
       sl.rows_hi = sl.pv.mbox[sl.pv.upper >= 0 ? sl.pv.upper : sl.pv.rank] + PeerLayout::kRows;
+      sl.hop_ticks = opt(OPT_SLAB_HOP_TICKS) > 0 ? (unsigned)opt(OPT_SLAB_HOP_TICKS) : 0u;
     }
   }
   int seg_len = (int)(40000.0 / ((double)R[0].a.nx * R[0].a.ny * 8.5e-6 + 4.0));   // ~10 ms of work per segment at 2048^2 per GPU (as cg.hip)
@@ -417,7 +418,7 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
         // records of 65536 launches ago could pass for new ones: everybody waits for everybody, then clears its own.
         if ((c->launches & 0xffffu) == 0 && c->launches > 0) {
           rc = comm.allreduce(R, 12, 1, stream);
-          if (rc == PISO_OK) PISO_HIP_CHECK(hipMemsetAsync(c->mbox[c->rank] + PeerLayout::x_rec(0, 0), 0, 2 * kMaxRanks * PeerLayout::kRecBytes, stream));
+          if (rc == PISO_OK) PISO_HIP_CHECK(hipMemsetAsync(c->mbox[c->rank] + PeerLayout::kXcdRecs, 0, PeerLayout::kXcdRecBytes, stream));
           if (rc == PISO_OK) rc = comm.allreduce(R, 12, 1, stream);
           if (rc != PISO_OK) return rc;
         }

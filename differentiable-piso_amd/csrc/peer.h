@@ -19,15 +19,20 @@ namespace piso {
 
 constexpr int kMaxRanks = 8;                   // GPUs of one node
 constexpr int kPeerRecWords = 16;              // 8-byte words per record: 8 sums x {low half | tag, high half | tag}
+constexpr int kPeerXcds = 8;                   // XCDs of one GPU (= kXcds of piso_common.h)
 constexpr unsigned kPeerSpinLimit = 1u << 24;  // polling passes before a wait gives up (seconds; a dead peer must not hang the node)
 
 // byte offsets inside a mailbox; row_cap = capacity of a halo row in elements of 8 bytes
 struct PeerLayout {
   static constexpr size_t kRecBytes = kPeerRecWords * 8;
   static constexpr size_t ar_rec(int parity, int src) { return ((size_t)parity * kMaxRanks + src) * kRecBytes; }             // host-level all-reduce
-  static constexpr size_t x_rec(int parity, int src) { return (size_t)2 * kMaxRanks * kRecBytes + ar_rec(parity, src); }     // persistent kernel's GPU records
-  static constexpr size_t ex_flag(int parity, int side) { return (size_t)4 * kMaxRanks * kRecBytes + ((size_t)parity * 2 + side) * 128; }
-  static constexpr size_t kRows = (size_t)4 * kMaxRanks * kRecBytes + 4 * 128;
+  static constexpr size_t ex_flag(int parity, int side) { return (size_t)2 * kMaxRanks * kRecBytes + ((size_t)parity * 2 + side) * 128; }
+  // persistent kernel: the records of the XCD leaders of EVERY rank (round 5: the leaders store straight into the peers' mailboxes -
+  // no "GPU total" level between the chip's exchange and the node's), [2 parities][kMaxRanks][kPeerXcds] records of 128 bytes
+  static constexpr size_t kXcdRecs = (size_t)2 * kMaxRanks * kRecBytes + 4 * 128;
+  static constexpr size_t xcd_rec(int parity, int src, int xcd) { return kXcdRecs + (((size_t)parity * kMaxRanks + src) * kPeerXcds + xcd) * kRecBytes; }
+  static constexpr size_t kXcdRecBytes = (size_t)2 * kMaxRanks * kPeerXcds * kRecBytes;
+  static constexpr size_t kRows = kXcdRecs + kXcdRecBytes;
   // side 0: the row BELOW my slab (written by my lower neighbour), side 1: the row ABOVE it (written by my upper neighbour)
   static constexpr size_t ex_row(int parity, int side, size_t row_cap) { return kRows + ((size_t)parity * 2 + side) * row_cap * 8; }   // host-level halo exchange
   static constexpr size_t z_row(int parity, int side, size_t row_cap) { return kRows + (4 + (size_t)parity * 2 + side) * row_cap * 8; }   // persistent kernel: z' halo rows

@@ -11,7 +11,7 @@ void set_error(const char* what, hipError_t err) {
 void set_error_msg(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
 
 static const char* const kOptNames[OPT_COUNT] = {"cg_persist", "cg_persist_r", "cg_persist_half", "cg_segment", "cg_persist_timing",
-                                                 "cg_rpw", "cg_maxblocks", "cg_nt", "cg_no_compact", "cg_no_recon", "cg_no_sym", "cg_verify", "cg_pad", "cg_xcd_local", "cg_tiny", "conv_lds", "bicg_fold", "slab_force"};
+                                                 "cg_rpw", "cg_maxblocks", "cg_nt", "cg_no_compact", "cg_no_recon", "cg_no_sym", "cg_verify", "cg_pad", "cg_xcd_local", "cg_tiny", "conv_lds", "bicg_fold", "slab_force", "slab_hop_ticks"};
 struct Options {
   int v[OPT_COUNT];
   Options() {                                      // the environment is read here, once, and never again
@@ -27,8 +27,6 @@ struct Options {
   }
 };
 static Options g_opt;
-static RowWin g_rows = {0, 0, 0, 0};
-RowWin row_window() { return g_rows; }
 int opt(Opt o) { return g_opt.v[o]; }
 static int opt_index(const char* name) {
   if (!name) return -1;
@@ -52,19 +50,6 @@ int piso_get_option(const char* name, int* value_out) {
   if (i < 0 || !value_out) { piso::set_error_msg("piso_get_option: unknown option"); return PISO_ERR_INVALID_ARG; }
   *value_out = piso::g_opt.v[i];
   return PISO_OK;
-}
-int piso_set_row_window(int row_begin, int row_end, int owns_last_face_row) {
-  if (row_begin < 0 && row_end < 0) { piso::g_rows = piso::RowWin{0, 0, 0, 0}; return PISO_OK; }
-  if (row_begin < 0 || row_end <= row_begin) { piso::set_error_msg("piso_set_row_window: need 0 <= row_begin < row_end"); return PISO_ERR_INVALID_ARG; }
-  piso::g_rows = piso::RowWin{1, row_begin, row_end, owns_last_face_row ? 1 : 0};
-  return PISO_OK;
-}
-int piso_get_row_window(int* row_begin, int* row_end, int* owns_last_face_row) {
-  const piso::RowWin r = piso::g_rows;
-  if (row_begin) *row_begin = r.on ? r.j0 : -1;
-  if (row_end) *row_end = r.on ? r.j1 : -1;
-  if (owns_last_face_row) *owns_last_face_row = r.last;
-  return r.on;
 }
 int piso_device_count(void) {
   int n = 0;

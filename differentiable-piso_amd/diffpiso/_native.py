@@ -108,10 +108,29 @@ lib.piso_comm_peer_connect.argtypes = [_vp, _vp]
 lib.piso_comm_peer_connect.restype = _i
 lib.piso_comm_stats.argtypes = [_vp, C.POINTER(C.c_longlong)]
 lib.piso_comm_stats.restype = _i
-lib.piso_set_row_window.argtypes = [_i, _i, _i]
-lib.piso_set_row_window.restype = _i
-lib.piso_get_row_window.argtypes = [_ip, _ip, _ip]
-lib.piso_get_row_window.restype = _i
+
+
+class Slab(C.Structure):
+    """include/piso_hip.h: piso_slab_t - one rank's rows of a grid cut into y-slabs (the *_slab entry points; local storage)."""
+    _fields_ = [("ny_global", _i), ("row_begin", _i), ("row_end", _i), ("owns_last_face_row", _i)]
+
+
+_sp = C.POINTER(Slab)
+lib.piso_slab_sizes.argtypes = [_sp, _i, _i, _i, _i, _ip]
+lib.piso_slab_sizes.restype = _i
+lib.piso_assemble_csr_slab.argtypes = lib.piso_assemble_csr.argtypes + [_sp, _i]
+lib.piso_assemble_csr_slab.restype = _i
+for _n in ("piso_laplace_matrix_f64", "piso_laplace_matrix_f32", "piso_pad_velocity", "piso_a0_vfirst", "piso_face_forward", "piso_face_backward",
+           "piso_divergence", "piso_divergence_adjoint", "piso_h_contribution", "piso_h_contribution_adjoint"):
+    getattr(lib, _n + "_slab").argtypes = getattr(lib, _n).argtypes + [_sp]
+    getattr(lib, _n + "_slab").restype = _i
+lib.piso_csr_matvec_f32_slab.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sp]
+lib.piso_csr_matvec_f32_slab.restype = _i
+lib.piso_bicgstab_slab_workspace_bytes.argtypes = [_i, _i, _i, _sp]
+lib.piso_bicgstab_slab_workspace_bytes.restype = _sz
+for _n in ("piso_multi_bicgstab_ilu_slab_local_f32", "piso_multi_bicgstab_ilu_slab_local_f64"):
+    getattr(lib, _n).argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _ip, _vp, _sz, _vp, _sp]
+    getattr(lib, _n).restype = _i
 lib.piso_comm_exchange.argtypes = [_vp, _vp, _i, _ip, _vp]
 lib.piso_comm_exchange.restype = _i
 lib.piso_comm_check.argtypes = [_vp, _vp]
@@ -139,21 +158,6 @@ def get_option(name):
     if lib.piso_get_option(name.encode(), C.byref(v)) != 0:
         raise PisoNativeError("unknown libpiso_hip option %r" % name)
     return v.value
-
-
-_window = (-1, -1, 0)
-
-
-def use_window(sharding):
-    """The row window of the library's element-wise / gather kernels (include/piso_hip.h: piso_set_row_window) is state of the
-    process; the package treats it as an attribute of every CALL: each kernel wrapper names the sharding (sharding.StepSharding) it
-    works for - None: the whole grid - right before it launches, so that two simulations in one process (a sharded training run next
-    to an un-sharded validation run, bench.py's other configurations) can never see each other's window."""
-    global _window
-    w = (-1, -1, 0) if sharding is None else (int(sharding.j0), int(sharding.j1), int(sharding.last))
-    if w != _window:
-        check(lib.piso_set_row_window(*w), "piso_set_row_window")
-        _window = w
 
 
 def cg_verify_stats():

@@ -237,3 +237,26 @@ def multi_bicgstab_ilu_slab(comm, values, row_ptr, col_indices, rhs, x0, nx, ny,
     if gather and comm.world > 1:
         x = gather_face_rows(comm, x, nx, ny)
     return x, (its[0], its[1])
+
+
+def multi_bicgstab_ilu_slab_local(comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn):
+    """piso_multi_bicgstab_ilu_slab_local_{f32,f64}: the slab-decomposed STEP's solve - every array (the workspace included) holds the
+    rank's stored rows (sharding.StepSharding, reached through the communicator); nx, ny are the whole grid's.  x is written on the
+    owned rows, the halo rows of the result stay zero."""
+    sh = comm.step_sharding
+    dt = values.dtype
+    assert dt in (torch.float32, torch.float64) and sh is not None
+    values, rhs, x0 = values.contiguous(), rhs.to(dt).contiguous(), x0.to(dt).contiguous()
+    row_ptr, col_indices = row_ptr.contiguous(), col_indices.contiguous()
+    assert rhs.numel() == sh.n_faces and x0.numel() == sh.n_faces
+    x = torch.zeros_like(rhs)
+    elem = 8 if dt == torch.float64 else 4
+    ws = N.workspace(N.lib.piso_bicgstab_slab_workspace_bytes(nx, ny, elem, sh.slab_ptr), rhs.device, "bicgstab_slab")
+    its = (C.c_int * 2)()
+    per_x, per_y = sh.periodic_xy
+    fn = N.lib.piso_multi_bicgstab_ilu_slab_local_f64 if dt == torch.float64 else N.lib.piso_multi_bicgstab_ilu_slab_local_f32
+    st = fn(comm.handle, N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(rhs), N.ptr(x0), N.ptr(x), nx, ny, int(per_x), int(per_y),
+            C.c_float(tol), int(max_it), int(bool(transpose)), int(band_rows), N.ptr(warn), its, N.ptr(ws), C.c_size_t(ws.numel()),
+            N.stream_ptr(), sh.slab_ptr)
+    N.check(st, "piso_multi_bicgstab_ilu_slab_local")
+    return x, (its[0], its[1])

@@ -22,6 +22,7 @@ import torch
 
 from . import _native as N
 from .grids import CenteredGrid, StaggeredGrid, as_tensor, axis_extrapolation, device_constant
+from .sharding import SlabCentered, SlabStaggered
 
 _PAD = {"constant": 0, "boundary": 1, "replicate": 1, "symmetric": 1, "periodic": 2, "circular": 2}
 FACE_RHS, FACE_CORR1, FACE_FINAL = 0, 1, 2
@@ -43,18 +44,27 @@ class Geometry(object):
             lo, hi = (e, e) if isinstance(e, str) else e
             modes += [_PAD[lo], _PAD[hi]]
         self.pad_modes = (C.c_int * 4)(*modes)
-        self.accessible = accessible                         # [(ny+2)(nx+2)] float32 on the device, or None
-        self.n_u, self.n_v = (self.nx + 1) * self.ny, self.nx * (self.ny + 1)
+        self.accessible = accessible                         # padded cell mask, float32 on the device (slab: the rank's stored mask rows), or None
+        # elements of a flat face vector / a cell array / the padded velocities AS STORED (slab-decomposed step: the rank's rows)
+        if sharding is None:
+            self.n_u, self.n_v = (self.nx + 1) * self.ny, self.nx * (self.ny + 1)
+            self.n_cells, self.cell_rows = self.nx * self.ny, self.ny
+            self.n_pad = (self.ny + 2) * (self.nx + 3) + (self.ny + 3) * (self.nx + 2)
+        else:
+            self.n_u, self.n_v, self.n_cells, self.cell_rows, self.n_pad = sharding.n_u, sharding.n_v, sharding.n_cells, sharding.cr, sharding.n_pad
 
     def f(self, v):
         return C.c_float(np.float32(v))
 
-    def activate(self):
-        """Every wrapper calls this before it launches: the kernels walk this geometry's rows (N.use_window)."""
-        N.use_window(self.sh)
+    def call(self, name, *args):
+        """libpiso_hip entry point `name` on the whole grid, or its *_slab twin on this rank's stored rows (include/piso_hip.h: piso_slab_t)."""
+        if self.sh is None:
+            N.check(getattr(N.lib, name)(*args), name)
+        else:
+            N.check(getattr(N.lib, name + "_slab")(*(args + (self.sh.slab_ptr,))), name + "_slab")
 
     def new_like(self, t):
-        """Output buffer of a kernel: a windowed launch (slab-decomposed step) fills this rank's rows, the rest must be zero."""
+        """Output buffer of a kernel: a slab launch fills this rank's OWNED rows; the halo rows stay zero until an exchange fills them."""
         return torch.zeros_like(t) if self.sh is not None else torch.empty_like(t)
 
     def new(self, n, device):
@@ -62,7 +72,9 @@ class Geometry(object):
 
 
 def flat_faces(x):
-    """Staggered tensor / StaggeredGrid -> flat u-first face vector (one gather)."""
+    """Staggered tensor / StaggeredGrid -> flat u-first face vector (one gather); a SlabStaggered IS its flat vector."""
+    if isinstance(x, SlabStaggered):
+        return x.flat
     grid = x if isinstance(x, StaggeredGrid) else StaggeredGrid(x)
     v, u = grid.data[0].data, grid.data[1].data
     return torch.cat([u.reshape(-1), v.reshape(-1)])
@@ -70,24 +82,22 @@ def flat_faces(x):
 
 def faces_to_grid(flat, geom, box, extrapolation):
     """Flat u-first vector -> StaggeredGrid whose components are VIEWS of `flat` (no copy)."""
+    if geom.sh is not None:
+        return SlabStaggered(flat, geom.sh, box, extrapolation)
     u = flat[:geom.n_u].view(1, geom.ny, geom.nx + 1, 1)
     v = flat[geom.n_u:].view(1, geom.ny + 1, geom.nx, 1)
     return StaggeredGrid([v, u], box, extrapolation=extrapolation)
 
 
 def pad_velocity(vel_flat, geom, per_x, per_y):
-    geom.activate()
-    out = geom.new((geom.ny + 2) * (geom.nx + 3) + (geom.ny + 3) * (geom.nx + 2), vel_flat.device)
-    N.check(N.lib.piso_pad_velocity(N.ptr(vel_flat), N.ptr(out), geom.nx, geom.ny, int(per_x), int(per_y), N.stream_ptr()),
-            "piso_pad_velocity")
+    out = geom.new(geom.n_pad, vel_flat.device)
+    geom.call("piso_pad_velocity", N.ptr(vel_flat), N.ptr(out), geom.nx, geom.ny, int(per_x), int(per_y), N.stream_ptr())
     return out
 
 
 def a0_vfirst(a_flat, geom, dx_factor):
-    geom.activate()
     out = geom.new_like(a_flat)
-    N.check(N.lib.piso_a0_vfirst(N.ptr(a_flat), N.ptr(out), geom.nx, geom.ny, geom.f(geom.beta), geom.f(dx_factor), N.stream_ptr()),
-            "piso_a0_vfirst")
+    geom.call("piso_a0_vfirst", N.ptr(a_flat), N.ptr(out), geom.nx, geom.ny, geom.f(geom.beta), geom.f(dx_factor), N.stream_ptr())
     if geom.sh is not None:
         geom.sh.halo_faces_vfirst(out)                       # the Laplacian of the slab's last cell row reads the face row above it
     return out
@@ -103,14 +113,13 @@ class _FaceOp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mode, geom, p, in0, in1, in2, a_flat, dmask):
         p, in0, in1, in2 = _c(p), _c(in0), _c(in1), _c(in2)
-        geom.activate()
         if geom.sh is not None:
             geom.sh.halo_cells(p)                            # G(p) on the slab's edge faces reads the neighbours' cell rows
         out0 = geom.new_like(in0)
         out1 = geom.new_like(in0) if mode == FACE_CORR1 else None
-        N.check(N.lib.piso_face_forward(mode, geom.nx, geom.ny, geom.pad_modes, geom.f(geom.dxdy), geom.f(geom.hx), geom.f(geom.hy),
-                                        geom.f(geom.beta), N.ptr(p), N.ptr(geom.accessible), N.ptr(a_flat), N.ptr(in0), N.ptr(in1),
-                                        N.ptr(in2), N.ptr(dmask), N.ptr(out0), N.ptr(out1), N.stream_ptr()), "piso_face_forward")
+        geom.call("piso_face_forward", mode, geom.nx, geom.ny, geom.pad_modes, geom.f(geom.dxdy), geom.f(geom.hx), geom.f(geom.hy),
+                  geom.f(geom.beta), N.ptr(p), N.ptr(geom.accessible), N.ptr(a_flat), N.ptr(in0), N.ptr(in1),
+                  N.ptr(in2), N.ptr(dmask), N.ptr(out0), N.ptr(out1), N.stream_ptr())
         ctx.mode, ctx.geom, ctx.a_flat, ctx.dmask = mode, geom, a_flat, dmask
         ctx.has = (in1 is not None, in2 is not None)
         ctx.p_shape = p.shape
@@ -123,17 +132,16 @@ class _FaceOp(torch.autograd.Function):
         mode, geom = ctx.mode, ctx.geom
         d0 = _c(d0)
         d1 = _c(d1) if mode == FACE_CORR1 else None
-        geom.activate()
         if geom.sh is not None:                              # d p gathers the face cotangents around every cell of the slab
             d0 = geom.sh.halo_faces(d0.clone())
             d1 = geom.sh.halo_faces(d1.clone()) if d1 is not None else None
         g0 = geom.new_like(d0)
         g1 = geom.new_like(d0) if (mode == FACE_FINAL or (mode == FACE_RHS and ctx.has[0])) else None
         g2 = geom.new_like(d0) if (mode == FACE_RHS and ctx.has[1]) else None
-        dp = geom.new(geom.nx * geom.ny, d0.device)
-        N.check(N.lib.piso_face_backward(mode, geom.nx, geom.ny, geom.pad_modes, geom.f(geom.dxdy), geom.f(geom.hx), geom.f(geom.hy),
-                                         geom.f(geom.beta), N.ptr(geom.accessible), N.ptr(ctx.a_flat), N.ptr(ctx.dmask), N.ptr(d0),
-                                         N.ptr(d1), N.ptr(g0), N.ptr(g1), N.ptr(g2), N.ptr(dp), N.stream_ptr()), "piso_face_backward")
+        dp = geom.new(geom.n_cells, d0.device)
+        geom.call("piso_face_backward", mode, geom.nx, geom.ny, geom.pad_modes, geom.f(geom.dxdy), geom.f(geom.hx), geom.f(geom.hy),
+                  geom.f(geom.beta), N.ptr(geom.accessible), N.ptr(ctx.a_flat), N.ptr(ctx.dmask), N.ptr(d0),
+                  N.ptr(d1), N.ptr(g0), N.ptr(g1), N.ptr(g2), N.ptr(dp), N.stream_ptr())
         return None, None, dp.view(ctx.p_shape), g0, g1, g2, None, None
 
 
@@ -143,25 +151,23 @@ class _Divergence(torch.autograd.Function):
     @staticmethod
     def forward(ctx, faces, geom, per_x, per_y):
         faces = _c(faces)
-        geom.activate()
         if geom.sh is not None:
             geom.sh.halo_faces(faces)                        # the slab's last cell row reads the face row above it
-        div = geom.new(geom.nx * geom.ny, faces.device)
-        N.check(N.lib.piso_divergence(N.ptr(faces), N.ptr(div), geom.nx, geom.ny, geom.f(geom.dxdy), geom.f(geom.hx), geom.f(geom.hy),
-                                      N.stream_ptr()), "piso_divergence")
+        div = geom.new(geom.n_cells, faces.device)
+        geom.call("piso_divergence", N.ptr(faces), N.ptr(div), geom.nx, geom.ny, geom.f(geom.dxdy), geom.f(geom.hx), geom.f(geom.hy),
+                  N.stream_ptr())
         ctx.meta = (geom, int(per_x), int(per_y))
-        return div.view(1, geom.ny, geom.nx, 1)
+        return div.view(1, geom.cell_rows, geom.nx, 1)
 
     @staticmethod
     def backward(ctx, dc):
         geom, per_x, per_y = ctx.meta
         dc = _c(dc)
-        geom.activate()
         if geom.sh is not None:
             dc = geom.sh.halo_cells(dc.clone())
         out = geom.new(geom.n_u + geom.n_v, dc.device)
-        N.check(N.lib.piso_divergence_adjoint(N.ptr(dc), N.ptr(out), geom.nx, geom.ny, per_x, per_y, geom.f(geom.dxdy), geom.f(geom.hx),
-                                              geom.f(geom.hy), N.stream_ptr()), "piso_divergence_adjoint")
+        geom.call("piso_divergence_adjoint", N.ptr(dc), N.ptr(out), geom.nx, geom.ny, per_x, per_y, geom.f(geom.dxdy), geom.f(geom.hx),
+                  geom.f(geom.hy), N.stream_ptr())
         return out, None, None, None
 
 
@@ -171,10 +177,9 @@ class _HContribution(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m_delta, delta, a_flat, geom):
         m_delta, delta = _c(m_delta), _c(delta)
-        geom.activate()
         h, hb = geom.new_like(delta), geom.new_like(delta)
-        N.check(N.lib.piso_h_contribution(N.ptr(m_delta), N.ptr(delta), N.ptr(a_flat), geom.f(geom.beta), N.ptr(h), N.ptr(hb), geom.nx,
-                                          geom.ny, N.stream_ptr()), "piso_h_contribution")
+        geom.call("piso_h_contribution", N.ptr(m_delta), N.ptr(delta), N.ptr(a_flat), geom.f(geom.beta), N.ptr(h), N.ptr(hb), geom.nx,
+                  geom.ny, N.stream_ptr())
         ctx.a_flat, ctx.geom = a_flat, geom
         return h, hb
 
@@ -182,10 +187,9 @@ class _HContribution(torch.autograd.Function):
     def backward(ctx, dh, dhb):
         geom = ctx.geom
         dh, dhb = _c(dh), _c(dhb)
-        geom.activate()
         d_md, d_delta = geom.new_like(dhb), geom.new_like(dhb)
-        N.check(N.lib.piso_h_contribution_adjoint(N.ptr(dh), N.ptr(dhb), N.ptr(ctx.a_flat), geom.f(geom.beta), N.ptr(d_md),
-                                                  N.ptr(d_delta), geom.nx, geom.ny, N.stream_ptr()), "piso_h_contribution_adjoint")
+        geom.call("piso_h_contribution_adjoint", N.ptr(dh), N.ptr(dhb), N.ptr(ctx.a_flat), geom.f(geom.beta), N.ptr(d_md),
+                  N.ptr(d_delta), geom.nx, geom.ny, N.stream_ptr())
         return d_md, d_delta, None, None
 
 
@@ -195,15 +199,18 @@ def divergence(faces, geom, per_x, per_y):
 
 def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, dirichlet_values, viscosity_field, forcing_term,
                     unrolling_step, warn, full_output):
-    """piso_step (diffpiso/piso_tf.py:11-81) on the fused kernels.  Called by piso.piso_step; same arguments and results."""
+    """piso_step (diffpiso/piso_tf.py:11-81) on the fused kernels.  Called by piso.piso_step; same arguments and results.  With
+    `sim.sharding` (sharding.StepSharding) the fields are SlabStaggered / SlabCentered: the rank's stored rows (local storage)."""
     from .piso import _CsrMatVec, assemble_from_padded
     ny, nx = [int(r) for r in velocity.resolution]
-    dev = velocity.data[0].data.device
+    sh = getattr(sim, "sharding", None)                                            # sharding.StepSharding: this rank's y-slab only
+    if (sh is not None) != isinstance(velocity, SlabStaggered) or (sh is not None) != isinstance(pressure, SlabCentered):
+        raise ValueError("piso_step: a simulation with `sharding` steps SlabStaggered / SlabCentered fields (sharding.scatter_*), "
+                         "one without steps StaggeredGrid / CenteredGrid")
+    dev = velocity.device if sh is not None else velocity.data[0].data.device
     dxdy = float(np.prod(velocity.dx))
     beta = dxdy / dt                                                               # :26
     per_y, per_x = [bool(b) for b in (sim.bool_periodic if sim.bool_periodic is not None else (False, False))]
-    acc = sim.accessible_mask_tensor(dev).reshape(-1)
-    sh = getattr(sim, "sharding", None)                                            # sharding.StepSharding: this rank's y-slab only
     if sh is not None and (sh.nx, sh.ny) != (nx, ny):
         raise ValueError("the step sharding was built for a %d x %d grid" % (sh.nx, sh.ny))
     for solver in (sim.linear_solver, sim.pressure_solver):
@@ -211,39 +218,41 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
         if (comm is not None and getattr(comm, "sharded", False)) != (sh is not None):
             raise ValueError("piso_step: the simulation's `sharding` and its solvers' slab communicators disagree - a sharded step needs both "
                              "solvers cut into the same slabs (solver.slab_comm), an un-sharded step none that is marked `sharded`")
+    if sh is None:
+        acc = sim.accessible_mask_tensor(dev).reshape(-1)
+        dmask, active, no_slip = sim.dirichlet_mask_flat(dev), sim.active_mask_tensor(dev), sim.no_slip_flat(dev, ny, nx)
+    else:
+        sh.periodic_xy = (per_x, per_y)
+        loc = sh.sim_tensors(sim, dev)
+        acc, dmask, active, no_slip = loc["accessible"], loc["dmask"], loc["active"], loc["no_slip"]
     geom = Geometry(nx, ny, velocity.dx, beta, pressure.extrapolation, acc, sh)
     staggered_shape = (1, ny + 1, nx + 1, 2)
     if warn is None:
         warn = torch.zeros(1, dtype=torch.uint8, device=dev)
     viscosity = sim.viscosity if viscosity_field is None else viscosity_field      # :21-24
+    if sh is not None and not isinstance(viscosity, (int, float, np.floating, np.integer)):
+        viscosity = sh.cached_scatter_faces(viscosity)                             # a per-face field: this rank's stored rows
 
     # ADVECTION MATRICES (:29-33) -- no gradient (:125-126)
     vel_flat = flat_faces(velocity)
-    dmask = sim.dirichlet_mask_flat(dev)
     with torch.no_grad():
         if sh is not None:
             sh.halo_faces(vel_flat)                                                # the padding / assembly of the slab's edge rows
-            if sh.pattern is None:                                                 # col / rowptr of the whole grid, once
-                geom.sh = None
-                try:
-                    pad0 = pad_velocity(torch.zeros_like(vel_flat), geom, per_x, per_y)
-                    _, rp0, col0, _, nnz0 = assemble_from_padded(pad0, nx, ny, velocity.dx, per_x, per_y, dmask, sim.active_mask_tensor(dev),
-                                                                 viscosity, sim.no_slip_flat(dev, ny, nx), beta)
-                finally:
-                    geom.sh = sh
-                sh.set_pattern(col0, rp0, int(nnz0[0]))
         vel_pad = pad_velocity(vel_flat.detach(), geom, per_x, per_y)
         matrix_values, row_pointers, column_indices, Aflat, matrix_nnz = assemble_from_padded(
-            vel_pad, nx, ny, velocity.dx, per_x, per_y, dmask, sim.active_mask_tensor(dev), viscosity, sim.no_slip_flat(dev, ny, nx), beta,
-            pattern=sh.pattern if sh is not None else None, sharding=sh)
+            vel_pad, nx, ny, velocity.dx, per_x, per_y, dmask, active, viscosity, no_slip, beta, sharding=sh)
         if sh is not None:                                                         # the solvers' transposes, the H product and A0 read
             sh.halo_csr_values(matrix_values)                                      # the matrix rows / diagonal of the neighbouring face rows
             sh.halo_faces(Aflat)
 
     # Predictor step (:36-47)
     p_data = pressure.data
-    forcing_flat = flat_faces(device_constant(forcing_term, device=dev)) if forcing_term is not None else None
-    dv_flat = flat_faces(device_constant(dirichlet_values, dtype=torch.float32, device=dev))
+    if sh is None:
+        forcing_flat = flat_faces(device_constant(forcing_term, device=dev)) if forcing_term is not None else None
+        dv_flat = flat_faces(device_constant(dirichlet_values, dtype=torch.float32, device=dev))
+    else:
+        forcing_flat = None if forcing_term is None else (forcing_term.flat if isinstance(forcing_term, SlabStaggered) else sh.scatter_staggered(forcing_term, device=dev))
+        dv_flat = dirichlet_values.flat if isinstance(dirichlet_values, SlabStaggered) else sh.cached_scatter_staggered(dirichlet_values)
     implicit_rhs = _FaceOp.apply(FACE_RHS, geom, p_data, vel_flat, forcing_flat, dv_flat, None, dmask)
     sol = sim.linear_solver.solve(-matrix_values, row_pointers, column_indices, implicit_rhs, staggered_shape, vel_flat, offset=1,
                                   transpose=False, unrolling_step=unrolling_step, warn=warn)
@@ -260,7 +269,7 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
     s2, delta = _FaceOp.apply(FACE_CORR1, geom1, p1, star, None, None, Aflat, None)
 
     # Corrector step 2 (:60-73)
-    m_delta = _CsrMatVec.apply(delta, matrix_values, row_pointers, column_indices, nx, ny, sh)
+    m_delta = _CsrMatVec.apply(delta, matrix_values, row_pointers, column_indices, nx, ny, sh, (per_x, per_y))
     H, Hb = _HContribution.apply(m_delta, delta, Aflat, geom)
     H_div = divergence(Hb, geom, per_x, per_y)
     p2, _, Lap2 = sim.pressure_solver.solve_flat(a0, H_div, sim, unrolling_step=1000 + unrolling_step)
@@ -268,12 +277,15 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
     s3 = _FaceOp.apply(FACE_FINAL, geom2, p2, s2, H, None, Aflat, None)
     velocity_s3 = faces_to_grid(s3, geom, velocity.box, velocity.extrapolation)
 
-    pressure_inc1 = CenteredGrid(p1, box=pressure_inc1.box, extrapolation=pressure_inc1.extrapolation)
-    pressure_inc2 = CenteredGrid(p2, box=pressure_inc2.box, extrapolation=pressure_inc2.extrapolation)
+    if sh is None:
+        pressure_inc1 = CenteredGrid(p1, box=pressure_inc1.box, extrapolation=pressure_inc1.extrapolation)
+        pressure_inc2 = CenteredGrid(p2, box=pressure_inc2.box, extrapolation=pressure_inc2.extrapolation)
+    else:
+        pressure_inc1, pressure_inc2 = pressure_inc1.rewrap(p1), pressure_inc2.rewrap(p2)
     pressure = pressure + pressure_inc1 + pressure_inc2                             # :75
 
     if full_output:
-        grid = lambda t: faces_to_grid(t, geom, velocity.box, velocity.extrapolation).staggered_tensor()
+        grid = (lambda t: t) if sh is not None else (lambda t: faces_to_grid(t, geom, velocity.box, velocity.extrapolation).staggered_tensor())
         return velocity_s3, pressure, pressure_inc1, pressure_inc2, matrix_values, column_indices, row_pointers, \
             grid(star), grid(s2), Aflat, implicit_rhs, grid(star), grid(s3), v1div, Lap1, Lap2, warn
     return velocity_s3, pressure, warn

@@ -90,29 +90,43 @@ _scalar_constants = {}
 
 
 def assemble_from_padded(vel_pad, nx, ny, dx_yx, per_x, per_y, dirichlet_mask_flat, active_mask, viscosity, no_slip_wall_mask, beta,
-                         pattern=None, sharding=None):
+                         sharding=None):
     """The CentralDifferenceMatrixCsr call of advection_matrix_cuda (piso_tf.py:95-123) on an already padded, flattened
     velocity.  Returns (matrix_values, row_pointers, column_indices, A_flat, matrix_nnz).
-    pattern = (col_indices, row_pointers) of the whole grid (slab-decomposed step, sharding.py): the launch assembles this
-    rank's rows only, rewrites their part of the pattern with the same numbers, and values / diagonal elsewhere are zero."""
+    sharding (slab-decomposed step, sharding.py): every array holds the rank's STORED rows; the launch assembles the rank's own rows
+    (values and diagonal of the halo rows stay zero until the caller's exchange); the pattern of all stored rows - geometry - is
+    assembled once per sharding (a pattern-only launch) and shared by every step."""
     dev = vel_pad.device
-    if (pattern is None) != (sharding is None):
-        raise ValueError("assemble_from_padded: a slab-decomposed assembly needs both the grid's pattern and the sharding")
-    N.use_window(sharding)
     dx = dx_yx
     grid_spacing = np.array([dx[1], dx[0]], dtype=np.float32)               # :96
     cell_area = (np.prod(dx) / np.array([dx[1], dx[0]], dtype=np.float32)).astype(np.float32)   # :97
-    nnz_u, nnz_v = C.c_int(0), C.c_int(0)
-    N.lib.piso_csr_nnz(nx, ny, int(per_x), int(per_y), C.byref(nnz_u), C.byref(nnz_v))
-    n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
-    nnz = nnz_u.value + nnz_v.value
-    if pattern is None:
+    if sharding is None:
+        nnz_u, nnz_v = C.c_int(0), C.c_int(0)
+        N.lib.piso_csr_nnz(nx, ny, int(per_x), int(per_y), C.byref(nnz_u), C.byref(nnz_v))
+        nnz_u, nnz_v = nnz_u.value, nnz_v.value
+        n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
+        mask_elems = (nx + 2) * (ny + 2)
+    else:
+        sz = sharding.sizes(per_x, per_y)
+        nnz_u, nnz_v, n_u, n_v = sz["nnz_u"], sz["nnz_v"], sharding.n_u, sharding.n_v
+        mask_elems = (nx + 2) * sz["mask_rows"]
+    nnz = nnz_u + nnz_v
+    if sharding is None:
         csr_val = torch.empty(nnz, dtype=torch.float32, device=dev)
         csr_col = torch.empty(nnz, dtype=torch.int32, device=dev)
         csr_row = torch.empty(n_u + n_v + 2, dtype=torch.int32, device=dev)
         diag = torch.empty(n_u + n_v, dtype=torch.float32, device=dev)
     else:
-        csr_col, csr_row = pattern
+        if sharding.pattern is None:
+            csr_col = torch.zeros(nnz, dtype=torch.int32, device=dev)
+            csr_row = torch.zeros(n_u + n_v + 2, dtype=torch.int32, device=dev)
+            st = N.lib.piso_assemble_csr_slab(None, None, N.ptr(csr_col), N.ptr(csr_row), None, None, None, None, 0, nx, ny, int(per_x), int(per_y),
+                                              C.c_float(cell_area[0]), C.c_float(cell_area[1]), C.c_float(grid_spacing[0]),
+                                              C.c_float(grid_spacing[1]), None, C.c_float(0.0), N.stream_ptr(), sharding.slab_ptr, 1)
+            N.check(st, "piso_assemble_csr_slab (pattern)")
+            sharding.set_pattern(csr_col, csr_row, nnz_u)
+            sharding.nnz = (nnz_u, nnz_v)
+        csr_col, csr_row = sharding.pattern
         csr_val = torch.zeros(nnz, dtype=torch.float32, device=dev)
         diag = torch.zeros(n_u + n_v, dtype=torch.float32, device=dev)
     if isinstance(viscosity, (int, float, np.floating, np.integer)):
@@ -130,15 +144,18 @@ def assemble_from_padded(vel_pad, nx, ny, dx_yx, per_x, per_y, dirichlet_mask_fl
         raise ValueError("viscosity field must have n_u + n_v entries (u first)")
     dmask = dirichlet_mask_flat if dirichlet_mask_flat.dtype == torch.uint8 else dirichlet_mask_flat.ne(0).to(torch.uint8)
     act = as_tensor(active_mask, dtype=torch.float32, device=dev).reshape(-1).contiguous()
-    if act.numel() != (nx + 2) * (ny + 2):
+    if act.numel() != mask_elems:
         raise ValueError("active_mask must have shape [1, Ny+2, Nx+2, 1]")
-    st = N.lib.piso_assemble_csr(N.ptr(vel_pad), N.ptr(csr_val), N.ptr(csr_col), N.ptr(csr_row), N.ptr(diag),
-                                 N.ptr(dmask.contiguous()), N.ptr(act), N.ptr(visc), is_field, nx, ny, int(per_x),
-                                 int(per_y), C.c_float(cell_area[0]), C.c_float(cell_area[1]),
-                                 C.c_float(grid_spacing[0]), C.c_float(grid_spacing[1]),
-                                 N.ptr(no_slip_wall_mask), C.c_float(np.float32(beta)), N.stream_ptr())
-    N.check(st, "piso_assemble_csr")
-    return csr_val, csr_row, csr_col, diag, np.array([nnz_u.value, nnz_v.value])
+    args = (N.ptr(vel_pad), N.ptr(csr_val), N.ptr(csr_col), N.ptr(csr_row), N.ptr(diag),
+            N.ptr(dmask.contiguous()), N.ptr(act), N.ptr(visc), is_field, nx, ny, int(per_x),
+            int(per_y), C.c_float(cell_area[0]), C.c_float(cell_area[1]),
+            C.c_float(grid_spacing[0]), C.c_float(grid_spacing[1]),
+            N.ptr(no_slip_wall_mask), C.c_float(np.float32(beta)), N.stream_ptr())
+    if sharding is None:
+        N.check(N.lib.piso_assemble_csr(*args), "piso_assemble_csr")
+    else:
+        N.check(N.lib.piso_assemble_csr_slab(*(args + (sharding.slab_ptr, 0))), "piso_assemble_csr_slab")
+    return csr_val, csr_row, csr_col, diag, np.array([nnz_u, nnz_v])
 
 
 def advection_matrix_cuda(velocity, dirichlet_mask_flat, viscosity, beta=0, no_slip_wall_mask=None, bool_periodic=None,
@@ -163,30 +180,36 @@ class _CsrMatVec(torch.autograd.Function):
     gradient (they come from advection_matrix_cuda), the vector's gradient is the transpose product."""
 
     @staticmethod
-    def forward(ctx, x_flat, values, row_ptr, col_indices, nx, ny, sharding=None):
+    def _product(values, row_ptr, col_indices, x, y, nx, ny, transpose, sharding, periodic_xy):
+        if sharding is None:
+            N.check(N.lib.piso_csr_matvec_f32(N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(x), N.ptr(y),
+                                              nx, ny, transpose, N.stream_ptr()), "piso_csr_matvec")
+        else:
+            N.check(N.lib.piso_csr_matvec_f32_slab(N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(x), N.ptr(y), nx, ny,
+                                                   int(periodic_xy[0]), int(periodic_xy[1]), transpose, N.stream_ptr(), sharding.slab_ptr),
+                    "piso_csr_matvec_slab")
+
+    @staticmethod
+    def forward(ctx, x_flat, values, row_ptr, col_indices, nx, ny, sharding=None, periodic_xy=(False, False)):
         x_flat = x_flat.contiguous()
-        N.use_window(sharding)
         if sharding is not None:
             sharding.halo_faces(x_flat)                      # the product gathers x from the face rows around the slab
         y = (torch.zeros_like if sharding is not None else torch.empty_like)(x_flat)
-        N.check(N.lib.piso_csr_matvec_f32(N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(x_flat), N.ptr(y),
-                                          nx, ny, 0, N.stream_ptr()), "piso_csr_matvec")
+        _CsrMatVec._product(values, row_ptr, col_indices, x_flat, y, nx, ny, 0, sharding, periodic_xy)
         ctx.save_for_backward(values, row_ptr, col_indices)
-        ctx.meta = (nx, ny, sharding)
+        ctx.meta = (nx, ny, sharding, periodic_xy)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         values, row_ptr, col_indices = ctx.saved_tensors
-        nx, ny, sharding = ctx.meta
+        nx, ny, sharding, periodic_xy = ctx.meta
         dy = dy.contiguous()
-        N.use_window(sharding)
         if sharding is not None:
             dy = sharding.halo_faces(dy.clone())
         dx = (torch.zeros_like if sharding is not None else torch.empty_like)(dy)
-        N.check(N.lib.piso_csr_matvec_f32(N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(dy), N.ptr(dx),
-                                          nx, ny, 1, N.stream_ptr()), "piso_csr_matvec^T")
-        return dx, None, None, None, None, None, None
+        _CsrMatVec._product(values, row_ptr, col_indices, dy, dx, nx, ny, 1, sharding, periodic_xy)
+        return dx, None, None, None, None, None, None, None
 
 
 def explicit_H_csr(matrix_values, row_pointers, column_indices, velocity, staggered_shape, A, beta=0):

@@ -88,9 +88,10 @@ def multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol
     (every rank passes the full arrays and works on its rows; dot products are all-reduced inside the scalar kernels, the edge
     rows of the SpMV inputs travel through the mailboxes) and every rank returns the full solution."""
     if slab_comm is not None and slab_comm.world > 1:
-        from .distributed import multi_bicgstab_ilu_slab
-        return multi_bicgstab_ilu_slab(slab_comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn,
-                                       gather=not slab_comm.sharded)
+        from .distributed import multi_bicgstab_ilu_slab, multi_bicgstab_ilu_slab_local
+        if slab_comm.sharded:                # slab-decomposed STEP: every array holds the rank's stored rows (sharding.py)
+            return multi_bicgstab_ilu_slab_local(slab_comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn)
+        return multi_bicgstab_ilu_slab(slab_comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn)
     dt = values.dtype
     assert dt in (torch.float32, torch.float64)
     values, rhs, x0 = values.contiguous(), rhs.to(dt).contiguous(), x0.to(dt).contiguous()
@@ -295,12 +296,18 @@ class PoissonSolver(object):
 
 
 def laplace_matrix_native(nx, ny, active, accessible, a0_vfirst, dtype, sharding=None):
-    # (sharding - the slab-decomposed step - fills this rank's rows only: the others are zero, not uninitialised)
-    N.use_window(sharding)
-    L = (torch.zeros if sharding is not None else torch.empty)(nx * ny * 5, dtype=dtype, device=a0_vfirst.device)
-    fn = N.lib.piso_laplace_matrix_f64 if dtype == torch.float64 else N.lib.piso_laplace_matrix_f32
-    N.check(fn(nx, ny, N.ptr(active), N.ptr(accessible), N.ptr(a0_vfirst.contiguous()), N.ptr(L), N.stream_ptr()),
-            "piso_laplace_matrix")
+    """[ny nx][5] pressure matrix; sharding (the slab-decomposed step): masks and a0 hold the rank's stored rows, the matrix its
+    OWNED rows [nyl nx][5] - what the slab CG takes."""
+    if sharding is None:
+        L = torch.empty(nx * ny * 5, dtype=dtype, device=a0_vfirst.device)
+        fn = N.lib.piso_laplace_matrix_f64 if dtype == torch.float64 else N.lib.piso_laplace_matrix_f32
+        N.check(fn(nx, ny, N.ptr(active), N.ptr(accessible), N.ptr(a0_vfirst.contiguous()), N.ptr(L), N.stream_ptr()),
+                "piso_laplace_matrix")
+        return L
+    L = torch.empty(nx * sharding.nyl * 5, dtype=dtype, device=a0_vfirst.device)
+    fn = N.lib.piso_laplace_matrix_f64_slab if dtype == torch.float64 else N.lib.piso_laplace_matrix_f32_slab
+    N.check(fn(nx, ny, N.ptr(active), N.ptr(accessible), N.ptr(a0_vfirst.contiguous()), N.ptr(L), N.stream_ptr(), sharding.slab_ptr),
+            "piso_laplace_matrix_slab")
     return L
 
 
@@ -504,13 +511,14 @@ class PisoPressureSolverCudaCustom(PoissonSolver):
             # (L and div of a sharded step are valid on this rank's rows only: the one-GPU kernel on the whole grid would read garbage)
             raise N.PisoNativeError("the slab-decomposed pressure CG is fp64 only: a sharded step needs cast_to_double=True")
         if self.slab_comm is not None and self.slab_comm.world > 1 and L.dtype == torch.float64:
-            from .distributed import cg_solve_slab, slab_rows
-            if self.slab_comm.sharded:       # slab-decomposed STEP: L and div are valid on this rank's rows, the result stays there
-                x_loc, it = cg_solve_slab(self.slab_comm, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient,
-                                          residual_reset, gather=False)
-                j0, j1 = slab_rows(self.slab_comm.rank, self.slab_comm.world, ny)
-                x = torch.zeros(nx * ny, dtype=x_loc.dtype, device=x_loc.device)
-                x[j0 * nx:j1 * nx] = x_loc
+            from .distributed import cg_solve_slab, cg_solve_slab_local
+            if self.slab_comm.sharded:       # slab-decomposed STEP: L holds the rank's owned rows, div its stored rows; the result stays there
+                sh = self.slab_comm.step_sharding
+                d_loc = sh.owned_cells(div.reshape(-1).to(torch.float64)).reshape(-1).contiguous()
+                x_loc, it = cg_solve_slab_local(self.slab_comm, nx, sh.nyl, per_x, per_y, L, d_loc, accuracy, max_iterations, rank_deficient,
+                                                residual_reset, gather=False)
+                x = torch.zeros(sh.n_cells, dtype=x_loc.dtype, device=x_loc.device)
+                sh.owned_cells(x).copy_(x_loc.view(sh.nyl, nx))
                 return x, it
             return cg_solve_slab(self.slab_comm, nx, ny, per_x, per_y, L, div, accuracy, max_iterations, rank_deficient,
                                  residual_reset)
@@ -525,13 +533,13 @@ class PisoPressureSolverCudaCustom(PoissonSolver):
     def solve_flat(self, a0_vfirst, divergence, simulation_physics, unrolling_step=0):
         """`solve` with the face coefficients already in the op's layout (flat, v faces first, :70); used by the fused step."""
         dt = torch.float64 if self.cast_to_double else torch.float32
-        ny, nx = int(divergence.shape[1]), int(divergence.shape[2])
+        sharding = getattr(simulation_physics, "sharding", None)
+        ny, nx = (int(divergence.shape[1]), int(divergence.shape[2])) if sharding is None else (sharding.ny, sharding.nx)
         dev = divergence.device
         a0 = a0_vfirst
-        active = simulation_physics.active_mask_tensor(dev)
-        accessible = simulation_physics.accessible_mask_tensor(dev)
         if self.laplace_rank_deficient is None:                                     # :84-87
-            a, c = accessible, active
+            # (looked at once per solver, on the host: the whole-grid masks of a sharded simulation never go to the device as a whole)
+            a, c = (as_tensor(m, dtype=torch.float32, device="cpu") for m in (simulation_physics.accessible_mask, simulation_physics.active_mask))
             prod = a * c + (1 - a) * (1 - c)
             prod = torch.prod(prod[0, 0, 1:-1, 0]) * torch.prod(prod[0, -1, 1:-1, 0]) * \
                 torch.prod(prod[0, 1:-1, 0, 0]) * torch.prod(prod[0, 1:-1, -1, 0])
@@ -539,10 +547,15 @@ class PisoPressureSolverCudaCustom(PoissonSolver):
         rank_def = self.laplace_rank_deficient
         if isinstance(rank_def, torch.Tensor):
             rank_def = bool(rank_def.reshape(-1)[0].item())
-        sharding = getattr(simulation_physics, "sharding", None)
         if (sharding is not None) != bool(self.slab_comm is not None and self.slab_comm.sharded):
             raise ValueError("pressure solve: the simulation's `sharding` and this solver's slab communicator disagree")
-        L = laplace_matrix_native(nx, ny, active.reshape(-1).contiguous(), accessible.reshape(-1).contiguous(), a0, dt, sharding)
+        if sharding is None:
+            active = simulation_physics.active_mask_tensor(dev).reshape(-1).contiguous()
+            accessible = simulation_physics.accessible_mask_tensor(dev).reshape(-1).contiguous()
+        else:
+            loc = sharding.sim_tensors(simulation_physics, dev)
+            active, accessible = loc["active"], loc["accessible"]
+        L = laplace_matrix_native(nx, ny, active, accessible, a0, dt, sharding)
         per_y, per_x = [bool(b) for b in simulation_physics.bool_periodic]          # given (y, x), flipped for the op (:95)
         pressure, iteration = _PressureSolveFn.apply(divergence, L, self, nx, ny, per_x, per_y, rank_def)
         self.solve_count = self.solve_count + .001

@@ -27,6 +27,19 @@ def zero_gradient_op(centered_data):
     return _ZeroGradient.apply(centered_data)
 
 
+def _staggered_like(ref, tensor):
+    """A field of `ref`'s kind around `tensor`: StaggeredGrid, or the SlabStaggered of a slab-decomposed simulation (sharding.py)."""
+    if hasattr(ref, "rewrap"):
+        return ref.rewrap(tensor)
+    return StaggeredGrid(tensor, ref.box, extrapolation=ref.extrapolation)
+
+
+def _centered_like(ref, data):
+    if hasattr(ref, "rewrap"):
+        return ref.rewrap(data)
+    return CenteredGrid(data, ref.box, ref.extrapolation)
+
+
 def unroll_piso_steps(velocity, pressure, dt, sim_physics, step_count=1, loss_influence_range=None, viscosity_field=None,
                       forcing_fn=None, dirichlet_update_fn=None):
     """The loop of run_piso_steps (:414-474) with hooks instead of dictionaries.
@@ -40,19 +53,19 @@ def unroll_piso_steps(velocity, pressure, dt, sim_physics, step_count=1, loss_in
     velocity_all_steps, pressure_all_steps = [], []
     for i in range(step_count):
         if i > 0 and loss_influence_range and i % loss_influence_range == 0:          # :436-438
-            velnew = StaggeredGrid(velnew.staggered_tensor().detach(), velnew.box, extrapolation=velnew.extrapolation)
-            pnew = CenteredGrid(zero_gradient_op(pnew.data), pnew.box, pnew.extrapolation)
+            velnew = _staggered_like(velnew, velnew.staggered_tensor().detach())
+            pnew = _centered_like(pnew, zero_gradient_op(pnew.data))
         if i > 0 and dirichlet_update_fn is not None:
             dirichlet_values = dirichlet_update_fn(i, sim_physics.dirichlet_values)
         forcing = forcing_fn(i, velnew, pnew) if forcing_fn is not None else None
-        pressure_inc1 = CenteredGrid(torch.zeros_like(pressure.data) + 5e-13, pressure.box, pressure.extrapolation)   # :456-457
-        pressure_inc2 = CenteredGrid(torch.zeros_like(pressure.data) + 1e-12, pressure.box, pressure.extrapolation)
+        pressure_inc1 = _centered_like(pressure, torch.zeros_like(pressure.data) + 5e-13)   # :456-457
+        pressure_inc2 = _centered_like(pressure, torch.zeros_like(pressure.data) + 1e-12)
         vel_piso, p_piso, warn[i] = piso_step(velnew, pnew, pressure_inc1, pressure_inc2, dt, sim_physics, dirichlet_values,
                                               viscosity_field=viscosity_field, forcing_term=forcing, unrolling_step=i)
         velocity_all_steps.append(vel_piso)
         pressure_all_steps.append(p_piso)
-        velnew = StaggeredGrid(vel_piso.staggered_tensor(), vel_piso.box, extrapolation=vel_piso.extrapolation)
-        pnew = CenteredGrid(p_piso.data, p_piso.box, p_piso.extrapolation)
+        velnew = _staggered_like(vel_piso, vel_piso.staggered_tensor())
+        pnew = _centered_like(p_piso, p_piso.data)
     return velocity_all_steps, pressure_all_steps, velnew, pnew, warn
 
 

@@ -40,6 +40,28 @@ extern "C" {
 
 typedef void* piso_stream_t;
 
+/* One rank's part of a grid cut into y-slabs (the slab-decomposed STEP; no counterpart in the reference).  The *_slab
+ * twin of an entry point takes the same arguments as the entry point itself - nx, ny and every index rule are the WHOLE grid's -
+ * plus this struct; its arrays hold the rank's rows only (LOCAL storage; round 5 - there is no process-wide row window any more):
+ *   cell arrays, u faces   the ring rows [row_begin - 2, row_end + 2) (mod ny_global), row_end - row_begin + 4 of them
+ *   v faces                the ring rows [row_begin - 3, row_end + 3) of the ring v[0] .. v[ny - 1], v[ny] (the duplicate row),
+ *                          row_end - row_begin + 6 of them; flat face vectors: the stored u rows followed by the stored v rows
+ *                          (v-first vectors: v then u)
+ *   padded cell masks      rows [row_begin, row_begin + (row_end - row_begin) + 3) of the [ny + 2] padded rows (no ring)
+ *   padded velocities      padded u rows [row_begin, row_end + 2), then padded v rows [row_begin, row_end + 3)
+ *   CSR                    the rows of the stored face rows (u rows, then v rows) in stored order; row pointers
+ *                          [stored u rows (nx + 1) + 1][stored v rows nx + 1] are offsets into the stored value / column arrays of
+ *                          each component; column indices keep the whole grid's numbering (component-local row numbers)
+ *   pressure matrix, CG    the owned rows only ([row_end - row_begin][nx][5]; what piso_cg_solve_slab_* takes)
+ * A launch writes the OWNED rows (cells / u rows [row_begin, row_end), v rows [row_begin, row_end + owns_last_face_row)) and reads
+ * the stored rows around them, which the caller fills with piso_comm_exchange (element segments of the stored arrays).
+ * Constraints: 4 <= row_end - row_begin <= ny_global - 6. */
+typedef struct piso_slab {
+  int ny_global;              /* cell rows of the whole grid (must equal the entry point's ny) */
+  int row_begin, row_end;     /* owned cell rows */
+  int owns_last_face_row;     /* the last slab also owns the duplicate face row v[ny] */
+} piso_slab_t;
+
 /* Library / build information. */
 const char* piso_version(void);
 const char* piso_last_error_string(void);
@@ -78,6 +100,16 @@ int piso_assemble_csr(const float* vel_pad, float* csr_val, int* csr_col, int* c
                       const uint8_t* dirichlet, const float* active, const float* viscosity, int viscosity_is_field,
                       int nx, int ny, int periodic_x, int periodic_y, float cell_area_x, float cell_area_y,
                       float spacing_x, float spacing_y, const uint8_t* no_slip, float beta, piso_stream_t stream);
+/* one rank's rows (piso_slab_t).  pattern_only != 0: column indices and row pointers of ALL stored rows (owned and halo: the pattern is
+ * geometry), no values - called once per set-up; pattern_only == 0: values, columns, row pointers and diag of the OWNED rows. */
+int piso_assemble_csr_slab(const float* vel_pad, float* csr_val, int* csr_col, int* csr_rowptr, float* diag,
+                           const uint8_t* dirichlet, const float* active, const float* viscosity, int viscosity_is_field,
+                           int nx, int ny, int periodic_x, int periodic_y, float cell_area_x, float cell_area_y,
+                           float spacing_x, float spacing_y, const uint8_t* no_slip, float beta, piso_stream_t stream,
+                           const piso_slab_t* slab, int pattern_only);
+/* sizes of a rank's stored arrays (piso_slab_t): out8 = {stored u rows, stored v rows, stored u faces, stored v faces, stored CSR
+ * entries of the u matrix, of the v matrix, stored mask rows, elements of the stored padded velocities} */
+int piso_slab_sizes(const piso_slab_t* slab, int nx, int ny, int periodic_x, int periodic_y, int* out8);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * ILU(0)-preconditioned BiCGStab on the u and v matrices (both components advance in the same launches).
@@ -107,6 +139,8 @@ int piso_multi_bicgstab_ilu_f64(const double* csr_val, const int* csr_rowptr, co
  * (diffpiso/piso_helpers.py:209-223 uses tf.gather/segment_sum for it). */
 int piso_csr_matvec_f32(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* x, float* y,
                         int nx, int ny, int transpose, piso_stream_t stream);
+int piso_csr_matvec_f32_slab(const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* x, float* y,
+                             int nx, int ny, int periodic_x, int periodic_y, int transpose, piso_stream_t stream, const piso_slab_t* slab);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused stencil glue of the step on the flat "u-first" face layout, forward and reverse mode (csrc/glue.hip).  Replaces the
@@ -140,6 +174,26 @@ int piso_h_contribution(const float* m_delta, const float* delta, const float* a
                         int ny, piso_stream_t stream);
 int piso_h_contribution_adjoint(const float* d_h, const float* d_h_over_bma, const float* a_flat, float beta, float* d_m_delta,
                                 float* d_delta, int nx, int ny, piso_stream_t stream);
+/* the same on one rank's rows (piso_slab_t: what the arrays hold, which rows a launch writes) */
+int piso_pad_velocity_slab(const float* vel_flat, float* vel_pad, int nx, int ny, int periodic_x, int periodic_y, piso_stream_t stream,
+                           const piso_slab_t* slab);
+int piso_a0_vfirst_slab(const float* a_flat, float* a0_vfirst, int nx, int ny, float beta, float dx_factor, piso_stream_t stream,
+                        const piso_slab_t* slab);
+int piso_face_forward_slab(int mode, int nx, int ny, const int* pad_modes, float dxdy, float hx, float hy, float beta, const float* p,
+                           const float* accessible, const float* a_flat, const float* in0, const float* in1, const float* in2,
+                           const uint8_t* dirichlet, float* out0, float* out1, piso_stream_t stream, const piso_slab_t* slab);
+int piso_face_backward_slab(int mode, int nx, int ny, const int* pad_modes, float dxdy, float hx, float hy, float beta,
+                            const float* accessible, const float* a_flat, const uint8_t* dirichlet, const float* d_out0,
+                            const float* d_out1, float* d_in0, float* d_in1, float* d_in2, float* d_p, piso_stream_t stream,
+                            const piso_slab_t* slab);
+int piso_divergence_slab(const float* faces, float* div, int nx, int ny, float dxdy, float hx, float hy, piso_stream_t stream,
+                         const piso_slab_t* slab);
+int piso_divergence_adjoint_slab(const float* d_div, float* d_faces, int nx, int ny, int periodic_x, int periodic_y, float dxdy, float hx,
+                                 float hy, piso_stream_t stream, const piso_slab_t* slab);
+int piso_h_contribution_slab(const float* m_delta, const float* delta, const float* a_flat, float beta, float* h, float* h_over_bma,
+                             int nx, int ny, piso_stream_t stream, const piso_slab_t* slab);
+int piso_h_contribution_adjoint_slab(const float* d_h, const float* d_h_over_bma, const float* a_flat, float beta, float* d_m_delta,
+                                     float* d_delta, int nx, int ny, piso_stream_t stream, const piso_slab_t* slab);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Pressure matrix.  Replaces LaplaceMatrixKernelLauncher (CUDAsrc/pressure_solve_op.cc:78-84,
@@ -149,6 +203,11 @@ int piso_laplace_matrix_f64(int nx, int ny, const float* active, const float* fl
                             double* laplace, piso_stream_t stream);
 int piso_laplace_matrix_f32(int nx, int ny, const float* active, const float* fluid, const float* a0_vfirst,
                             float* laplace, piso_stream_t stream);
+/* one rank's OWNED rows: laplace [(row_end - row_begin) nx][5], masks and a0_vfirst as piso_slab_t stores them */
+int piso_laplace_matrix_f64_slab(int nx, int ny, const float* active, const float* fluid, const float* a0_vfirst,
+                                 double* laplace, piso_stream_t stream, const piso_slab_t* slab);
+int piso_laplace_matrix_f32_slab(int nx, int ny, const float* active, const float* fluid, const float* a0_vfirst,
+                                 float* laplace, piso_stream_t stream, const piso_slab_t* slab);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Pressure CG.  Replaces LaunchPressureKernel (CUDAsrc/pressure_solve_op.cc:48-76,
@@ -263,18 +322,14 @@ int piso_leaky_relu_backward(const float* grad_out, const float* out, float* gra
 int piso_comm_peer_create(int rank, int world, int row_capacity, void** comm_out, void* ipc_handle64_out);
 int piso_comm_peer_connect(void* comm, const void* ipc_handles64_all_ranks);
 int piso_comm_stats(void* comm, long long* out6);
-/* The slab-decomposed STEP (new design, SURVEY.md 8e: assembly, stencil glue and Laplacian on the rows of the rank's y-slab).
- * piso_set_row_window(j0, j1, owns_last): from now on piso_assemble_csr, piso_pad_velocity, piso_a0_vfirst, piso_face_forward /
- * _backward, piso_divergence(_adjoint), piso_h_contribution(_adjoint), piso_laplace_matrix_* and piso_csr_matvec_f32 work on the
- * cell rows [j0, j1) of the GLOBALLY indexed arrays only (u rows [j0, j1), v rows [j0, j1 + owns_last)); (-1, -1, 0) = whole
- * grid.  Process-wide (one process per GPU).  piso_get_row_window returns 1 if a window is set.
+/* The slab-decomposed STEP (new design): the *_slab twins of piso_assemble_csr, piso_pad_velocity, piso_a0_vfirst,
+ * piso_face_forward / _backward, piso_divergence(_adjoint), piso_h_contribution(_adjoint), piso_laplace_matrix_* and piso_csr_matvec_f32
+ * (declared next to their entry points; piso_slab_t above says what the arrays hold) work on one rank's rows.
  * piso_comm_exchange fills halo rows: msgs28 = 4 x {count <= 3, off[3], len[3]} element segments of `vec` {sent to the upper
  * neighbour, sent to the lower, received from the lower, received from the upper} (ring neighbours); dtype 0 float, 1 double,
  * 2 int32; a no-op on one rank.  Peer transport: one launch, the elements cross xGMI as 8-byte words written into the consumer's
  * mailbox.  RCCL transport: grouped ncclSend / ncclRecv of the segments on the stream, straight from / into `vec`.
  * piso_comm_check: has a wait on a peer given up (agreed over the ranks; peer transport - RCCL has no bounded waits)? */
-int piso_set_row_window(int row_begin, int row_end, int owns_last_face_row);
-int piso_get_row_window(int* row_begin, int* row_end, int* owns_last_face_row);
 int piso_comm_exchange(void* comm, void* vec, int dtype, const int* msgs28, piso_stream_t stream);
 int piso_comm_check(void* comm, piso_stream_t stream);
 /* Slab-decomposed ILU(0)-BiCGStab (either transport): same arguments as piso_multi_bicgstab_ilu_*, all arrays FULL on every rank
@@ -293,6 +348,18 @@ int piso_multi_bicgstab_ilu_slab_f64(void* comm, const double* csr_val, const in
                                      const double* x0, double* x_out, int nx, int ny, float tol, int max_it, int transpose,
                                      int band_rows, uint8_t* warning, int* iterations_out, void* workspace, size_t workspace_bytes,
                                      piso_stream_t stream);
+/* The same solver on LOCAL storage (the slab-decomposed step, round 5): csr_*, rhs, x0, x_out and the workspace hold the rank's stored
+ * rows only (piso_slab_t; the caller fills the halo rows of csr_val with piso_comm_exchange - the transposed solve gathers from them);
+ * nx, ny, periodic_* are the whole grid's.  x_out is written on the owned rows. */
+size_t piso_bicgstab_slab_workspace_bytes(int nx, int ny, int elem_size, const piso_slab_t* slab);
+int piso_multi_bicgstab_ilu_slab_local_f32(void* comm, const float* csr_val, const int* csr_rowptr, const int* csr_col, const float* rhs,
+                                           const float* x0, float* x_out, int nx, int ny, int periodic_x, int periodic_y, float tol, int max_it,
+                                           int transpose, int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
+                                           size_t workspace_bytes, piso_stream_t stream, const piso_slab_t* slab);
+int piso_multi_bicgstab_ilu_slab_local_f64(void* comm, const double* csr_val, const int* csr_rowptr, const int* csr_col, const double* rhs,
+                                           const double* x0, double* x_out, int nx, int ny, int periodic_x, int periodic_y, float tol, int max_it,
+                                           int transpose, int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
+                                           size_t workspace_bytes, piso_stream_t stream, const piso_slab_t* slab);
 int piso_comm_unique_id(void* id128);
 int piso_comm_create(const void* id128, int rank, int world, void** comm_out);
 int piso_comm_destroy(void* comm);

@@ -95,16 +95,17 @@ def test_slab_rows_rejects_uneven_split():
 
 
 def test_step_sharding_halo_messages_are_consistent():
-    """Host logic of the sharded step (diffpiso/sharding.py): for every pair of ring neighbours the segments a rank SENDS are the
-    segments its neighbour expects to RECEIVE (same offsets in the globally indexed vector, same lengths), the duplicate face row
-    v[ny] crosses the periodic seam with the last slab's rows, and the row window is what the kernels are told."""
-    import ctypes as C
-    import diffpiso._native as N
+    """Host logic of the sharded step (diffpiso/sharding.py, LOCAL storage): for every pair of ring neighbours the segments a rank SENDS
+    are the segments its neighbour expects to RECEIVE - the same lengths, and the same rows of the whole grid once each side's offsets
+    into its STORED arrays are mapped back; the duplicate face row v[ny] crosses the periodic seam with the last slab's rows; scatter
+    and owned_* are inverse to each other; the library computes the same sizes."""
+    import numpy as np
+    import torch
     from diffpiso.sharding import HALO, StepSharding
 
     class FakeComm(object):
         def __init__(self, rank, world):
-            self.rank, self.world, self.handle, self.sharded = rank, world, None, False
+            self.rank, self.world, self.handle, self.sharded, self.device = rank, world, None, False, torch.device("cpu")
 
     def msgs(arr):
         out = []
@@ -114,28 +115,63 @@ def test_step_sharding_halo_messages_are_consistent():
         return out        # to_upper, to_lower, from_lower, from_upper
 
     nx, ny = 12, 48
-    n_u = (nx + 1) * ny
-    try:
-        for world in (2, 4, 8):
-            sh = [StepSharding(FakeComm(r, world), nx, ny) for r in range(world)]
-            for r in range(world):
-                j0, j1, last = C.c_int(), C.c_int(), C.c_int()
-                # the row window is an attribute of every CALL (N.use_window names the sharding a kernel wrapper works for), not of
-                # the process: building a sharding does not touch it, naming one sets exactly its rows, naming none clears it
-                assert N.lib.piso_get_row_window(C.byref(j0), C.byref(j1), C.byref(last)) == 0
-                N.use_window(sh[r])
-                assert N.lib.piso_get_row_window(C.byref(j0), C.byref(j1), C.byref(last)) == 1
-                assert (j0.value, j1.value, last.value) == (r * ny // world, (r + 1) * ny // world, int(r == world - 1))
-                N.use_window(None)
-                assert N.lib.piso_get_row_window(C.byref(j0), C.byref(j1), C.byref(last)) == 0
-                up, lo = (r + 1) % world, (r - 1) % world
-                for kind in ("msgs_faces", "msgs_faces_vfirst", "msgs_cells"):
-                    mine, theirs_up, theirs_lo = msgs(getattr(sh[r], kind)), msgs(getattr(sh[up], kind)), msgs(getattr(sh[lo], kind))
-                    assert mine[0] == theirs_up[2], (world, r, kind)         # what I send up is what my upper neighbour receives from below
-                    assert mine[1] == theirs_lo[3], (world, r, kind)         # what I send down is what my lower neighbour receives from above
-            # the last slab sends its HALO last v rows AND the duplicate row v[ny] upwards (across the seam to rank 0)
-            top = msgs(sh[world - 1].msgs_faces)[0]
-            assert top[1] == (n_u + (ny - HALO) * nx, (HALO + 1) * nx)
-            assert msgs(sh[0].msgs_faces)[2][1] == top[1]
-    finally:
-        N.use_window(None)
+
+    def global_rows(sh, kind, segs):
+        """(component, whole-grid row) of every row a list of (offset, length) segments of a stored array covers"""
+        rows = []
+        for off, ln in segs:
+            if kind == "msgs_cells":
+                assert off % nx == 0 and ln % nx == 0
+                rows += [("c", (sh.cb + off // nx + k) % ny) for k in range(ln // nx)]
+                continue
+            first_u = kind == "msgs_faces"
+            n_first = sh.n_u if first_u else sh.n_v
+            comp = ("u" if first_u else "v") if off < n_first else ("v" if first_u else "u")
+            o = off if off < n_first else off - n_first
+            w = nx + 1 if comp == "u" else nx
+            assert o % w == 0 and ln % w == 0
+            base, period = (sh.cb, ny) if comp == "u" else (sh.vb, ny + 1)
+            rows += [(comp, (base + o // w + k) % period) for k in range(ln // w)]
+        return rows
+
+    for world in (2, 4, 8):
+        sh = [StepSharding(FakeComm(r, world), nx, ny) for r in range(world)]
+        for r in range(world):
+            up, lo = (r + 1) % world, (r - 1) % world
+            for kind in ("msgs_faces", "msgs_faces_vfirst", "msgs_cells"):
+                mine, theirs_up, theirs_lo = msgs(getattr(sh[r], kind)), msgs(getattr(sh[up], kind)), msgs(getattr(sh[lo], kind))
+                assert [n for _, n in mine[0]] == [n for _, n in theirs_up[2]] and [n for _, n in mine[1]] == [n for _, n in theirs_lo[3]]
+                # what I send up is what my upper neighbour receives from below, row for row of the whole grid; the same downwards
+                assert global_rows(sh[r], kind, mine[0]) == global_rows(sh[up], kind, theirs_up[2]), (world, r, kind)
+                assert global_rows(sh[r], kind, mine[1]) == global_rows(sh[lo], kind, theirs_lo[3]), (world, r, kind)
+                # what a rank sends are rows it owns; what it receives are rows it stores and does not own
+                own_u, own_v = range(sh[r].j0, sh[r].j1), range(sh[r].j0, sh[r].j1 + (1 if sh[r].last else 0))
+                for comp, j in global_rows(sh[r], kind, mine[0]) + global_rows(sh[r], kind, mine[1]):
+                    assert j in (own_v if comp == "v" else own_u)
+                for comp, j in global_rows(sh[r], kind, mine[2]) + global_rows(sh[r], kind, mine[3]):
+                    assert j not in (own_v if comp == "v" else own_u)
+        # the last slab sends its HALO last v rows AND the duplicate row v[ny] upwards (across the seam to rank 0)
+        top = global_rows(sh[world - 1], "msgs_faces", msgs(sh[world - 1].msgs_faces)[0])
+        assert [j for c, j in top if c == "v"] == [ny - 2, ny - 1, ny] and HALO == 2
+        # scatter / owned round trip: every face and cell of the whole grid is owned by exactly one rank, with its own value
+        st = np.arange((ny + 1) * (nx + 1) * 2, dtype=np.float32).reshape(1, ny + 1, nx + 1, 2)
+        cells = np.arange(ny * nx, dtype=np.float32).reshape(1, ny, nx, 1)
+        got_u, got_v, got_c = [], [], []
+        for r in range(world):
+            flat = sh[r].scatter_staggered(st)
+            assert flat.numel() == sh[r].n_faces
+            u, v = sh[r].owned_faces(flat)
+            got_u.append(u.numpy()); got_v.append(v.numpy())
+            got_c.append(sh[r].owned_cells(sh[r].scatter_cells(cells)).numpy())
+            # the stored rows next to the owned ones are the ring neighbours' (first slab below: v[ny - 2], v[ny - 1], v[ny])
+            vs = flat[sh[r].n_u:].view(sh[r].vr, nx).numpy()
+            np.testing.assert_array_equal(vs[0], st[0, (sh[r].j0 - 3) % (ny + 1), :nx, 0])
+            np.testing.assert_array_equal(vs[-1], st[0, (sh[r].j1 + 2) % (ny + 1), :nx, 0])
+        np.testing.assert_array_equal(np.concatenate(got_u), st[0, :ny, :, 1])
+        np.testing.assert_array_equal(np.concatenate(got_v), st[0, :, :nx, 0])
+        np.testing.assert_array_equal(np.concatenate(got_c), cells[0, :, :, 0])
+        for r in range(world):
+            z = sh[r].sizes(True, True)
+            assert z["mask_rows"] == sh[r].mr and z["nnz_u"] == 5 * sh[r].n_u and z["nnz_v"] == 5 * sh[r].n_v      # (periodic: 5 entries per row)
+            z = sh[r].sizes(False, False)
+            assert 0 < z["nnz_u"] <= 5 * sh[r].n_u and 0 < z["nnz_v"] <= 5 * sh[r].n_v
