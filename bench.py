@@ -157,21 +157,28 @@ def run_unrolled(P, steps, backward=True, clock=None, keep=None):
     clock (optional dict): 'fwd_s' / 'bwd_s' accumulate wall time with a device synchronisation between the two sweeps."""
     import torch
     import diffpiso as dp
-    vel_t = P["vel_t"].clone().requires_grad_(backward)
-    p_t = P["p_t"].clone().requires_grad_(backward)
     ext = dp.Material.extrapolation_mode(P["domain"].boundaries)
-    velocity = dp.StaggeredGrid(vel_t, P["domain"].box, extrapolation=ext)
-    pressure = dp.CenteredGrid(p_t, P["domain"].box, dp.pressure_extrapolation(P["domain"].boundaries))
+    p_ext = dp.pressure_extrapolation(P["domain"].boundaries)
+    sh = P.get("sharding")
+    if sh is None:
+        vel_t = P["vel_t"].clone().requires_grad_(backward)
+        p_t = P["p_t"].clone().requires_grad_(backward)
+        velocity = dp.StaggeredGrid(vel_t, P["domain"].box, extrapolation=ext)
+        pressure = dp.CenteredGrid(p_t, P["domain"].box, p_ext)
+    else:           # slab-decomposed step (local storage): the rank's stored rows of the fields, cut from the host copy of the box
+        vel_t = P["vel_loc"].clone().requires_grad_(backward)
+        p_t = P["p_loc"].clone().requires_grad_(backward)
+        velocity = sh.staggered_grid(vel_t, P["domain"].box, ext)
+        pressure = sh.centered_grid(p_t, P["domain"].box, p_ext)
     t0 = time.perf_counter()
     with torch.set_grad_enabled(backward):
         out = dp.run_piso_steps(velocity, pressure, P["domain"], None, {"dt": P["dt"], "dt_ratio": 1},
                                 {"step_count": steps, "loss_influence_range": steps + 1}, None, None, P["sim"], None, None, None)
         vn, warn = out[3], out[6]
-        sh = P.get("sharding")
         if sh is None:
             loss = 0.5 * (vn.staggered_tensor() ** 2).sum()
-        else:       # slab-decomposed step: L = 1/2 |u_K|^2 is the sum over the ranks of the part on their own face rows
-            loss = 0.5 * ((vn.staggered_tensor() * sh.owned_mask_staggered(vel_t.device)) ** 2).sum()
+        else:       # L = 1/2 |u_K|^2 is the sum over the ranks of the part on the face rows they own
+            loss = 0.5 * sh.owned_sum_of_squares(vn.staggered_tensor())
     if clock is not None:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -186,7 +193,7 @@ def run_unrolled(P, steps, backward=True, clock=None, keep=None):
     return vel_t.grad, float(loss.detach()), warn
 
 
-def bicgstab_fixed_work(P, n, iters=10, reps=3):
+def bicgstab_fixed_work(P, n, iters=10, reps=3, real=True):
     """Fixed-work run of the ILU(0)-BiCGStab on the benchmark's matrices: tol = 0 makes every iteration of both restart passes
     run on both components (no early-return launches), 2 * iters iterations per call; timed with events on the launch stream."""
     import torch
@@ -208,7 +215,7 @@ def bicgstab_fixed_work(P, n, iters=10, reps=3):
     best, its = None, (0, 0)
     for r in range(reps + 1):
         ev[0].record()
-        x, its = multi_bicgstab_ilu_native(-val, rp, col, rhs, x0, n, n, 0.0, iters, False, 0, warn)
+        x, its = multi_bicgstab_ilu_native(val, rp, col, rhs, x0, n, n, 0.0, iters, False, 0, warn, negate=True)
         ev[1].record()
         torch.cuda.synchronize()
         ms = ev[0].elapsed_time(ev[1])
@@ -217,56 +224,131 @@ def bicgstab_fixed_work(P, n, iters=10, reps=3):
     total_its = max(its)                      # iterations executed per component (two passes of `iters`)
     nbytes = rows * (BICG_BYTES_PER_ROW_ITER * total_its + 2 * BICG_BYTES_PER_ROW_ONCE)
     gbs = nbytes / (best * 1e-3) / 1e9
+    # the solve the step really runs: to the benchmark's tolerance (~3 iterations: set-up - conversion, factorisation, first residual -
+    # is then a quarter of it)
+    real_best, real_its = None, (0, 0)
+    for r in range(3 if real else 0):
+        ev[0].record()
+        x, real_its = multi_bicgstab_ilu_native(val, rp, col, rhs, x0, n, n, 1e-6, 100, False, 0, warn, negate=True)
+        ev[1].record()
+        torch.cuda.synchronize()
+        ms = ev[0].elapsed_time(ev[1])
+        real_best = ms if real_best is None else min(real_best, ms)
+    real_bytes = rows * (BICG_BYTES_PER_ROW_ITER * max(real_its) + BICG_BYTES_PER_ROW_ONCE)
+    real_best = real_best if real_best is not None else float("nan")
+    # fabric bytes of the fixed-work solve from the PMC passes of scripts/profile_bench.sh (same sources only)
+    pmc, pmc_src = measured_traffic(n, "bicgstab")
+    traffic = pmc["bytes_per_solve"] if pmc and pmc.get("iterations_per_solve") == total_its else None
     return {"bound": "hbm", "kernel": "piso_multi_bicgstab_ilu_f32: whole solve (u and v together), %d iterations per component, "
                                       "no early-return launches, host look every 2 iterations included" % total_its,
-            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_over_algorithmic": (traffic / nbytes) if traffic else None, "traffic_source": pmc_src,
             "ms_per_solve": best, "us_per_iteration": 1e3 * best / max(total_its, 1), "rows": rows,
-            "algorithmic_bytes_per_solve": nbytes, "bytes_per_row_iteration": BICG_BYTES_PER_ROW_ITER}
+            "algorithmic_bytes_per_solve": nbytes, "bytes_per_row_iteration": BICG_BYTES_PER_ROW_ITER,
+            "solve_to_1e-6": {"iterations": list(real_its), "ms": real_best, "algorithmic_GBs": real_bytes / (real_best * 1e-3) / 1e9,
+                              "frac": real_bytes / (real_best * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
 
-def slab_kernel_loopback(n, device, iters=3000):
+def slab_kernel_loopback(n, device, iters=2000):
     """N = 1 only, after the timed region: the SLAB instance of the persistent CG kernel (cg_persist1<..., SLAB>, the kernel of
-    the sharded N > 1 headline) in a ring of ONE rank - the edge rows of z' and the GPU's totals go through the rank's own
+    the sharded N > 1 headline) in a ring of ONE rank - the edge rows of z' and the XCD leaders' records go through the rank's own
     peer mailbox, so every slab-specific instruction runs, only the xGMI hop is local - next to the plain kernel on the same
-    system, same box, same fixed iteration count.  The ratio is the weak-scaling efficiency of the kernel before any hop."""
+    system, same box, same fixed iteration count.  The ratio is the weak-scaling efficiency of the kernel before any hop;
+    `latency_sweep` injects a hop: the XCD leaders' records leave 0 / 0.5 / 1 / 2 / 3 us late (option slab_hop_ticks), as they would
+    over a link of that latency - the kernel-level efficiency a real node can be expected to show, and the latency at which the
+    north star's 0.75 is lost.  Shapes: n x n (the slab of the N > 1 headline) and 4096 x 512 (one rank's slab of BASELINE config 5).
+    `rccl_two_kernel`: the same solve over the RCCL transport (ring of one; two kernels + two all-reduces + a send / recv per
+    iteration) - what a node that refuses hipIpc would run."""
     import torch
+    import diffpiso._native as N
     from diffpiso.distributed import SlabCommunicator, cg_solve_slab
     from diffpiso.solvers import cg_solve_native, laplace_matrix_native
-    g = torch.Generator(device="cpu")
-    g.manual_seed(11)
-    a0 = 0.5 + torch.rand(n * (n + 1) + (n + 1) * n, generator=g)
-    av, au = a0[:n * (n + 1)].view(n + 1, n), a0[n * (n + 1):].view(n, n + 1)
-    av[n] = av[0]
-    au[:, n] = au[:, 0]
-    ones = torch.ones((n + 2) * (n + 2), device=device)
-    L = laplace_matrix_native(n, n, ones, ones, a0.to(device), torch.float64)
-    b = torch.randn(n * n, generator=g, dtype=torch.float64).to(device)
-    b -= b.mean()
-    comm = SlabCommunicator(rank=0, world=1, device=device, transport="peer", row_capacity=n)
+
+    def system(nx, ny):
+        g = torch.Generator(device="cpu")
+        g.manual_seed(11)
+        a0 = 0.5 + torch.rand(nx * (ny + 1) + (nx + 1) * ny, generator=g)
+        av, au = a0[:nx * (ny + 1)].view(ny + 1, nx), a0[nx * (ny + 1):].view(ny, nx + 1)
+        av[ny] = av[0]
+        au[:, nx] = au[:, 0]
+        ones = torch.ones((ny + 2) * (nx + 2), device=device)
+        L = laplace_matrix_native(nx, ny, ones, ones, a0.to(device), torch.float64)
+        b = torch.randn(nx * ny, generator=g, dtype=torch.float64).to(device)
+        b -= b.mean()
+        return L, b
+
+    def timed(fn, k, reps=2):
+        best = None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn(k)
+            torch.cuda.synchronize()
+            us = 1e6 * (time.perf_counter() - t0) / k
+            best = us if best is None else min(best, us)
+        return best
+
+    def shape(nx, ny, sweep):
+        L, b = system(nx, ny)
+        comm = SlabCommunicator(rank=0, world=1, device=device, transport="peer", row_capacity=nx)
+        try:
+            plain_fn = lambda k: cg_solve_native(nx, ny, True, True, L, b, 1e-30, k, False, 1 << 30)
+            slab_fn = lambda k: cg_solve_slab(comm, nx, ny, True, True, L, b, 1e-30, k, False, 1 << 30)
+            xp, _ = plain_fn(100)
+            xs, _ = slab_fn(100)
+            plain = timed(plain_fn, iters)
+            out = {"grid": [ny, nx], "iterations_timed": iters, "us_per_iteration_plain_kernel": plain,
+                   "max_rel_diff_after_100_iterations": float((xs - xp).abs().max() / xp.abs().max())}
+            rows = []
+            for hop_us in sweep:
+                N.set_option("slab_hop_ticks", int(round(hop_us * 100)))
+                us = timed(slab_fn, iters)
+                rows.append({"injected_hop_us": hop_us, "us_per_iteration": us, "implied_efficiency": plain / us})
+            N.set_option("slab_hop_ticks", 0)
+            out["us_per_iteration_slab_kernel_ring_of_one"] = rows[0]["us_per_iteration"]
+            out["ratio_plain_over_slab"] = rows[0]["implied_efficiency"]
+            out["latency_sweep"] = rows
+            lost = [r["injected_hop_us"] for r in rows if r["implied_efficiency"] < 0.75]
+            kept = [r for r in rows if r["implied_efficiency"] >= 0.75]
+            if lost and kept:       # linear between the last point above 0.75 and the first below
+                a, c = kept[-1], [r for r in rows if r["injected_hop_us"] == lost[0]][0]
+                t = (a["implied_efficiency"] - 0.75) / max(a["implied_efficiency"] - c["implied_efficiency"], 1e-12)
+                out["hop_us_at_which_0.75_is_lost"] = a["injected_hop_us"] + t * (c["injected_hop_us"] - a["injected_hop_us"])
+            else:
+                out["hop_us_at_which_0.75_is_lost"] = None if not lost else 0.0
+            st = comm.stats()
+            out.update(persistent_slab_iterations=st["persistent_iterations"], persistent_fallbacks=st["persistent_fallbacks"],
+                       verification_failures=st["verification_failures"])
+            return out
+        finally:
+            N.set_option("slab_hop_ticks", 0)
+            comm.close()
+
+    out = shape(n, n, (0.0, 0.5, 1.0, 2.0, 3.0))
+    out["note"] = ("whole solves (set-up, first iteration and the true-residual check included); the hop to the mailbox is local, "
+                   "`injected_hop_us` delays the records that cross GPUs by that much")
     try:
-        res = {}
-        for key, fn in (("plain", lambda k: cg_solve_native(n, n, True, True, L, b, 1e-30, k, False, 1 << 30)),
-                        ("slab", lambda k: cg_solve_slab(comm, n, n, True, True, L, b, 1e-30, k, False, 1 << 30))):
-            x, _ = fn(100)
-            res[key + "_x"] = x
-            best = None
-            for _ in range(2):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                fn(iters)
-                torch.cuda.synchronize()
-                us = 1e6 * (time.perf_counter() - t0) / iters
-                best = us if best is None else min(best, us)
-            res[key] = best
-        st = comm.stats()
-        diff = float((res["slab_x"] - res["plain_x"]).abs().max() / res["plain_x"].abs().max())
-        return {"grid": [n, n], "iterations_timed": iters, "us_per_iteration_slab_kernel_ring_of_one": res["slab"],
-                "us_per_iteration_plain_kernel": res["plain"], "ratio_plain_over_slab": res["plain"] / res["slab"],
-                "max_rel_diff_after_100_iterations": diff, "persistent_slab_iterations": st["persistent_iterations"],
-                "persistent_fallbacks": st["persistent_fallbacks"], "verification_failures": st["verification_failures"],
-                "note": "whole solves (set-up, first iteration and the true-residual check included); the hop to the mailbox is local"}
-    finally:
-        comm.close()
+        out["config5_slab_4096x512"] = shape(4096, 512, (0.0, 0.5, 1.0, 2.0, 3.0))
+    except Exception as e:
+        out["config5_slab_4096x512"] = {"error": repr(e)}
+    # the RCCL-only node: two-kernel slab iteration over the library's RCCL communicator (ring of one, slab_force)
+    try:
+        L, b = system(n, n)
+        rc = SlabCommunicator(rank=0, world=1, device=device, transport="rccl")
+        try:
+            N.set_option("slab_force", 1)
+            k = 300
+            fn = lambda kk: cg_solve_slab(rc, n, n, True, True, L, b, 1e-30, kk, False, 1 << 30)
+            fn(20)
+            us = timed(fn, k)
+            out["rccl_two_kernel"] = {"us_per_iteration": us, "iterations_timed": k, "ratio_to_mailbox_slab_kernel": us / out["us_per_iteration_slab_kernel_ring_of_one"],
+                                      "note": "K1 + 3-double ncclAllReduce + K2 + 3-double ncclAllReduce + one-row send / recv per iteration, stream-ordered"}
+        finally:
+            N.set_option("slab_force", 0)
+            rc.close()
+    except Exception as e:
+        out["rccl_two_kernel"] = {"error": repr(e)}
+    return out
 
 
 def cpu_baseline(P, n, tol, cg_iters_per_step, bicg_solves_per_step=2, sample_iters=240):
@@ -650,11 +732,12 @@ def main():
     decomp = "replicas" if auto else args.decomp
     slab_weak = world > 1 and decomp == "slab-weak"
     ny_grid = n * world if slab_weak else (args.grid_ny if args.grid_ny > 0 else n)
-    P = build_problem(n, device, args.tol, args.max_iterations, args.residual_reset, ny=ny_grid)
     slab = world > 1 and decomp in ("slab", "slab-weak")
+    # (a sharded run builds the box on the HOST - every rank the same seeded arrays - and sends only its own rows to its GPU)
+    P = build_problem(n, torch.device("cpu") if slab else device, args.tol, args.max_iterations, args.residual_reset, ny=ny_grid)
     if args.perturb_input > 0:
         gen_ = torch.Generator(device="cpu").manual_seed(99)
-        P["vel_t"] = P["vel_t"] * (1.0 + args.perturb_input * torch.randn(P["vel_t"].shape, generator=gen_).to(device))
+        P["vel_t"] = P["vel_t"] * (1.0 + args.perturb_input * torch.randn(P["vel_t"].shape, generator=gen_).to(P["vel_t"].device))
     if args.unshifted:
         P["ps"].laplace_rank_deficient = False
     if args.lin_tol > 0:
@@ -686,6 +769,9 @@ def main():
             raise RuntimeError("the %s transport could not be set up: %s" % (args.transport, comm_err))
         P["lin"].slab_comm = P["ps"].slab_comm       # the ILU(0)-BiCGStab is cut into the same slabs (dot products all-reduced)
         P["sharding"] = P["sim"].sharding = StepSharding(P["ps"].slab_comm, n, ny_grid)   # ... and so is everything else of the step
+        P["vel_loc"] = P["sharding"].scatter_staggered(P["vel_t"], device=device)          # the rank's stored rows (local storage)
+        P["p_loc"] = P["sharding"].scatter_cells(P["p_t"], device=device)
+        del P["vel_t"], P["p_t"]                                                           # (host copies of the whole box)
 
     def barrier():
         torch.cuda.synchronize()
@@ -729,12 +815,17 @@ def main():
     elapsed = time.perf_counter() - t0
     if keep:
         sh_ = P.get("sharding")
-        j0, j1, last = (sh_.j0, sh_.j1, 1 if sh_.last else 0) if sh_ is not None else (0, ny_grid, 1)
         os.makedirs(args.dump_fields, exist_ok=True)
-        np.savez(os.path.join(args.dump_fields, "rank%d.npz" % rank), j0=j0, j1=j1, last=last,
-                 u_v=keep["u"][0, j0:j1 + last, :, 0].cpu().numpy(), u_u=keep["u"][0, j0:j1, :, 1].cpu().numpy(), p=keep["p"][0, j0:j1, :, 0].cpu().numpy(),
-                 du_v=keep["du"][0, j0:j1 + last, :, 0].cpu().numpy(), du_u=keep["du"][0, j0:j1, :, 1].cpu().numpy(),
-                 dp=keep["dp"][0, j0:j1, :, 0].cpu().numpy())
+        if sh_ is not None:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+            from sharded_worker import owned_rows_npz
+            owned_rows_npz(os.path.join(args.dump_fields, "rank%d.npz" % rank), sh_, keep["u"], keep["p"], keep["du"], keep["dp"])
+        else:
+            j0, j1, last = 0, ny_grid, 1
+            np.savez(os.path.join(args.dump_fields, "rank%d.npz" % rank), j0=j0, j1=j1, last=last,
+                     u_v=keep["u"][0, j0:j1 + last, :, 0].cpu().numpy(), u_u=keep["u"][0, j0:j1, :, 1].cpu().numpy(), p=keep["p"][0, j0:j1, :, 0].cpu().numpy(),
+                     du_v=keep["du"][0, j0:j1 + last, :, 0].cpu().numpy(), du_u=keep["du"][0, j0:j1, :, 1].cpu().numpy(),
+                     dp=keep["dp"][0, j0:j1, :, 0].cpu().numpy())
         del keep
     ms_sum = (C.c_double * 4)()
     cnt = (C.c_longlong * 4)()
@@ -758,7 +849,8 @@ def main():
                         "persistent_slab_iterations": st_["persistent_iterations"], "persistent_fallbacks": st_["persistent_fallbacks"],
                         "slab_solves_verified_against_true_residual": st_["solves_verified"], "verification_failures": st_["verification_failures"],
                         "what_is_sharded": "assembly, padding, stencil glue (forward + reverse mode), Laplacian, CSR product, ILU(0)-BiCGStab, "
-                                           "pressure CG: every kernel of the step works on the rank's rows; nothing is all-gathered"}
+                                           "pressure CG: every kernel of the step works on the rank's rows; nothing is all-gathered",
+                        "storage": "local: every tensor of the step, the tape and the solvers' workspaces hold the rank's rows plus halo rows (1 / ranks of the box)"}
 
     out = None
     if rank == 0:

@@ -119,7 +119,11 @@ __device__ __forceinline__ bool csr_find(const int* __restrict__ rp, const int* 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __restrict__ val_all,
                                                      const int* __restrict__ rp_all, const int* __restrict__ col_all,
-                                                     const T* __restrict__ x0, int transpose) {
+                                                     const T* __restrict__ x0, int transpose_flags) {
+  // transpose_flags: bit 0 = gather the transposed coefficients (adjoint solve), bit 1 = the matrix is -val (piso_tf.py:41 hands the
+  // solver `-matrix_values`: negating here, in the one pass that reads the values anyway, saves the caller a pass over the array)
+  const int transpose = transpose_flags & 1;
+  const T sgn = (transpose_flags & 2) ? (T)-1 : (T)1;
   const int c = blockIdx.y;
   const Geo& g = a.g;
   const int W = g.W[c], H = g.H[c], n = g.n[c];
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
     const int rl = a.rpx(c, row);
     for (int q = rp[rl]; q < rp[rl + 1]; ++q) {
       const int cq = col[q];
-      const T vq = val[q];
+      const T vq = sgn * val[q];
       nan_seen |= is_nan(vq);
       int kind;   // 0..4 near slots, 5 exception
       if (cq == row) kind = 2;
@@ -165,10 +169,10 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
     }
     if (transpose) {
       T vq;
-      if (i >= 1 && csr_find(rp, col, val, row - 1, row, &vq, M, c)) w = vq;            // A(k-1, k)
-      if (i <= W - 2 && csr_find(rp, col, val, row + 1, row, &vq, M, c)) e = vq;        // A(k+1, k)
-      if (j >= 1 && csr_find(rp, col, val, row - W, row, &vq, M, c)) s = vq;            // A(k-W, k)
-      if (j <= H - 2 && csr_find(rp, col, val, row + W, row, &vq, M, c)) nn = vq;       // A(k+W, k)
+      if (i >= 1 && csr_find(rp, col, val, row - 1, row, &vq, M, c)) w = sgn * vq;            // A(k-1, k)
+      if (i <= W - 2 && csr_find(rp, col, val, row + 1, row, &vq, M, c)) e = sgn * vq;        // A(k+1, k)
+      if (j >= 1 && csr_find(rp, col, val, row - W, row, &vq, M, c)) s = sgn * vq;            // A(k-W, k)
+      if (j <= H - 2 && csr_find(rp, col, val, row + W, row, &vq, M, c)) nn = sgn * vq;       // A(k+W, k)
       if (fo >= 0) {
         const int cand[4] = {row - g.xw[c], row + g.xw[c], row - g.yw[c], row + g.yw[c]};
 #pragma unroll
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
           const int m = cand[q];
           if (m < 0 || m >= n || m == row - 1 || m == row + 1 || m == row - W || m == row + W || m == row) continue;
           if (csr_find(rp, col, val, m, row, &vq, M, c)) {
-            if (ne < kExcSlots) { ec[ne] = m; ev[ne] = vq; ++ne; } else bad = true;
+            if (ne < kExcSlots) { ec[ne] = m; ev[ne] = sgn * vq; ++ne; } else bad = true;
           }
         }
       }
@@ -878,7 +882,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   if (need > 32) { set_error_msg("piso_multi_bicgstab_ilu: nx > 8191 not supported"); return PISO_ERR_INVALID_ARG; }
 
   bi_init_scalars<T><<<1, 256, 0, stream>>>(a);
-  bi_convert<T><<<grid_v, kBlock, 0, stream>>>(a, val, rowptr, col, x0, transpose ? 1 : 0);
+  bi_convert<T><<<grid_v, kBlock, 0, stream>>>(a, val, rowptr, col, x0, transpose & 3);
   if (slab && rccl) { const int rc = comm_rccl_allreduce_i32(pc, a.flags, 2, stream); if (rc != PISO_OK) return rc; }   // (sums: non-zero = set)
   else if (slab) bi_flags_allreduce<T><<<1, 64, 0, stream>>>(a, next_seq());
   if (need <= 1) launch_factor<T, 1>(a, grid_b, stream);

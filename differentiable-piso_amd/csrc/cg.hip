@@ -89,6 +89,13 @@ static size_t cg_workspace_bytes(int nx_in, int ny_in) {
   return b + 4096;
 }
 
+// Which (state, coefficient, matrix) combinations have a 16-row instance at all: the ones that keep their registers.  fp32 state
+// without a symmetric matrix with rebuilt diagonals (26-84 spilled vector registers) and fp64 COEFFICIENTS (a general matrix: 8
+// spilled vector registers) are tiled with regions of 4 / 2 rows instead - those instances spill nothing - or iterate on the
+// two-kernel path; the spilling instances are not compiled.
+template <typename T, typename CT, bool RECON, bool SYMV>
+constexpr bool kHas16 = (sizeof(T) == 8 && sizeof(CT) == 4) || (sizeof(T) == 4 && sizeof(CT) == 4 && RECON && SYMV);
+
 template <typename T, typename CT, bool RECON, bool SYMV>
 static const void* persist_kernel(int R, bool ragged = false) {
   if constexpr (sizeof(T) == 8 && RECON && SYMV) {
@@ -103,7 +110,9 @@ static const void* persist_kernel(int R, bool ragged = false) {
   switch (R) {
     case 2: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 2, RECON, SYMV>);
     case 4: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 4, 2, RECON, SYMV>);
-    default: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 16, 1, RECON, SYMV>);
+    default:
+      if constexpr (kHas16<T, CT, RECON, SYMV>) return reinterpret_cast<const void*>(&cg_persist1<T, CT, 16, 1, RECON, SYMV>);
+      else return nullptr;
   }
 }
 
@@ -177,7 +186,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
   const int force = opt(OPT_CG_PERSIST), force_r = opt(OPT_CG_PERSIST_R);   // -1: automatic
   // fp32 state: the 16-row instance keeps its registers only for a symmetric matrix with rebuilt diagonals (the others spill
   // 26-84 VGPRs); any other fp32 system is tiled with regions of 4 / 2 rows (no spills), or iterates on the two-kernel path
-  const bool f32_small_regions = sizeof(T) != 8 && !(symmetric && RECON);
+  const bool f32_small_regions = (sizeof(T) != 8 && !(symmetric && RECON)) || sizeof(CT) == 8;     // (see kHas16)
   if (V == 16 / (int)sizeof(T) && a.per_y != 2 && allow_persist && force != 0) {
     int dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
@@ -234,8 +243,11 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     int per_cu = 0, dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    PISO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPersistThreads, 0));
-    if ((long long)per_cu * cus < launch_grid) persist_R = 0;
+    if (!kfn) persist_R = 0;                                 // (a forced 16-row shape for a combination that has no such instance: kHas16)
+    else {
+      PISO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPersistThreads, 0));
+      if ((long long)per_cu * cus < launch_grid) persist_R = 0;
+    }
   }
   if (persist_R) {
     pc.rec = reinterpret_cast<unsigned long long*>(persist_ws);
@@ -280,7 +292,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     do {                                                                                                                     \
       if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);        \
       else if (persist_R == 4) cg_persist1<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
-      else cg_persist1<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);                      \
+      else if constexpr (kHas16<T, CT, RECON, SYMV>) cg_persist1<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);  \
     } while (0)
     constexpr bool kCanSymPlain = sizeof(CT) == 4 && (RECON || sizeof(T) == 8);     // (see kCanSymO above)
     if constexpr (kCanSymPlain) {

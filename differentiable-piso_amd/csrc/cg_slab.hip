@@ -307,7 +307,7 @@ static void launch_slab_segment(int R, int grid, const CgArgs<T>& a, const Persi
     switch (R) {
       case 2: cg_persist1<T, CT, 2, 2, RECON, SYMV, true><<<grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pend, sl); break;
       case 4: cg_persist1<T, CT, 4, 2, RECON, SYMV, true><<<grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pend, sl); break;
-      default: cg_persist1<T, CT, 16, 1, RECON, SYMV, true><<<grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pend, sl); break;
+      default: if constexpr (sizeof(CT) == 4 && SYMV) cg_persist1<T, CT, 16, 1, RECON, SYMV, true><<<grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pend, sl); break;
     }
   }
 }
@@ -317,7 +317,9 @@ static const void* slab_segment_kernel(int R) {
     switch (R) {
       case 2: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 2, RECON, SYMV, true>);
       case 4: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 4, 2, RECON, SYMV, true>);
-      default: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 16, 1, RECON, SYMV, true>);
+      default:                                              // (fp64 coefficients or an unsymmetric matrix - a general system - have no 16-row instance: it spills; cg.hip kHas16)
+        if constexpr (sizeof(CT) == 4 && SYMV) return reinterpret_cast<const void*>(&cg_persist1<T, CT, 16, 1, RECON, SYMV, true>);
+        else return nullptr;
     }
   }
   return nullptr;
@@ -363,12 +365,19 @@ static int slab_iterate(std::vector<SlabRank<T>>& R, Comm<T>& comm, float accura
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     shape = persist_shape(R[0].a.nx, R[0].a.ny, V, cus, opt(OPT_CG_PERSIST_R));
     if (shape.R == 8) shape.R = 0;                          // (two regions of 8 rows: cg_persist1 spills registers there)
+    if (shape.R == 16 && (sizeof(CT) == 8 || !(kCanSym && symmetric))) {     // (no 16-row slab instance for general matrices: regions of 4 / 2 rows, or two kernels)
+      shape = PersistShape();
+      if (opt(OPT_CG_PERSIST_R) <= 0) { shape = persist_shape(R[0].a.nx, R[0].a.ny, V, cus, 4); if (!shape.R) shape = persist_shape(R[0].a.nx, R[0].a.ny, V, cus, 2); }
+    }
     if (shape.R && (size_t)R[0].a.nx * R[0].a.ny < 16384 && opt(OPT_CG_PERSIST) != 1) shape.R = 0;
     if (shape.R) {
       const void* kfn = slab_segment_kernel<T, CT, RECON, false>(shape.R);
       if constexpr (kCanSym) { if (symmetric) kfn = slab_segment_kernel<T, CT, RECON, true>(shape.R); }
-      PISO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPersistThreads, 0));
-      if ((long long)per_cu * cus < shape.grid || shape.grid > kPersistMaxGrid) shape.R = 0;
+      if (!kfn) shape.R = 0;
+      else {
+        PISO_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, kPersistThreads, 0));
+        if ((long long)per_cu * cus < shape.grid || shape.grid > kPersistMaxGrid) shape.R = 0;
+      }
     }
     if (shape.R) {
       pc.rec = reinterpret_cast<unsigned long long*>(persist_ws);

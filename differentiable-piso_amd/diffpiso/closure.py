@@ -123,14 +123,24 @@ class FullyConvNetwork(torch.nn.Module):
     """7-layer fully convolutional network 4 -> 16 -> 16 -> 32 -> 64 -> 64 -> 64 -> 2, kernels 7,5,5,3,3,1,1, leaky ReLU (0.2)
     after all but the last layer (networks.py:3-57).  Tensors are NHWC like the reference's."""
 
-    def __init__(self, buffer_width=None, padding="SAME", restore_shape=False, in_channels=4, seed=None):
+    def __init__(self, buffer_width=None, padding="SAME", restore_shape=False, in_channels=4, seed=None, initialiser=None):
         super().__init__()
         gen = torch.Generator().manual_seed(seed) if seed is not None else None
         self.weights = torch.nn.ParameterList()
         for i, (k, cin, cout) in enumerate(_KERNELS):
             cin = in_channels if i == 0 else cin
-            std = float(np.sqrt(2.0 / (k * k * cin + k * k * cout)))               # tf.glorot_normal_initializer
-            w = torch.randn(cout, cin, k, k, generator=gen) * std
+            # tf.glorot_normal_initializer (networks.py:57) = VarianceScaling(1.0, "fan_avg", "truncated_normal"): a normal distribution
+            # truncated at two standard deviations whose standard deviation AFTER the truncation is sqrt(2 / (fan_in + fan_out)) -
+            # TensorFlow samples with sigma / 0.87962566103423978 for that
+            std = float(np.sqrt(2.0 / (k * k * cin + k * k * cout)))
+            sig = std / 0.87962566103423978
+            if initialiser == "normal":                       # the same scale without the truncation (the draw of rounds 1 - 4: the config-4 fixture's weights)
+                w = torch.randn(cout, cin, k, k, generator=gen) * std
+            elif initialiser in (None, "glorot_normal"):
+                w = torch.empty(cout, cin, k, k)
+                torch.nn.init.trunc_normal_(w, mean=0.0, std=sig, a=-2.0 * sig, b=2.0 * sig, generator=gen)
+            else:
+                raise ValueError("initialiser: None / 'glorot_normal' (tf.glorot_normal_initializer, the reference's default) or 'normal'")
             self.weights.append(torch.nn.Parameter(w))
         self.buffer_width = buffer_width
         self.padding = padding
@@ -160,7 +170,7 @@ class FullyConvNetwork(torch.nn.Module):
 
 def initialise_fullyconv_network(buffer_width, padding="SAME", restore_shape=False, initialiser=None, seed=None):
     """networks.py:59-77 -> (callable, weights, reduced_buffer_width)."""
-    net = FullyConvNetwork(buffer_width, padding, restore_shape, seed=seed)
+    net = FullyConvNetwork(buffer_width, padding, restore_shape, seed=seed, initialiser=initialiser)
     rbw = net.reduced_buffer_width
     if buffer_width is not None:
         rbw = [[i + rbw for i in j] for j in buffer_width]

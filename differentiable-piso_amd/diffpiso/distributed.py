@@ -221,7 +221,7 @@ def gather_face_rows(comm, x, nx, ny):
     return out
 
 
-def multi_bicgstab_ilu_slab(comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn, gather=True):
+def multi_bicgstab_ilu_slab(comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn, gather=True, negate=False):
     """piso_multi_bicgstab_ilu_slab_{f32,f64}: all arrays are the FULL ones on every rank; the rank solves its slab."""
     dt = values.dtype
     assert dt in (torch.float32, torch.float64)      # (both transports: mailbox kernels, or RCCL send / recv + all-reduce)
@@ -232,14 +232,14 @@ def multi_bicgstab_ilu_slab(comm, values, row_ptr, col_indices, rhs, x0, nx, ny,
     its = (C.c_int * 2)()
     fn = N.lib.piso_multi_bicgstab_ilu_slab_f64 if dt == torch.float64 else N.lib.piso_multi_bicgstab_ilu_slab_f32
     st = fn(comm.handle, N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(rhs), N.ptr(x0), N.ptr(x), nx, ny, C.c_float(tol),
-            int(max_it), int(bool(transpose)), int(band_rows), N.ptr(warn), its, N.ptr(ws), C.c_size_t(ws.numel()), N.stream_ptr())
+            int(max_it), (1 if transpose else 0) | (2 if negate else 0), int(band_rows), N.ptr(warn), its, N.ptr(ws), C.c_size_t(ws.numel()), N.stream_ptr())
     N.check(st, "piso_multi_bicgstab_ilu_slab")
     if gather and comm.world > 1:
         x = gather_face_rows(comm, x, nx, ny)
     return x, (its[0], its[1])
 
 
-def multi_bicgstab_ilu_slab_local(comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn):
+def multi_bicgstab_ilu_slab_local(comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn, negate=False):
     """piso_multi_bicgstab_ilu_slab_local_{f32,f64}: the slab-decomposed STEP's solve - every array (the workspace included) holds the
     rank's stored rows (sharding.StepSharding, reached through the communicator); nx, ny are the whole grid's.  x is written on the
     owned rows, the halo rows of the result stay zero."""
@@ -256,7 +256,7 @@ def multi_bicgstab_ilu_slab_local(comm, values, row_ptr, col_indices, rhs, x0, n
     per_x, per_y = sh.periodic_xy
     fn = N.lib.piso_multi_bicgstab_ilu_slab_local_f64 if dt == torch.float64 else N.lib.piso_multi_bicgstab_ilu_slab_local_f32
     st = fn(comm.handle, N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(rhs), N.ptr(x0), N.ptr(x), nx, ny, int(per_x), int(per_y),
-            C.c_float(tol), int(max_it), int(bool(transpose)), int(band_rows), N.ptr(warn), its, N.ptr(ws), C.c_size_t(ws.numel()),
+            C.c_float(tol), int(max_it), (1 if transpose else 0) | (2 if negate else 0), int(band_rows), N.ptr(warn), its, N.ptr(ws), C.c_size_t(ws.numel()),
             N.stream_ptr(), sh.slab_ptr)
     N.check(st, "piso_multi_bicgstab_ilu_slab_local")
     return x, (its[0], its[1])

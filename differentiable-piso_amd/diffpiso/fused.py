@@ -75,6 +75,9 @@ def flat_faces(x):
     """Staggered tensor / StaggeredGrid -> flat u-first face vector (one gather); a SlabStaggered IS its flat vector."""
     if isinstance(x, SlabStaggered):
         return x.flat
+    flat = getattr(x, "_flat_ufirst", None)
+    if flat is not None:                                     # a grid the step itself made (faces_to_grid): its components are views of this vector
+        return flat
     grid = x if isinstance(x, StaggeredGrid) else StaggeredGrid(x)
     v, u = grid.data[0].data, grid.data[1].data
     return torch.cat([u.reshape(-1), v.reshape(-1)])
@@ -86,7 +89,9 @@ def faces_to_grid(flat, geom, box, extrapolation):
         return SlabStaggered(flat, geom.sh, box, extrapolation)
     u = flat[:geom.n_u].view(1, geom.ny, geom.nx + 1, 1)
     v = flat[geom.n_u:].view(1, geom.ny + 1, geom.nx, 1)
-    return StaggeredGrid([v, u], box, extrapolation=extrapolation)
+    grid = StaggeredGrid([v, u], box, extrapolation=extrapolation)
+    grid._flat_ufirst = flat                                 # (flat_faces of this grid: no gather)
+    return grid
 
 
 def pad_velocity(vel_flat, geom, per_x, per_y):
@@ -202,6 +207,7 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
     """piso_step (diffpiso/piso_tf.py:11-81) on the fused kernels.  Called by piso.piso_step; same arguments and results.  With
     `sim.sharding` (sharding.StepSharding) the fields are SlabStaggered / SlabCentered: the rank's stored rows (local storage)."""
     from .piso import _CsrMatVec, assemble_from_padded
+    from .solvers import LinearSolverCudaMultiBicgstabILU
     ny, nx = [int(r) for r in velocity.resolution]
     sh = getattr(sim, "sharding", None)                                            # sharding.StepSharding: this rank's y-slab only
     if (sh is not None) != isinstance(velocity, SlabStaggered) or (sh is not None) != isinstance(pressure, SlabCentered):
@@ -254,8 +260,12 @@ def piso_step_fused(velocity, pressure, pressure_inc1, pressure_inc2, dt, sim, d
         forcing_flat = None if forcing_term is None else (forcing_term.flat if isinstance(forcing_term, SlabStaggered) else sh.scatter_staggered(forcing_term, device=dev))
         dv_flat = dirichlet_values.flat if isinstance(dirichlet_values, SlabStaggered) else sh.cached_scatter_staggered(dirichlet_values)
     implicit_rhs = _FaceOp.apply(FACE_RHS, geom, p_data, vel_flat, forcing_flat, dv_flat, None, dmask)
-    sol = sim.linear_solver.solve(-matrix_values, row_pointers, column_indices, implicit_rhs, staggered_shape, vel_flat, offset=1,
-                                  transpose=False, unrolling_step=unrolling_step, warn=warn)
+    if isinstance(sim.linear_solver, LinearSolverCudaMultiBicgstabILU):             # (-matrix_values, :41: the sign is applied inside the solver's
+        sol = sim.linear_solver.solve(matrix_values, row_pointers, column_indices, implicit_rhs, staggered_shape, vel_flat, offset=1,   # conversion pass)
+                                      transpose=False, unrolling_step=unrolling_step, warn=warn, negate=True)
+    else:
+        sol = sim.linear_solver.solve(-matrix_values, row_pointers, column_indices, implicit_rhs, staggered_shape, vel_flat, offset=1,
+                                      transpose=False, unrolling_step=unrolling_step, warn=warn)
     warn = sol[1]
     star = sol[0]
 

@@ -227,7 +227,7 @@ def piso_step(velocity, pressure, pressure_inc1, pressure_inc2, dt, simulation_p
     step, forward and reverse mode with the reference's custom gradients).  There is no other implementation in the package: the
     statement-by-statement torch transcription that the tests hold the fused path to lives in tests/piso_step_transcription.py."""
     from . import stencils
-    if not velocity.data[0].data.is_cuda:
+    if not (velocity.flat if hasattr(velocity, "flat") else velocity.data[0].data).is_cuda:
         raise N.PisoNativeError("piso_step: the fields must live on the GPU (the PISO path has no CPU implementation)")
     if not stencils.REFERENCE_ADJOINTS:
         raise ValueError("piso_step implements the reference's custom gradients (stencils.REFERENCE_ADJOINTS = True); the exact "

@@ -82,16 +82,18 @@ class LinearSolverScipy(LinearSolver):
                                    bool(transpose))
 
 
-def multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn, slab_comm=None):
+def multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn, slab_comm=None, negate=False):
     """One call of piso_multi_bicgstab_ilu_{f32,f64}. Returns (x, iterations[2]); sets warn[0] in place on NaN input.
     slab_comm (distributed.SlabCommunicator, either transport, more than one rank): the solve is cut into y-slabs over the ranks
     (every rank passes the full arrays and works on its rows; dot products are all-reduced inside the scalar kernels, the edge
-    rows of the SpMV inputs travel through the mailboxes) and every rank returns the full solution."""
+    rows of the SpMV inputs travel through the mailboxes) and every rank returns the full solution.
+    negate: the system matrix is -values (the sign is applied where the kernel reads the values: no pass over the array for it)."""
     if slab_comm is not None and slab_comm.world > 1:
         from .distributed import multi_bicgstab_ilu_slab, multi_bicgstab_ilu_slab_local
         if slab_comm.sharded:                # slab-decomposed STEP: every array holds the rank's stored rows (sharding.py)
-            return multi_bicgstab_ilu_slab_local(slab_comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn)
-        return multi_bicgstab_ilu_slab(slab_comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn)
+            return multi_bicgstab_ilu_slab_local(slab_comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn,
+                                                 negate=negate)
+        return multi_bicgstab_ilu_slab(slab_comm, values, row_ptr, col_indices, rhs, x0, nx, ny, tol, max_it, transpose, band_rows, warn, negate=negate)
     dt = values.dtype
     assert dt in (torch.float32, torch.float64)
     values, rhs, x0 = values.contiguous(), rhs.to(dt).contiguous(), x0.to(dt).contiguous()
@@ -103,7 +105,7 @@ def multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol
     its = (C.c_int * 2)()
     fn = N.lib.piso_multi_bicgstab_ilu_f64 if dt == torch.float64 else N.lib.piso_multi_bicgstab_ilu_f32
     st = fn(N.ptr(values), N.ptr(row_ptr), N.ptr(col_indices), N.ptr(rhs), N.ptr(x0), N.ptr(x), nx, ny, C.c_float(tol),
-            int(max_it), int(bool(transpose)), int(band_rows), N.ptr(warn), its, N.ptr(ws), C.c_size_t(ws.numel()),
+            int(max_it), (1 if transpose else 0) | (2 if negate else 0), int(band_rows), N.ptr(warn), its, N.ptr(ws), C.c_size_t(ws.numel()),
             N.stream_ptr())
     N.check(st, "piso_multi_bicgstab_ilu")
     return x, (its[0], its[1])
@@ -114,32 +116,32 @@ class _LinearSolveFn(torch.autograd.Function):
     the transposed matrix (same initial guess), multiplied by (1 - warn)."""
 
     @staticmethod
-    def forward(ctx, rhs, values, row_ptr, col_indices, x0, solver, nx, ny, transpose, warn):
+    def forward(ctx, rhs, values, row_ptr, col_indices, x0, solver, nx, ny, transpose, warn, negate=False):
         tol = _scalar(solver.accuracy)
         x, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs, x0, nx, ny, tol, solver.max_iterations,
-                                           transpose, solver.band_rows, warn, solver.slab_comm)
+                                           transpose, solver.band_rows, warn, solver.slab_comm, negate=negate)
         solver.last_iterations = its
         solver.stats["solves"] += 1
         solver.stats["iterations"] += max(its)
         # the reference's backward op receives the SAME warn buffer the forward op aliased and mutated
         # (linear_solver.py:165-173, multi_bicgstab_ilu_linear_solve_op.cc:136-140): a forward warning zeroes the gradient
         ctx.save_for_backward(values, row_ptr, col_indices, x0, warn.clone())
-        ctx.meta = (solver, nx, ny, transpose)
+        ctx.meta = (solver, nx, ny, transpose, negate)
         return x.to(torch.float32), warn.to(torch.float32)
 
     @staticmethod
     def backward(ctx, ds, dw):
         values, row_ptr, col_indices, x0, warn_fwd = ctx.saved_tensors
-        solver, nx, ny, transpose = ctx.meta
+        solver, nx, ny, transpose, negate = ctx.meta
         warn_b = warn_fwd.clone()
         tol = _scalar(solver.accuracy)
         df, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, ds.to(values.dtype), x0, nx, ny, tol,
-                                            solver.max_iterations, not transpose, solver.band_rows, warn_b, solver.slab_comm)
+                                            solver.max_iterations, not transpose, solver.band_rows, warn_b, solver.slab_comm, negate=negate)
         solver.last_adjoint_iterations = its
         solver.stats["adjoint_solves"] += 1
         solver.stats["adjoint_iterations"] += max(its)
         df = df.to(torch.float32) * (1.0 - warn_b.to(torch.float32)[0])
-        return df, None, None, None, None, None, None, None, None, None
+        return df, None, None, None, None, None, None, None, None, None, None
 
 
 class LinearSolverCudaMultiBicgstabILU(LinearSolver):
@@ -160,7 +162,9 @@ class LinearSolverCudaMultiBicgstabILU(LinearSolver):
         self.stats = dict(solves=0, iterations=0, adjoint_solves=0, adjoint_iterations=0)   # cumulative (max over u, v per solve)
 
     def solve(self, matrix_values, row_ptr, col_indices, rhs, staggered_shape, initial_guess=None, offset=0,
-              transpose=False, unrolling_step=0, warn=None):
+              transpose=False, unrolling_step=0, warn=None, negate=False):
+        """negate (not in the reference): the system matrix is -matrix_values.  The reference's step passes `-matrix_values`
+        (piso_tf.py:41) - a pass over the whole value array per step; `piso_step` here passes the values and this flag instead."""
         dt = torch.float64 if self.cast_to_double else torch.float32
         values = matrix_values.reshape(-1).to(dt)
         flat_rhs = rhs.reshape(-1)
@@ -175,7 +179,7 @@ class LinearSolverCudaMultiBicgstabILU(LinearSolver):
         elif warn.dtype != torch.uint8:
             warn = (warn != 0).to(torch.uint8)
         sol, w = _LinearSolveFn.apply(flat_rhs, values.detach(), row_ptr.reshape(-1), col_indices.reshape(-1), flat_x, self,
-                                      nx, ny, bool(transpose), warn)
+                                      nx, ny, bool(transpose), warn, bool(negate))
         return [sol, w]
 
 
@@ -191,6 +195,7 @@ class _SingleSolveFn(torch.autograd.Function):
         x, its = multi_bicgstab_ilu_native(values, row_ptr, col_indices, rhs_pair, x0, nx, ny, _scalar(solver.accuracy),
                                            solver.max_iterations, transpose, 0, warn)
         solver.last_iterations = its
+        solver.last_warn = warn                              # (device byte: NaN input; `solve` looks at it)
         ctx.save_for_backward(values, row_ptr, col_indices, x0)
         ctx.meta = (solver, nx, ny, transpose)
         return x
@@ -212,12 +217,33 @@ class LinearSolverCudaBicgstabILU(LinearSolver):
     ([1, ny+1, nx+1, 2]), `component` ('u' | 'v') and `bool_periodic` ((y, x)) are additional keyword arguments of `solve`.  The
     other component is filled in with a diffusion matrix of the same grid and a zero right-hand side (it converges at once)."""
 
-    def __init__(self, accuracy=1e-5, max_iterations=2000):
+    _patterns = {}       # (nx, ny, per_x, per_y, device) -> (stand-in pair values, row pointers, columns, nnz): geometry only, built once
+
+    def __init__(self, accuracy=1e-5, max_iterations=2000, raise_on_nan=True):
         LinearSolver.__init__(self, "HIP iLU-preconditioned BiCGStab solve", supported_devices=("GPU",), supports_guess=True,
                               supports_batch=False, solver_type="iterative", input_format="csr")
         self.accuracy = accuracy
         self.max_iterations = max_iterations
         self.last_iterations = None
+        self.last_warn = None           # the pair solver's warning byte of the last solve (1: NaN in the matrix / right-hand side / guess)
+        self.raise_on_nan = raise_on_nan
+
+    @classmethod
+    def _pattern(cls, nx, ny, per_x, per_y, dev):
+        """The pair's pattern and a well-posed stand-in for the other component (diffusion + identity on a resting fluid), cached per
+        grid: it depends on (nx, ny, periodicity) only, and checking a caller's pattern against it costs two host synchronisations."""
+        from .piso import assemble_from_padded
+        key = (nx, ny, per_x, per_y, str(dev))
+        hit = cls._patterns.get(key)
+        if hit is None:
+            n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
+            pad = torch.zeros((ny + 2) * (nx + 3) + (ny + 3) * (nx + 2), dtype=torch.float32, device=dev)
+            val, rp, col, _, nnz = assemble_from_padded(pad, nx, ny, (1.0, 1.0), per_x, per_y, torch.zeros(n_u + n_v, dtype=torch.uint8, device=dev),
+                                                        torch.ones((ny + 2) * (nx + 2), dtype=torch.float32, device=dev), 1.0, None, 1.0)
+            if len(cls._patterns) > 8:
+                cls._patterns.clear()
+            hit = cls._patterns[key] = (-val, rp, col, (int(nnz[0]), int(nnz[1])), set())      # (piso_step hands the solver -matrix_values, piso_tf.py:41)
+        return hit
 
     def solve(self, matrix_values, row_ptr, col_indices, rhs, initial_guess=None, offset=0, transpose=False,
               staggered_shape=None, component=None, bool_periodic=(False, False)):
@@ -225,24 +251,24 @@ class LinearSolverCudaBicgstabILU(LinearSolver):
             raise NotImplementedError("LinearSolverCudaBicgstabILU.solve: the MI355X engine takes the matrix structure from the staggered grid - "
                                       "pass staggered_shape=[1, ny+1, nx+1, 2], component='u'|'v' (and bool_periodic), or use "
                                       "LinearSolverCudaMultiBicgstabILU, which is what the reference's scripts use")
-        from .piso import assemble_from_padded
         ny, nx = int(staggered_shape[1]) - 1, int(staggered_shape[2]) - 1
         n_u, n_v = (nx + 1) * ny, nx * (ny + 1)
         dev = rhs.device
         per_y, per_x = bool(bool_periodic[0]), bool(bool_periodic[1])
-        # the pair's pattern and a well-posed stand-in for the other component: diffusion + identity on a resting fluid
-        pad = torch.zeros((ny + 2) * (nx + 3) + (ny + 3) * (nx + 2), dtype=torch.float32, device=dev)
-        val, rp, col, _, nnz = assemble_from_padded(pad, nx, ny, (1.0, 1.0), per_x, per_y, torch.zeros(n_u + n_v, dtype=torch.uint8, device=dev),
-                                                    torch.ones((ny + 2) * (nx + 2), dtype=torch.float32, device=dev), 1.0, None, 1.0)
-        val = -val                                           # (piso_step hands the solver -matrix_values, piso_tf.py:41)
-        nnz_u, nnz_v = int(nnz[0]), int(nnz[1])
+        val, rp, col, (nnz_u, nnz_v), checked = self._pattern(nx, ny, per_x, per_y, dev)
         lo, hi, r0, rows = (0, nnz_u, 0, n_u) if component == "u" else (nnz_u, nnz_u + nnz_v, n_u + 1, n_v)
         mv = matrix_values.reshape(-1).to(torch.float32)
         if mv.numel() != hi - lo or int(row_ptr.numel()) != rows + 1 or int(col_indices.numel()) != hi - lo:
             raise ValueError("LinearSolverCudaBicgstabILU: the matrix is not the %s matrix of a %d x %d staggered grid (%d values, expected %d)"
                              % (component, nx, ny, mv.numel(), hi - lo))
-        if not (torch.equal(row_ptr.reshape(-1).to(torch.int32), rp[r0:r0 + rows + 1]) and torch.equal(col_indices.reshape(-1).to(torch.int32), col[lo:hi])):
-            raise ValueError("LinearSolverCudaBicgstabILU: row pointers / column indices are not the 5-point pattern of the grid")
+        # (a caller's pattern arrays are compared with the grid's ONCE per pair of tensors: the comparison synchronises the host)
+        pat_key = (component, row_ptr.data_ptr(), col_indices.data_ptr(), int(row_ptr._version), int(col_indices._version))
+        if pat_key not in checked:
+            if not (torch.equal(row_ptr.reshape(-1).to(torch.int32), rp[r0:r0 + rows + 1]) and torch.equal(col_indices.reshape(-1).to(torch.int32), col[lo:hi])):
+                raise ValueError("LinearSolverCudaBicgstabILU: row pointers / column indices are not the 5-point pattern of the grid")
+            if len(checked) > 16:
+                checked.clear()
+            checked.add(pat_key)
         val = val.clone()
         val[lo:hi] = mv
         flat_rhs = rhs.reshape(-1).to(torch.float32)
@@ -253,6 +279,10 @@ class LinearSolverCudaBicgstabILU(LinearSolver):
         embed = torch.zeros(n_u + n_v, dtype=torch.float32, device=dev)
         pair_rhs = embed.index_put((torch.arange(off, off + rows, device=dev),), flat_rhs)          # (differentiable w.r.t. rhs)
         sol = _SingleSolveFn.apply(pair_rhs, val, rp, col, x0, self, nx, ny, bool(transpose))
+        if self.raise_on_nan and int(self.last_warn.item()) != 0:
+            # (the pair solver's failure handling is the reference's - NaN input: warning byte, zero solution; this class has no `warn`
+            # output to hand it to, so it says so instead of returning zeros silently)
+            raise N.PisoNativeError("LinearSolverCudaBicgstabILU: NaN in the matrix, the right-hand side or the initial guess (the solver's warning byte is set)")
         return sol[off:off + rows]
 
 

@@ -51,6 +51,10 @@ def unroll_piso_steps(velocity, pressure, dt, sim_physics, step_count=1, loss_in
     dirichlet_values = sim_physics.dirichlet_values
     velnew, pnew = velocity, pressure
     velocity_all_steps, pressure_all_steps = [], []
+    # (:456-457 builds the two increments anew in every step; the step only reads their box and extrapolation - the guesses are ignored,
+    # piso_cuda_pressure_solver.py:95 - so they are built once per unroll: two fills instead of four launches per step)
+    pressure_inc1 = _centered_like(pressure, torch.full_like(pressure.data, 5e-13))
+    pressure_inc2 = _centered_like(pressure, torch.full_like(pressure.data, 1e-12))
     for i in range(step_count):
         if i > 0 and loss_influence_range and i % loss_influence_range == 0:          # :436-438
             velnew = _staggered_like(velnew, velnew.staggered_tensor().detach())
@@ -58,14 +62,13 @@ def unroll_piso_steps(velocity, pressure, dt, sim_physics, step_count=1, loss_in
         if i > 0 and dirichlet_update_fn is not None:
             dirichlet_values = dirichlet_update_fn(i, sim_physics.dirichlet_values)
         forcing = forcing_fn(i, velnew, pnew) if forcing_fn is not None else None
-        pressure_inc1 = _centered_like(pressure, torch.zeros_like(pressure.data) + 5e-13)   # :456-457
-        pressure_inc2 = _centered_like(pressure, torch.zeros_like(pressure.data) + 1e-12)
         vel_piso, p_piso, warn[i] = piso_step(velnew, pnew, pressure_inc1, pressure_inc2, dt, sim_physics, dirichlet_values,
                                               viscosity_field=viscosity_field, forcing_term=forcing, unrolling_step=i)
         velocity_all_steps.append(vel_piso)
         pressure_all_steps.append(p_piso)
-        velnew = _staggered_like(vel_piso, vel_piso.staggered_tensor())
-        pnew = _centered_like(p_piso, p_piso.data)
+        # (:472-473 re-wraps the step's results in new grids around the same data; the step's own result objects carry their flat face
+        # vector along - fused.faces_to_grid - which the next step reads without stacking and flattening the tensor again)
+        velnew, pnew = vel_piso, p_piso
     return velocity_all_steps, pressure_all_steps, velnew, pnew, warn
 
 

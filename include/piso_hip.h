@@ -117,7 +117,8 @@ int piso_slab_sizes(const piso_slab_t* slab, int nx, int ny, int periodic_x, int
  * .cu.cc:455-531 float / :912-988 double; per-component algorithm :85-453 / :540-910).
  *   csr_*      the concatenated two-matrix CSR produced by piso_assemble_csr (values possibly negated by the caller)
  *   rhs, x0    [n_u + n_v];  x_out [n_u + n_v]
- *   tol        absolute ||r||_2 tolerance; max_it per restart; transpose != 0 solves with A^T (adjoint)
+ *   tol        absolute ||r||_2 tolerance; max_it per restart; transpose: bit 0 = solve with A^T (adjoint), bit 1 = the system matrix
+ *              is -csr_val (the reference hands the op `-matrix_values`, piso_tf.py:41: the sign is applied where the values are read)
  *   band_rows  rows of faces per preconditioner block: < 0  = one block (global structured ILU0),
  *              0 = automatic, > 0 = that many.  See DESIGN.md "structured block ILU0".
  *   warning    device byte, set to 1 on NaN input (never cleared);  iterations_out: host int[2] or NULL

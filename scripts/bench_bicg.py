@@ -9,4 +9,5 @@ import bench
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 P = bench.build_problem(n, torch.device("cuda"), 1e-6, 10000, 1000)
-print(json.dumps(bench.bicgstab_fixed_work(P, n, iters=10, reps=3)))
+# PISO_BICG_PROFILE=1 (the PMC passes of scripts/profile_bench.sh): the four fixed-work solves only, so that the counters' sums divide by four
+print(json.dumps(bench.bicgstab_fixed_work(P, n, iters=10, reps=3, real=os.environ.get("PISO_BICG_PROFILE", "0") != "1")))

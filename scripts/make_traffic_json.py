@@ -50,4 +50,19 @@ for name, key in (("cg_persist1", "cg_persist"), ("cg_persist<", "cg_persist"), 
         rec["iterations_per_launch"] = 149          # PMC passes run with --max-iterations 150: one segment of 149 iterations
         rec["bytes_per_iteration"] = rec["bytes"] / 149.0
     out["2048"][key] = rec
+# BiCGStab (optional third argument: the PMC summary of scripts/bench_bicg.py): all bi_* kernels of the run, per solve.  The run makes
+# four fixed-work solves (PISO_BICG_PROFILE=1: nothing else)
+if len(sys.argv) > 3:
+    btxt = open(sys.argv[3]).read()
+    tot = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
+    for m in re.finditer(r"^(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*(\d+) mean=([0-9.e+]+) sum=([0-9.e+]+)", btxt, re.M):
+        if "bi_" in m.group(1):
+            tot[m.group(2)] += float(m.group(5))
+    fixed_its, fixed_solves = 20, 4                                    # bench.bicgstab_fixed_work under PISO_BICG_PROFILE=1: 4 solves of 2 x 10 iterations
+    share = 1.0
+    rb = tot["FETCH_SIZE"] * 1024 * (cal["read_16B_per_lane"] or 1.0) / fixed_solves
+    wb = tot["WRITE_SIZE"] * 1024 * (cal["write_16B_per_lane"] or 1.0) / fixed_solves
+    out["2048"]["bicgstab"] = {"kernel": "bi_* (whole fixed-work solve)", "fetch_kb_all_solves": tot["FETCH_SIZE"], "write_kb_all_solves": tot["WRITE_SIZE"],
+                               "share_of_the_fixed_work_solves": share, "iterations_per_solve": fixed_its, "bytes_per_solve": rb + wb,
+                               "kernel_source_sha": sha, "source": "profiles/%s_bicgstab2048_pmc_fetch_write_summary.txt" % tag}
 print(json.dumps(out, indent=1))

@@ -21,7 +21,13 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/calib_writ
 python3 $R/scripts/summarize_pmc.py /tmp/prof_fetch /tmp/prof_write /tmp/calib_fetch /tmp/calib_write > $OUT/${TAG}_bench2048_pmc_fetch_write_summary.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bicg -o bicg -- python3 $R/scripts/bench_bicg.py 2048 > $OUT/${TAG}_bicg_run.log 2>&1
 for f in $(find /tmp/prof_bicg -name "*kernel_stats.csv"); do cp $f $OUT/${TAG}_bicgstab2048_kernel_stats.csv; done
-python3 $R/scripts/make_traffic_json.py $OUT/${TAG}_bench2048_pmc_fetch_write_summary.txt $TAG > $OUT/traffic.json 2> $OUT/${TAG}_traffic.log
+# 4b. PMC passes of the same fixed-work BiCGStab run (bytes per solve over all bi_* kernels: bench.py -> bicgstab.traffic)
+export PISO_BICG_PROFILE=1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/bicg_fetch -o bicg -- python3 $R/scripts/bench_bicg.py 2048 > $OUT/${TAG}_bicg_fetch_run.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/bicg_write -o bicg -- python3 $R/scripts/bench_bicg.py 2048 > $OUT/${TAG}_bicg_write_run.log 2>&1
+unset PISO_BICG_PROFILE
+python3 $R/scripts/summarize_pmc.py /tmp/bicg_fetch /tmp/bicg_write > $OUT/${TAG}_bicgstab2048_pmc_fetch_write_summary.txt 2>&1
+python3 $R/scripts/make_traffic_json.py $OUT/${TAG}_bench2048_pmc_fetch_write_summary.txt $TAG $OUT/${TAG}_bicgstab2048_pmc_fetch_write_summary.txt > $OUT/traffic.json 2> $OUT/${TAG}_traffic.log
 # 6. the bench line of the SAME sources with the traffic record just taken (bench.py reads profiles/traffic.json and uses it only if the
 #    sha of the kernel sources matches): fail loudly if it does not
 cp $OUT/traffic.json $R/profiles/traffic.json

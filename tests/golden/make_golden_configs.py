@@ -95,7 +95,8 @@ CFG4_SIMPAR = dict(HRres=[256, 1024], sponge_ratio=0.875, dx_ratio=1)
 def sml_network(dp, torch):
     """The closure of config 4 with seeded weights: VALID padding + restore_shape and zero buffer width
     (spatial_mixing_layer_differentiable_training.py:46,49-50,55), damped so that the forcing stays a perturbation."""
-    net, weights, _ = dp.initialise_fullyconv_network([[0, 0], [0, 0]], padding="VALID", restore_shape=True, seed=1)
+    net, weights, _ = dp.initialise_fullyconv_network([[0, 0], [0, 0]], padding="VALID", restore_shape=True, seed=1,
+                                                      initialiser="normal")      # (the draw the committed fixture was made with)
     with torch.no_grad():
         for w in net.weights:
             w.mul_(0.6)

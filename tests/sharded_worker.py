@@ -35,6 +35,10 @@ def build_case(case, device):
     import torch
     import diffpiso as dp
     kind, _, rest = case.partition(":")
+    if rest.endswith(":persist0"):                          # (more slab kernels than the ONE shared GPU holds side by side: two-kernel CG iteration)
+        import diffpiso._native as N
+        N.set_option("cg_persist", 0)
+        rest = rest[:-len(":persist0")]
     if kind == "fixture" and rest.startswith("bench"):
         import bench
         d = np.load(os.path.join(HERE, "golden", rest))
@@ -69,24 +73,46 @@ def build_case(case, device):
 
 
 def run_case(B, sharding=None):
-    """Forward `steps` unrolled steps + reverse sweep -> (u_K staggered tensor, p_K, dL/du_0, dL/dp_0, loss, warn)."""
+    """Forward `steps` unrolled steps + reverse sweep -> (u_K, p_K, dL/du_0, dL/dp_0, loss, warn): staggered tensors / cell arrays of the
+    whole grid on one GPU; with a `sharding` the rank's STORED rows (flat u-first face vectors, [1, rows, nx, 1] cell arrays) - the
+    rank's part of L = 1/2 |u_K|^2 is the sum over the faces it owns."""
     import torch
     import diffpiso as dp
-    vel_t = B["vel_t"].clone().requires_grad_(True)
-    p_t = B["p_t"].clone().requires_grad_(True)
     ext = dp.Material.extrapolation_mode(B["domain"].boundaries)
-    velocity = dp.StaggeredGrid(vel_t, B["domain"].box, extrapolation=ext)
-    pressure = dp.CenteredGrid(p_t, B["domain"].box, dp.pressure_extrapolation(B["domain"].boundaries))
+    p_ext = dp.pressure_extrapolation(B["domain"].boundaries)
+    if sharding is None:
+        vel_t = B["vel_t"].clone().requires_grad_(True)
+        p_t = B["p_t"].clone().requires_grad_(True)
+        velocity = dp.StaggeredGrid(vel_t, B["domain"].box, extrapolation=ext)
+        pressure = dp.CenteredGrid(p_t, B["domain"].box, p_ext)
+    else:
+        vel_t = sharding.scatter_staggered(B["vel_t"]).requires_grad_(True)
+        p_t = sharding.scatter_cells(B["p_t"]).requires_grad_(True)
+        velocity = sharding.staggered_grid(vel_t, B["domain"].box, ext)
+        pressure = sharding.centered_grid(p_t, B["domain"].box, p_ext)
     va, pa, vn, pn, warn = dp.unroll_piso_steps(velocity, pressure, B["dt"], B["sim"], step_count=B["steps"])
     u = vn.staggered_tensor()
-    if sharding is None:
-        loss = 0.5 * (u ** 2).sum()
-    else:
-        loss = 0.5 * ((u * sharding.owned_mask_staggered(u.device)) ** 2).sum()
+    loss = 0.5 * (u ** 2).sum() if sharding is None else 0.5 * sharding.owned_sum_of_squares(u)
     if B.get("p_tol_adjoint"):
         B["ps"].accuracy = B["p_tol_adjoint"]
     loss.backward()
     return u.detach(), pn.data.detach(), vel_t.grad, p_t.grad, float(loss.detach()), float(sum(float(w.detach().sum()) for w in warn))
+
+
+def owned_rows_npz(path, sh, u, p, du, dp_):
+    """The rows a rank owns, in the shapes the tests gather them in: face rows [rows, nx + 1] (v: the staggered tensor's pad column is
+    zero), cell rows [rows, nx]."""
+    import numpy as np
+    import torch
+
+    def faces(flat):
+        uo, vo = sh.owned_faces(flat)
+        vpad = torch.cat([vo, torch.zeros((vo.shape[0], 1), dtype=vo.dtype, device=vo.device)], dim=1)
+        return uo.cpu().numpy(), vpad.cpu().numpy()
+    u_u, u_v = faces(u)
+    du_u, du_v = faces(du)
+    np.savez(path, j0=sh.j0, j1=sh.j1, last=1 if sh.last else 0, u_v=u_v, u_u=u_u, p=sh.owned_cells(p).cpu().numpy(),
+             du_v=du_v, du_u=du_u, dp=sh.owned_cells(dp_).cpu().numpy())
 
 
 def main():
@@ -97,26 +123,45 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     device = torch.device("cuda", 0)
     out = {"rank": rank, "world": world, "ok": False}
+    if world == 1:
+        # the ONE-GPU run of the case in a process of its own: the memory figure the sharded ranks' 1 / ranks is measured against
+        try:
+            B = build_case(case, device)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats(device)
+            u, p, du, dp_, loss, warn = run_case(B, None)
+            torch.cuda.synchronize()
+            out.update(ok=True, max_memory_allocated=int(torch.cuda.max_memory_allocated(device)), loss=loss, warn=warn,
+                       cg_iterations=[int(B["ps"].last_iterations or 0), int(B["ps"].last_adjoint_iterations or 0)],
+                       bicgstab_iterations=[int(v) for v in (B["lin"].last_iterations or ())])
+            ny = B["ny"]
+            np.savez(os.path.join(outdir, "rank0.npz"), j0=0, j1=ny, last=1, u_v=u[0, :, :, 0].cpu().numpy(), u_u=u[0, :ny, :, 1].cpu().numpy(),
+                     p=p[0, :, :, 0].cpu().numpy(), du_v=du[0, :, :, 0].cpu().numpy(), du_u=du[0, :ny, :, 1].cpu().numpy(),
+                     dp=dp_[0, :, :, 0].cpu().numpy())
+        except Exception as e:
+            import traceback
+            out["error"] = "%r\n%s" % (e, traceback.format_exc()[-1500:])
+        print("SLAB_WORKER " + json.dumps(out), flush=True)
+        return
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     comm = None
     try:
         from diffpiso.distributed import SlabCommunicator
         from diffpiso.sharding import StepSharding
-        B = build_case(case, device)
+        # the case is built on the HOST (every rank the same seeded arrays of the whole grid): only the rank's rows go to its GPU
+        B = build_case(case, torch.device("cpu") if os.environ.get("PISO_SHARDED_HOST_SETUP", "1") == "1" else device)
         nx, ny = B["nx"], B["ny"]
         comm = SlabCommunicator(rank=rank, world=world, device=device, transport="peer", row_capacity=26 * nx + 64)
         B["ps"].slab_comm = comm
         B["lin"].slab_comm = comm
         sh = B["sim"].sharding = StepSharding(comm, nx, ny)
+        torch.cuda.reset_peak_memory_stats(device)
         u, p, du, dp_, loss, warn = run_case(B, sh)
         sh.check()
-        j0, j1, last = sh.j0, sh.j1, 1 if sh.last else 0
-        np.savez(os.path.join(outdir, "rank%d.npz" % rank), j0=j0, j1=j1, last=last,
-                 u_v=u[0, j0:j1 + last, :, 0].cpu().numpy(), u_u=u[0, j0:j1, :, 1].cpu().numpy(), p=p[0, j0:j1, :, 0].cpu().numpy(),
-                 du_v=du[0, j0:j1 + last, :, 0].cpu().numpy(), du_u=du[0, j0:j1, :, 1].cpu().numpy(), dp=dp_[0, j0:j1, :, 0].cpu().numpy())
+        owned_rows_npz(os.path.join(outdir, "rank%d.npz" % rank), sh, u, p, du, dp_)
         st = comm.stats()
         out.update(ok=True, loss=loss, warn=warn, stats=st, halo_exchanges=sh.exchanges,
                    cg_iterations=[int(B["ps"].last_iterations or 0), int(B["ps"].last_adjoint_iterations or 0)],

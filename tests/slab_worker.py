@@ -1,6 +1,6 @@
 """One rank of a multi-process slab-CG run (started by tests/test_gpu_multiproc.py and usable by hand):
 
-    python tests/slab_worker.py RANK WORLD PORT NX NY WALLS [SHARE_GPU]
+    python tests/slab_worker.py RANK WORLD PORT NX NY WALLS [SHARE_GPU [REGION_ROWS]]
 
 Every rank builds the same NX x NY pressure system (same seed), solves its slab through the PEER transport (mailboxes mapped
 across processes with hipIpc handles; torch.distributed/gloo only carries the handles) and compares its rows with the
@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
 def main():
     rank, world, port, nx, ny, walls = (int(v) for v in sys.argv[1:7])
     share = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+    region_rows = int(sys.argv[8]) if len(sys.argv) > 8 else 16
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -36,7 +37,8 @@ def main():
         j0, j1 = slab_rows(rank, world, ny)
         own = slice(j0 * nx, j1 * nx)
         comm = SlabCommunicator(rank=rank, world=world, transport="peer", row_capacity=nx)
-        N.set_option("cg_persist_r", 16)              # 16-row regions: a slab of ny/world rows takes (nx/128)(ny/world/16)/8 CUs
+        N.set_option("cg_persist_r", region_rows)     # 16-row regions: a slab of ny/world rows takes (nx/128)(ny/world/16)/8 CUs; 4: the
+                                                      # instance BASELINE config 5's 4096 x 512 slabs run (two regions per wave)
         N.set_option("cg_segment", 60)                # several segments per solve
         runs = {}
         for label, persist in (("persistent", -1), ("two_kernel", 0)):

@@ -95,6 +95,35 @@ def test_config1_lid_driven_cavity_at_the_reference_scripts_own_settings():
     assert err[0] < 1e-3 and err[1] < 2e-2
 
 
+def test_config1_script_settings_deterministic_variant_fixed_iterations():
+    """The DETERMINISTIC twin of the test above (its bound is calibrated on the oracle's own spread and would let a 5x regression pass):
+    the reference script's settings - advection solver 1e-3 / 100, residual_reset 10, dt 0.01, fluid at rest under the moving lid, 3
+    steps - with the two things that make the comparison irreproducible taken out: the pressure CG runs UN-shifted and for a FIXED
+    number of iterations (accuracy 1e-30 is never met: every solve of both sides ends at the cap of 200, twenty reset cycles).  Same
+    iterates on both sides then; held at 1e-5 on u AND p, iteration counts equal."""
+    import diffpiso as dp
+    c = make_case("cavity", 65, 64, seed=0, viscosity=1.0 / 400)
+    c["vel"][...] = np.where(c["dirichlet_mask"], c["dirichlet_values"], 0.0)
+    c["dt"] = 0.01
+    kw = dict(lin_tol=1e-3, lin_max_it=100, p_tol=1e-30, p_max_it=200, p_reset=10, rank_deficient=False)
+    s = oracle_setup(c, **kw)
+    P = product_setup(c, **kw)
+    steps = 3
+    vels, ps, tapes = R.run_steps(s, c["vel"], c["p"] * 0, c["dt"], c["dirichlet_values"], steps)
+    assert not any(t["warn"] for t in tapes) and all(t["it1"] == 200 and t["it2"] == 200 for t in tapes)
+    vel = dp.StaggeredGrid(torch.tensor(c["vel"], device="cuda"), P["velocity"].box, extrapolation=P["velocity"].extrapolation)
+    prs = dp.CenteredGrid(torch.zeros_like(P["pressure"].data), P["pressure"].box, P["pressure"].extrapolation)
+    its = []
+    cg = P["ps"]._cg
+    P["ps"]._cg = lambda *a, **k: (lambda r: (its.append(int(r[1])), r)[1])(cg(*a, **k))
+    with torch.no_grad():
+        va, pa, vn, pn, warn = dp.unroll_piso_steps(vel, prs, c["dt"], P["sim"], step_count=steps)
+    assert float(sum(w.sum() for w in warn)) == 0 and its == [200] * (2 * steps), its
+    err = (rel(vn.staggered_tensor().cpu().numpy(), vels[-1]), rel(pn.data[0, :, :, 0].cpu().numpy(), ps[-1]))
+    print("config 1, script settings, un-shifted, 200 fixed iterations per solve: HIP vs oracle (u, p) %.2e %.2e" % err)
+    assert err[0] <= 1e-5 and err[1] <= 1e-5, err
+
+
 def test_config2_decaying_turbulence_256_forward():
     import diffpiso as dp
     c = make_case("periodic", 256, 256, seed=0, viscosity=1e-3)

@@ -174,3 +174,28 @@ def test_fused_step_launch_count():
             counts[flag] = sum(e.count for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA)
     print("device launches per forward step: fused %d, torch glue %d" % (counts[True], counts[False]))
     assert counts[True] < 0.6 * counts[False]
+
+
+def test_forward_step_launches_outside_the_solver_iterations():
+    """EVERY device launch of a forward step - the library's and torch's element-wise kernels between them - with the solvers'
+    iteration kernels (bi_*, cg_*) left out: the step is a launch train on small grids (BASELINE config 2), so what torch adds between
+    the library's launches counts.  Round 5: the sign of `-matrix_values` is applied inside the solver's conversion pass, the unroll
+    hands the step's flat face vector on (no stack + flatten between steps), the pressure increments are built once per unroll."""
+    import diffpiso as dp
+    from torch.profiler import ProfilerActivity, profile
+    c = make_case("periodic", 32, 128, seed=1)
+    P = product_setup(c, lin_tol=1e-3, lin_max_it=2, p_tol=1e-1, p_max_it=10, p_reset=1000)
+    with torch.no_grad():
+        dp.unroll_piso_steps(P["velocity"], P["pressure"], c["dt"], P["sim"], step_count=2)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            dp.unroll_piso_steps(P["velocity"], P["pressure"], c["dt"], P["sim"], step_count=3)
+            torch.cuda.synchronize()
+    rows = [(e.key, e.count) for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA]
+    solver = lambda k: any(t in k for t in ("bi_", "cg_", "Memcpy", "Memset", "memcpy", "memset"))
+    outside = [(k, n) for k, n in rows if not solver(k)]
+    per_step = sum(n for _, n in outside) / 3.0
+    for k, n in sorted(outside, key=lambda r: -r[1]):
+        print("%5.1f per step  %s" % (n / 3.0, k[:110]))
+    print("launches per forward step outside the solver iterations: %.1f (library glue + torch)" % per_step)
+    assert per_step <= 40, per_step

@@ -358,3 +358,19 @@ def test_bench_auto_policy_tries_peer_then_rccl_then_reports_replicas():
     # 6. ... also when this rank's own attempt looked fine but another rank's did not
     att, calls = script((line, None, False, False))
     assert bench.sharded_headline(att, False)[3] == 3
+
+
+def test_closure_initialiser_is_tensorflows_glorot_normal():
+    """networks.py:57 draws the closure's weights from `tf.glorot_normal_initializer()`: a normal distribution truncated at two standard
+    deviations whose standard deviation AFTER the truncation is sqrt(2 / (fan_in + fan_out)).  A random draw cannot be compared value
+    for value; its support and its scale can."""
+    import numpy as np
+    from diffpiso.closure import FullyConvNetwork
+    net = FullyConvNetwork(seed=5)
+    for w in net.weights:
+        cout, cin, k, _ = w.shape
+        std = np.sqrt(2.0 / (k * k * cin + k * k * cout))
+        sig = std / 0.87962566103423978
+        assert float(w.abs().max()) <= 2.0 * sig * (1 + 1e-6)                       # truncated at two sigma
+        if w.numel() >= 4096:                                                        # (enough samples for a 5 % statement)
+            assert abs(float(w.std()) / std - 1.0) < 0.05, (tuple(w.shape), float(w.std()), std)
