@@ -9,6 +9,8 @@ calls in its own process for the one-GPU run of the same case.
 
 CASE:  fixture:bench1024_tight_step.npz      the benchmark's workload at 1024^2 with converged solves (committed oracle fixture)
        fixture:cfg3_tml_512x256.npz          BASELINE config 3, 4 steps (x periodic, walls in y)
+       case:NAME:NY:NX:STEPS                 a set-up of tests/cases.py at that size (spatial_ml: inflow / outflow in x, open y, a per-face viscosity field;
+                                             cavity: solid lid row, no-slip mask), converged solves
        box:NX:NY:STEPS:TOL:MAXIT:SHIFT[:PERSIST]   decaying turbulence on an NX x NY periodic box (bench.py's builder); SHIFT 0: un-shifted CG;
                                              PERSIST 0: two-kernel CG iteration"""
 import importlib.util
@@ -57,6 +59,16 @@ def build_case(case, device):
         P = product_setup(c, device=str(device), **meta["solver"])
         return dict(sim=P["sim"], lin=P["lin"], ps=P["ps"], domain=P["domain"], vel_t=P["vel_tensor"], p_t=P["pressure"].data, dt=c["dt"],
                     steps=meta["steps"], nx=c["nx"], ny=c["ny"], p_tol_adjoint=None, dx_yx=c["dx_yx"])
+    if kind == "case":
+        # case:NAME:NY:NX:STEPS - a synthetic set-up of tests/cases.py (cavity, spatial_ml, xper_ywall, periodic) with converged solves
+        from tests.cases import make_case, product_setup
+        name, ny, nx, steps = rest.split(":")[:4]
+        c = make_case(name, int(ny), int(nx), seed=3, variable_viscosity=(name == "spatial_ml"))
+        # (un-shifted pressure CG: the shifted operator's iterates are not reproducible between summation orders)
+        P = product_setup(c, device=str(device), lin_tol=1e-9, lin_max_it=300, p_tol=1e-10, p_max_it=6000, p_reset=1000, lin_double=True,
+                          rank_deficient=False)
+        return dict(sim=P["sim"], lin=P["lin"], ps=P["ps"], domain=P["domain"], vel_t=P["vel_tensor"], p_t=P["pressure"].data, dt=c["dt"],
+                    steps=int(steps), nx=c["nx"], ny=c["ny"], p_tol_adjoint=None, dx_yx=c["dx_yx"])
     if kind == "box":
         import bench
         nx, ny, steps, tol, maxit, shift = rest.split(":")[:6]

@@ -198,4 +198,4 @@ def test_forward_step_launches_outside_the_solver_iterations():
     for k, n in sorted(outside, key=lambda r: -r[1]):
         print("%5.1f per step  %s" % (n / 3.0, k[:110]))
     print("launches per forward step outside the solver iterations: %.1f (library glue + torch)" % per_step)
-    assert per_step <= 40, per_step
+    assert per_step <= 30, per_step                         # (measured 23.3: 11 library launches, ~12 torch copies / adds / fills)

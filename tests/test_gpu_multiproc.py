@@ -86,9 +86,15 @@ def test_slab_cg_config5_slab_shape_four_row_regions_over_two_processes():
         assert r["ok"], r
         print(r)
         for label in ("persistent", "two_kernel"):
-            assert max(r[label]["fixed_run_diffs"]) <= 2e-10, (label, r[label])
+            # fixed runs of 1, 2, 7, 45 iterations: round-off level.  After 150 iterations on this 8 : 1 grid two summation orders of the
+            # SAME iteration are 1e-8 apart (the system does not converge within 20 000 iterations: round-off is amplified along the
+            # way) - the slab's two-kernel iteration, which is not in question, shows exactly that (measured 1.1e-8, the persistent
+            # kernel 2.1e-8): the persistent kernel is held to the same order of magnitude there
+            assert max(r[label]["fixed_run_diffs"][:4]) <= 2e-10, (label, r[label])
+            assert r[label]["fixed_run_diffs"][4] <= 1e-7, (label, r[label])
             ita, itb = r[label]["converged_its"]
             assert (ita == itb == 20000) or (ita < 20000 and itb < 20000 and abs(ita - itb) <= max(10, 0.1 * ita)), (label, ita, itb)
+        assert r["persistent"]["fixed_run_diffs"][4] <= 5 * max(r["two_kernel"]["fixed_run_diffs"][4], 1e-12), r
         assert r["stats"]["persistent_iterations"] > 150 and r["stats"]["persistent_fallbacks"] == 0, r["stats"]
         assert r["stats"]["solves_verified"] >= 5 and r["stats"]["verification_failures"] == 0, r["stats"]
 

@@ -220,6 +220,29 @@ def test_sharded_config3_mixing_layer_512x256_two_ranks_fields_vs_one_gpu_and_or
     assert not bad, bad
 
 
+@pytest.mark.parametrize("name,ny,nx", [("spatial_ml", 64, 48), ("cavity", 48, 40), ("xper_ywall", 32, 128)])
+def test_sharded_small_cases_without_periodic_x_two_ranks_vs_one_gpu(name, ny, nx):
+    """The row map's CSR numbering and the kernels' boundary rules on grids that are NOT periodic in x (and not in y): the spatial
+    mixing layer (inflow / outflow, open y, a per-face viscosity FIELD cut to the rank's rows), the lid-driven cavity (solid lid row,
+    no-slip mask cut to the rank's mask rows) and a channel whose rows the persistent kernel tiles - two unrolled steps forward +
+    reverse sweep on two ranks against the one-GPU product."""
+    case = "case:%s:%d:%d:2" % (name, ny, nx)
+    u1, p1, du1, dp1, loss1, its1, B = _one_gpu(case)
+    res, out = _spawn(2, case)
+    u, p, du, dp, edges = _gather(out, 2, ny, nx)
+    for r in res:
+        assert r["warn"] == 0 and r["halo_exchanges"] > 0, r
+    tol = 2e-5
+    for nm, a, b in (("u", u, u1), ("p", p, p1), ("dL/du_0", du, du1), ("dL/dp_0", dp, dp1)):
+        e = float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+        scale = np.linalg.norm(du1) if nm == "dL/dp_0" else None
+        if scale is not None:          # (dL/dp_0 cancels to a small part of its summands: measured against dL/du_0's size)
+            e = float(np.linalg.norm(a.astype(np.float64) - b) / max(scale, np.linalg.norm(b)))
+        print("%s %dx%d x2 %s: sharded vs one GPU rel-L2 %.2e" % (name, ny, nx, nm, e))
+        assert e <= tol, (nm, e)
+    assert abs(sum(r["loss"] for r in res) - loss1) <= 1e-5 * abs(loss1)
+
+
 def _bench_dump(env_extra, args, nproc, outdir, timeout=600):
     """bench.py (torch.distributed.run for nproc > 1) with --dump-fields: the path tests/test_gpu_multiproc.py::test_config5_4096_eight_slabs runs."""
     s = socket.socket()
