@@ -668,7 +668,18 @@ def slab_self_check(n, device, rank, world, iters=300, share_gpu=False, settings
         comm.close()
 
 
+def _keep_stdout_for_the_json_line():
+    """stdout carries ONE line, the JSON record.  Libraries write there too - RCCL prints a version banner through C stdio when its first
+    communicator comes up, flushed at exit, i.e. BEHIND the record - so file descriptor 1 is pointed at stderr for the rest of the
+    process and Python's sys.stdout keeps the original descriptor."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w", buffering=1)
+    os.dup2(2, 1)
+    sys.stdout = real
+
+
 def main():
+    _keep_stdout_for_the_json_line()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)

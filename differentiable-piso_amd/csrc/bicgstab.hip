@@ -913,10 +913,10 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
     else if (need <= 16) launch_sweeps<T, 16>(aL, aU, grid_b, in, out, stream);
     else launch_sweeps<T, 32>(aL, aU, grid_b, in, out, stream);
   };
-  // Scalar stages folded into their consumers (folded_scalars): one GPU, systems whose partial records a block re-reads in passing
-  // (<= 512 per component: grids up to 1024 x 512).  14 -> 9 launches per iteration; at 2048^2 the 1024 x 2 blocks of a vector kernel
-  // would each read 16 KB of records for nothing measurable.  Option bicg_fold: 0 never, 1 on one GPU at any size.
-  const bool fold_ok = !slab && opt(OPT_BICG_FOLD) != 0 && (gv <= 512 || opt(OPT_BICG_FOLD) == 1);
+  // Scalar stages folded into their consumers (folded_scalars) on one GPU: 14 -> 9 launches per iteration.  Every block of a vector
+  // kernel re-reads the partial records in passing (<= 16 KB, L2-resident); at 2048^2 the five launches saved are worth 2.5 % of the
+  // iteration (606 -> 590 us, round 5), more on smaller grids.  Option bicg_fold: 0 never.
+  const bool fold_ok = !slab && opt(OPT_BICG_FOLD) != 0;
   auto F = [&](int stage) -> int { return fold_ok ? stage + 1 : 0; };
 
   BiHost<T> host;

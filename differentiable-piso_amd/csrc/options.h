@@ -21,7 +21,7 @@ enum Opt {
   OPT_CG_XCD_LOCAL,        // 0: never run a small grid's persistent solve on the workgroups of ONE XCD (default: on)
   OPT_CG_TINY,             // 0: never solve a tiny grid (<= 4 608 cells) inside one workgroup (cg_tiny.h; default: on)
   OPT_CONV_LDS,            // 0: the closure's forward / input-gradient convolutions read their operands straight from L2 (default: staged through LDS)
-  OPT_BICG_FOLD,           // 0: the BiCGStab scalar stages always run as launches of their own; 1: folded into their consumers at any size (default: small systems)
+  OPT_BICG_FOLD,           // 0: the BiCGStab scalar stages always run as launches of their own (default: folded into their consumers on one GPU)
   OPT_SLAB_FORCE,          // 1: a communicator of ONE rank still runs the slab code paths (ring of one: halo messages and sums to itself; tests)
   OPT_SLAB_HOP_TICKS,      // measurements only: the persistent slab kernel's cross-GPU records leave this many 10 ns ticks late (an emulated link latency)
   OPT_COUNT

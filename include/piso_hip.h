@@ -72,8 +72,8 @@ int piso_device_count(void);
  * concurrent solve.  Names: cg_persist (0 forbid / 1 force the persistent CG kernel), cg_persist_r (2|4|16 rows per region),
  * cg_persist_half (0: small regions never run with one working wave per SIMD and twice the workgroups; 1: wherever that fits the
  * chip, also where it pushes a grid out of one XCD),
- * bicg_fold (0: the scalar stages of BiCGStab always run as launches of their own; 1: folded into the kernels that consume them at
- * any size on one GPU; default: systems of up to 512 partial records per component),
+ * bicg_fold (0: the scalar stages of BiCGStab always run as launches of their own; default: folded into the kernels that consume
+ * them on one GPU),
  * slab_force (1: a communicator of ONE rank still runs the slab code paths - a ring with itself; tests), conv_lds (0: the closure's
  * forward / input-gradient convolutions read their operands straight from L2 instead of staging them through LDS),
  * cg_segment (iterations per persistent launch),

@@ -9,7 +9,7 @@ have, want = t["2048"]["cg_persist"]["kernel_source_sha"], bench.kernel_source_s
 if have != want:
     sys.exit("profiles/traffic.json was taken on sources %s, this tree has %s" % (have, want))
 if len(sys.argv) > 1:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith('{"metric"')][-1])
     r = d["roofline"]
     if r["traffic"] is None:
         sys.exit("the bench line carries no PMC traffic: %s" % r["frac_source"])
