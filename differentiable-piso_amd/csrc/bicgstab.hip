@@ -51,6 +51,11 @@ __device__ __forceinline__ int frame_ordinal(int i, int j, int W, int H) {
 }
 
 template <typename T>
+struct alignas(2 * sizeof(T)) Pair { T a, b; };
+template <typename T>
+struct Tri { T d, a, b; };
+
+template <typename T>
 struct CompScalars {
   T rho, rho_prev, alpha, omega, beta, nrm;
   int done;        // 1: converged (||r|| < tol) -- no more work in this pass
@@ -67,7 +72,9 @@ struct BiArgs {
   int* ecol;
   T* eval;
   // preconditioner
-  T *dinv, *LW, *LS, *UE, *UN;
+  // (what a sweep needs of a row is ONE element: it reads its input and one coefficient stream and writes)
+  Pair<T>* L;                     // {LW, LS}
+  Tri<T>* U;                      // {1 / d, UE, UN}
   // vectors
   const T* rhs;
   T *x, *r, *rh, *p, *v, *t, *y, *ph, *sh;
@@ -297,16 +304,116 @@ __global__ __launch_bounds__(kBlock) void bi_factor(BiArgs<T> a) {
         const int k = kb + i;
         const T d = A[e] - B[e] / dl;
         const T inv = (T)1 / d;
-        a.dinv[k] = inv;
-        a.LW[k] = (i >= 1) ? cw[e] / dl : (T)0;
-        a.LS[k] = (j > j0) ? cs[e] / d_prev_row[e] : (T)0;
-        a.UE[k] = ce[e] * inv;
-        a.UN[k] = (j < j1 - 1) ? cn[e] * inv : (T)0;
+        a.L[k] = Pair<T>{(i >= 1) ? cw[e] / dl : (T)0, (j > j0) ? cs[e] / d_prev_row[e] : (T)0};
+        a.U[k] = Tri<T>{inv, ce[e] * inv, (j < j1 - 1) ? cn[e] * inv : (T)0};
         dl = d;
         d_prev_row[e] = d;
         cN_prev_row[e] = cn[e];
       }
     }
+  }
+}
+
+template <int E>
+__device__ __forceinline__ int sweep_slot(int s) { return (E % 2 == 0) ? s + (s >> 5) : s; }
+template <typename T, int E>
+// (rows of up to 1 024 faces - E <= 4 - are no faster this way: 512^2 89.6 against 97.1 us per iteration, 1024^2 166.0 against 160.9)
+constexpr bool kSweepLds = E >= 5 && (size_t)4 * (E * kBlock + E * 8) * sizeof(T) <= (size_t)96 * 1024;
+
+// bi_factor with coalesced memory accesses (see bi_sweep_lds): a row's five coefficients come in element order, are staged in LDS,
+// read back E consecutive elements per thread; the five results go the same way back.  Bitwise bi_factor's results.
+template <typename T, int E>
+__global__ __launch_bounds__(kBlock) void bi_factor_lds(BiArgs<T> a) {
+  constexpr int kRow = E * kBlock + E * 8;
+  __shared__ Moebius<T> smem[4];
+  __shared__ T bw[kRow], bs[kRow], bc[kRow], be[kRow], bn[kRow];
+  const int c = blockIdx.y;
+  const Geo& g = a.g;
+  const int band = a.bb[c] + blockIdx.x;
+  if (band >= a.be[c]) return;
+  const int W = g.W[c], H = g.H[c];
+  const int j0 = band * g.R, j1 = min(j0 + g.R, H);
+  const int i0 = threadIdx.x * E;
+  T d_prev_row[E], cN_prev_row[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { d_prev_row[e] = 1; cN_prev_row[e] = 0; }
+  T lw[E], ls[E], lc[E], le[E], ln[E];
+  auto load_row = [&](int j) __attribute__((always_inline)) {
+    const int kb = a.kx(c, j * W);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = e * kBlock + threadIdx.x;
+      lw[e] = ls[e] = lc[e] = le[e] = ln[e] = 0;
+      if (i < W && j < j1) {
+        const int k = kb + i;
+        lw[e] = a.cW[k]; ls[e] = a.cS[k]; lc[e] = a.cC[k]; le[e] = a.cE[k]; ln[e] = a.cN[k];
+      }
+    }
+  };
+  auto stage_row = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = e * kBlock + threadIdx.x;
+      if (i < W) {
+        const int q = sweep_slot<E>(i);
+        bw[q] = lw[e]; bs[q] = ls[e]; bc[q] = lc[e]; be[q] = le[e]; bn[q] = ln[e];
+      }
+    }
+  };
+  load_row(j0);
+  stage_row();
+  __syncthreads();
+  for (int j = j0; j < j1; ++j) {
+    const int kb = a.kx(c, j * W);
+    T A[E], B[E], cw[E], cs[E], ce[E], cn[E];
+    Moebius<T> f = Moebius<T>::identity();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = i0 + e;
+      A[e] = 1; B[e] = 0; cw[e] = cs[e] = ce[e] = cn[e] = 0;
+      if (i < W) {
+        const int q = sweep_slot<E>(i);
+        cw[e] = bw[q]; cs[e] = bs[q]; ce[e] = be[q]; cn[e] = bn[q];
+        const T ce_left = (i >= 1) ? (e > 0 ? ce[e - 1] : be[sweep_slot<E>(i - 1)]) : (T)0;
+        A[e] = bc[q] - ((j > j0) ? cs[e] * cN_prev_row[e] / d_prev_row[e] : (T)0);
+        B[e] = cw[e] * ce_left;
+        const Moebius<T> fi = {A[e], -B[e], (T)1, (T)0};
+        f = Moebius<T>::then(f, fi);
+      }
+    }
+    load_row(j + 1);                              // (in flight during the scan)
+    const Moebius<T> pre = block_exclusive_scan(f, smem);      // (its barriers: every thread has read the staged row)
+    T dl = (threadIdx.x == 0 || pre.c == 0) ? (T)1 : pre.a / pre.c;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = i0 + e;
+      if (i < W) {
+        const int q = sweep_slot<E>(i);
+        const T d = A[e] - B[e] / dl;
+        const T inv = (T)1 / d;
+        bw[q] = (i >= 1) ? cw[e] / dl : (T)0;                           // LW
+        bs[q] = (j > j0) ? cs[e] / d_prev_row[e] : (T)0;                // LS
+        bc[q] = inv;
+        be[q] = ce[e] * inv;                                            // UE
+        bn[q] = (j < j1 - 1) ? cn[e] * inv : (T)0;                      // UN
+        dl = d;
+        d_prev_row[e] = d;
+        cN_prev_row[e] = cn[e];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = e * kBlock + threadIdx.x;
+      if (i < W) {
+        const int q = sweep_slot<E>(i);
+        a.L[kb + i] = Pair<T>{bw[q], bs[q]};
+        a.U[kb + i] = Tri<T>{bc[q], be[q], bn[q]};
+      }
+    }
+    __syncthreads();                              // (the results are out of LDS)
+    stage_row();                                  // row j + 1
+    __syncthreads();
   }
 }
 
@@ -329,8 +436,8 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
   if (band >= a.be[c]) return;
   const int W = g.W[c], H = g.H[c];
   const int j0 = band * g.R, j1 = min(j0 + g.R, H);
-  const T* __restrict__ ca = FWD ? a.LW : a.UE;
-  const T* __restrict__ cb = FWD ? a.LS : a.UN;
+  const Pair<T>* __restrict__ cl = a.L;
+  const Tri<T>* __restrict__ cu = a.U;
   // element order along the scan: forward i ascending, backward i descending
   const int i0 = threadIdx.x * E;
   T prev[E];
@@ -338,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
   for (int e = 0; e < E; ++e) prev[e] = 0;
   // The rows of a band are sequential (y(k) needs y(k-W)), but what a row READS from memory does not depend on the
   // recurrence: the inputs of row jj+1 are loaded while row jj is scanned (a row is latency-, not bandwidth-bound).
-  T nv[E], na[E], nb[E];
+  T nv[E], na[E], nb[E], nd[E];
   auto load_row = [&](int jj) __attribute__((always_inline)) {
     const int j = FWD ? j0 + jj : j1 - 1 - jj;
     const int kb = a.kx(c, j * W);
@@ -346,12 +453,13 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
     for (int e = 0; e < E; ++e) {
       const int s = i0 + e;
       const int i = FWD ? s : W - 1 - s;
-      nv[e] = 0; na[e] = 0; nb[e] = 0;
+      nv[e] = 0; na[e] = 0; nb[e] = 0; nd[e] = 0;
       if (s < W && jj < j1 - j0) {
         const int k = kb + i;
-        T v = in[k];
-        if (!FWD) v *= a.dinv[k];
-        nv[e] = v; na[e] = ca[k]; nb[e] = cb[k];
+        nv[e] = in[k];
+        if (FWD) { const Pair<T> cf = cl[k]; na[e] = cf.a; nb[e] = cf.b; }
+        else { const Tri<T> cf = cu[k]; nd[e] = cf.d; na[e] = cf.a; nb[e] = cf.b; }      // (y / d is formed where the row is consumed: a product
+                                                                                        // here would wait for the loads BEFORE the scan they hide behind)
       }
     }
   };
@@ -366,7 +474,8 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
       const int s = i0 + e;                       // position along the scan
       m[e] = 0; cst[e] = 0;
       if (s < W) {
-        cst[e] = nv[e] - nb[e] * prev[e];
+        const T v = FWD ? nv[e] : nv[e] * nd[e];
+        cst[e] = v - nb[e] * prev[e];
         m[e] = -na[e];
         f = Affine<T>::then(f, Affine<T>{m[e], cst[e]});
       }
@@ -388,6 +497,103 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
   }
 }
 
+// The same sweep with every global access COALESCED (round 5).  In bi_sweep a thread loads and stores the E consecutive elements it
+// scans: lanes E * 4 bytes apart, every load / store instruction touches E cache lines' worth of address range per 64 lanes and every
+// line is visited by E instructions - the texture addresser, not HBM, set the pace (2048^2: 2.0 / 3.6 TB/s forward / backward).  Here
+// a row moves between memory and LDS in element order (lane = consecutive element) and between LDS and the scan's registers in
+// thread order (E consecutive elements per thread; odd strides are conflict-free, even ones padded by one word per 32).  One more
+// barrier per row; the arithmetic, the scan and therefore every result are bitwise bi_sweep's.  2048^2, per sweep: forward 47 -> 29 us,
+// backward 68 -> 33 us (of which 59 -> 33 by forming y / d behind the scan instead of in front of it, see load_row).
+template <typename T, int E, bool FWD>
+__global__ __launch_bounds__(kBlock) void bi_sweep_lds(BiArgs<T> a, const T* __restrict__ in, T* __restrict__ out) {
+  constexpr int kRow = E * kBlock + E * 8;
+  __shared__ Affine<T> smem[4];
+  __shared__ T smem_fold[16];
+  __shared__ T bv[kRow], ba[kRow], bb[kRow], by[kRow];
+  const int c = blockIdx.y;
+  const Geo& g = a.g;
+  if (folded_scalars(a, c, smem_fold).done) return;
+  const int band = a.bb[c] + blockIdx.x;
+  if (band >= a.be[c]) return;
+  const int W = g.W[c], H = g.H[c];
+  const int j0 = band * g.R, j1 = min(j0 + g.R, H);
+  const Pair<T>* __restrict__ cl = a.L;
+  const Tri<T>* __restrict__ cu = a.U;
+  const int i0 = threadIdx.x * E;
+  T prev[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) prev[e] = 0;
+  T nv[E], na[E], nb[E], nd[E];
+  // memory side: column i = e * kBlock + thread (ascending addresses in both directions); its place along the scan is i (forward) or
+  // W - 1 - i (backward)
+  auto load_row = [&](int jj) __attribute__((always_inline)) {
+    const int j = FWD ? j0 + jj : j1 - 1 - jj;
+    const int kb = a.kx(c, j * W);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = e * kBlock + threadIdx.x;
+      nv[e] = 0; na[e] = 0; nb[e] = 0; nd[e] = 0;
+      if (i < W && jj < j1 - j0) {
+        const int k = kb + i;
+        nv[e] = in[k];
+        if (FWD) { const Pair<T> cf = cl[k]; na[e] = cf.a; nb[e] = cf.b; }
+        else { const Tri<T> cf = cu[k]; nd[e] = cf.d; na[e] = cf.a; nb[e] = cf.b; }      // (y / d is formed where the row is consumed: a product
+                                                                                        // here would wait for the loads BEFORE the scan they hide behind)
+      }
+    }
+  };
+  auto stage_row = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = e * kBlock + threadIdx.x;
+      if (i < W) {
+        const int q = sweep_slot<E>(FWD ? i : W - 1 - i);
+        bv[q] = FWD ? nv[e] : nv[e] * nd[e]; ba[q] = na[e]; bb[q] = nb[e];
+      }
+    }
+  };
+  load_row(0);
+  stage_row();
+  __syncthreads();
+  for (int jj = 0; jj < j1 - j0; ++jj) {
+    const int j = FWD ? j0 + jj : j1 - 1 - jj;
+    const int kb = a.kx(c, j * W);
+    T m[E], cst[E];
+    Affine<T> f = Affine<T>::identity();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int s = i0 + e;                       // position along the scan
+      m[e] = 0; cst[e] = 0;
+      if (s < W) {
+        const int q = sweep_slot<E>(s);
+        cst[e] = bv[q] - bb[q] * prev[e];
+        m[e] = -ba[q];
+        f = Affine<T>::then(f, Affine<T>{m[e], cst[e]});
+      }
+    }
+    load_row(jj + 1);                             // (in flight during the scan below)
+    const Affine<T> pre = block_exclusive_scan(f, smem);      // (its barriers: every thread has read the staged row)
+    T yl = pre.c;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int s = i0 + e;
+      if (s < W) {
+        const T y = fma(m[e], yl, cst[e]);
+        by[sweep_slot<E>(s)] = y;
+        prev[e] = y;
+        yl = y;
+      }
+    }
+    stage_row();                                  // row jj + 1
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = e * kBlock + threadIdx.x;
+      if (i < W) out[kb + i] = by[sweep_slot<E>(FWD ? i : W - 1 - i)];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // vector kernels (blockIdx.y = component); partial sums to parts[c][q][blockIdx.x]
 // ------------------------------------------------------------------------------------------------------------------
@@ -399,30 +605,6 @@ __device__ __forceinline__ void store_partials(BiArgs<T>& a, int c, T* vals, int
   block_sum<T, 4>(tmp, smem);
   if (threadIdx.x == 0)
     for (int q = 0; q < count; ++q) a.parts[(c * 4 + q) * kBiParts + slot0 + blockIdx.x] = tmp[q];
-}
-
-// y = B x for one row (near stencil + exceptions)
-template <typename T>
-__device__ __forceinline__ T stencil_row(const BiArgs<T>& a, int c, int row, const T* __restrict__ x) {
-  const Geo& g = a.g;
-  const int W = g.W[c], H = g.H[c];
-  const int i = row % W, j = row / W, k = a.kx(c, row);
-  T acc = 0;
-  if (j >= 1) acc = fma(a.cS[k], x[k - W], acc);
-  if (i >= 1) acc = fma(a.cW[k], x[k - 1], acc);
-  acc = fma(a.cC[k], x[k], acc);
-  if (i <= W - 2) acc = fma(a.cE[k], x[k + 1], acc);
-  if (j <= H - 2) acc = fma(a.cN[k], x[k + W], acc);
-  const int fo = frame_ordinal(i, j, W, H);
-  if (fo >= 0) {
-    const int base = (g.f0[c] + fo) * kExcSlots;
-#pragma unroll
-    for (int q = 0; q < kExcSlots; ++q) {
-      const int ec = a.ecol[base + q];
-      if (ec >= 0) acc = fma(a.eval[base + q], x[a.kx(c, ec)], acc);
-    }
-  }
-  return acc;
 }
 
 // ---- the scalar recurrences between the vector kernels (multi_bicgstab_ilu_linear_solve_op.cu.cc:263-408): one STAGE per reduction
@@ -501,22 +683,6 @@ __device__ __forceinline__ CompScalars<T> folded_scalars(const BiArgs<T>& a, int
   return s;
 }
 
-// r = rhs - B x ; rh = r ; p = v = 0 ; partial ||r||^2   (:266-300)
-template <typename T>
-__global__ __launch_bounds__(kBlock) void bi_residual_init(BiArgs<T> a) {
-  __shared__ T smem[16];
-  const int c = blockIdx.y;
-  if (a.sc[c].done) return;
-  T acc[1] = {0};
-  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
-    const int k = a.kx(c, row);
-    const T r = a.rhs[k] - stencil_row(a, c, row, a.x);
-    a.r[k] = r; a.rh[k] = r; a.p[k] = 0; a.v[k] = 0;
-    acc[0] = fma(r, r, acc[0]);
-  }
-  store_partials(a, c, acc, 1, smem);
-}
-
 // p = r + beta (p - omega v)   (:316-318)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void bi_update_p(BiArgs<T> a) {
@@ -535,25 +701,90 @@ __global__ __launch_bounds__(kBlock) void bi_update_p(BiArgs<T> a) {
 // interior (owned rows minus kEdgeRows face rows at either end: they read owned rows only), part 2 = those edge rows (they read
 // the neighbours' rows - and, across the periodic seam, the wrap partners v[ny] / v[0] / v[1] / v[ny - 1] of rows 1 / ny - 1 / ny / 0).
 constexpr int kEdgeRows = 2;
+// Four rows per thread and pass, 256 rows apart (every access of a wave is one run of consecutive elements): all loads of the four
+// rows - five coefficients, five values of `in` at clamped addresses, the dot product's partner - are issued before anything is
+// consumed, the store of a row cannot stand between the loads of the next (round 5: with one row per pass, a division per row and the
+// stores in between the kernel moved 2.85 TB/s at 2048^2).  The row's sum keeps stencil_row's order: S, W, C, E, N, exceptions.
+constexpr int kSpmvRows = 4;
+// emit(k, o, d): row at place k of the vectors, o = (B in)(row), d = extra[k] (loaded with the row's other operands)
+template <typename T, typename Emit>
+__device__ __forceinline__ void stencil_rows(const BiArgs<T>& a, int c, const T* __restrict__ in, const T* __restrict__ extra, int part,
+                                             Emit emit) {
+  const Geo& g = a.g;
+  const int W = g.W[c], H = g.H[c];
+  const int eb = kEdgeRows * W;                             // elements of one edge
+  const int begin = part == 1 ? a.rb[c] + eb : (part == 2 ? 0 : a.rb[c]);
+  const int end = part == 1 ? a.re[c] - eb : (part == 2 ? 2 * eb : a.re[c]);
+  const float inv_w = 1.0f / (float)W;
+  for (int base = begin + blockIdx.x * (kSpmvRows * kBlock); base < end; base += gridDim.x * (kSpmvRows * kBlock)) {
+    int k[kSpmvRows], fo[kSpmvRows];
+    bool on[kSpmvRows], hs[kSpmvRows], hw[kSpmvRows], he[kSpmvRows], hn[kSpmvRows];
+    T cs[kSpmvRows], cw[kSpmvRows], cc[kSpmvRows], ce[kSpmvRows], cn[kSpmvRows];
+    T xs[kSpmvRows], xw[kSpmvRows], xc[kSpmvRows], xe[kSpmvRows], xn[kSpmvRows], d[kSpmvRows];
+#pragma unroll
+    for (int u = 0; u < kSpmvRows; ++u) {
+      const int idx = base + u * kBlock + (int)threadIdx.x;
+      on[u] = idx < end;
+      const int idc = on[u] ? idx : end - 1;                  // (a row of the range: its loads are harmless, nothing is stored)
+      const int row = part == 2 ? (idc < eb ? a.rb[c] + idc : a.re[c] - 2 * eb + idc) : idc;
+      int j = (int)((float)row * inv_w), i = row - j * W;     // (rows < 2^31, j < 2^22: the float quotient is off by one at most)
+      if (i < 0) { --j; i += W; } else if (i >= W) { ++j; i -= W; }
+      fo[u] = frame_ordinal(i, j, W, H);
+      k[u] = a.kx(c, row);
+      hs[u] = j >= 1; hw[u] = i >= 1; he[u] = i <= W - 2; hn[u] = j <= H - 2;
+      cs[u] = a.cS[k[u]]; cw[u] = a.cW[k[u]]; cc[u] = a.cC[k[u]]; ce[u] = a.cE[k[u]]; cn[u] = a.cN[k[u]];
+      xs[u] = in[hs[u] ? k[u] - W : k[u]]; xw[u] = in[hw[u] ? k[u] - 1 : k[u]]; xc[u] = in[k[u]];
+      xe[u] = in[he[u] ? k[u] + 1 : k[u]]; xn[u] = in[hn[u] ? k[u] + W : k[u]];
+      d[u] = extra[k[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < kSpmvRows; ++u) {
+      T o = 0;
+      o = hs[u] ? fma(cs[u], xs[u], o) : o;
+      o = hw[u] ? fma(cw[u], xw[u], o) : o;
+      o = fma(cc[u], xc[u], o);
+      o = he[u] ? fma(ce[u], xe[u], o) : o;
+      o = hn[u] ? fma(cn[u], xn[u], o) : o;
+      if (fo[u] >= 0) {
+        const int eb0 = (g.f0[c] + fo[u]) * kExcSlots;
+#pragma unroll
+        for (int q = 0; q < kExcSlots; ++q) {
+          const int ec = a.ecol[eb0 + q];
+          if (ec >= 0) o = fma(a.eval[eb0 + q], in[a.kx(c, ec)], o);
+        }
+      }
+      if (on[u]) emit(k[u], o, d[u]);
+    }
+  }
+}
+
 template <typename T, int WHICH>
 __global__ __launch_bounds__(kBlock) void bi_spmv(BiArgs<T> a, const T* __restrict__ in, T* __restrict__ out, int part, int slot0) {
   __shared__ T smem[16];
   const int c = blockIdx.y;
   if (a.sc[c].done) return;
-  const int W = a.g.W[c];
-  const int eb = kEdgeRows * W;                             // elements of one edge
-  const int begin = part == 1 ? a.rb[c] + eb : (part == 2 ? 0 : a.rb[c]);
-  const int end = part == 1 ? a.re[c] - eb : (part == 2 ? 2 * eb : a.re[c]);
   T acc[2] = {0, 0};
-  for (int idx = begin + blockIdx.x * kBlock + threadIdx.x; idx < end; idx += gridDim.x * kBlock) {
-    const int row = part == 2 ? (idx < eb ? a.rb[c] + idx : a.re[c] - 2 * eb + idx) : idx;
-    const int k = a.kx(c, row);
-    const T o = stencil_row(a, c, row, in);
+  stencil_rows(a, c, in, WHICH == 0 ? a.rh : a.r, part, [&](int k, T o, T d) __attribute__((always_inline)) {
     out[k] = o;
-    if (WHICH == 0) acc[0] = fma(a.rh[k], o, acc[0]);
-    else { acc[0] = fma(o, a.r[k], acc[0]); acc[1] = fma(o, o, acc[1]); }
-  }
+    if (WHICH == 0) acc[0] = fma(d, o, acc[0]);
+    else { acc[0] = fma(o, d, acc[0]); acc[1] = fma(o, o, acc[1]); }
+  });
   store_partials(a, c, acc, WHICH == 0 ? 1 : 2, smem, slot0);
+}
+
+// r = rhs - B x ; rh = r ; p = v = 0 ; partial ||r||^2   (:266-300)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void bi_residual_init(BiArgs<T> a) {
+  __shared__ T smem[16];
+  const int c = blockIdx.y;
+  if (a.sc[c].done) return;
+  T acc[1] = {0};
+  stencil_rows(a, c, a.x, a.rhs, 0, [&](int k, T o, T d) __attribute__((always_inline)) {
+    const T r = d - o;
+    a.r[k] = r; a.rh[k] = r; a.p[k] = 0; a.v[k] = 0;
+    acc[0] = fma(r, r, acc[0]);
+  });
+  store_partials(a, c, acc, 1, smem);
 }
 
 // x += coef * dir ; r -= coef * w ; partials ||r||^2, rh.r     (WHICH 0: alpha, p_hat, v ; 1: omega, s_hat, t)
@@ -713,9 +944,21 @@ struct BiHost {
 };
 
 template <typename T, int E>
-static void launch_factor(const BiArgs<T>& a, dim3 gb, hipStream_t s) { bi_factor<T, E><<<gb, kBlock, 0, s>>>(a); }
+static void launch_factor(const BiArgs<T>& a, dim3 gb, hipStream_t s) {
+  if constexpr (kSweepLds<T, E> && (size_t)5 * (E * kBlock + E * 8) * sizeof(T) <= (size_t)96 * 1024) {
+    if (opt(OPT_BICG_SWEEP_LDS) != 0) { bi_factor_lds<T, E><<<gb, kBlock, 0, s>>>(a); return; }
+  }
+  bi_factor<T, E><<<gb, kBlock, 0, s>>>(a);
+}
 template <typename T, int E>
 static void launch_sweeps(const BiArgs<T>& aL, const BiArgs<T>& aU, dim3 gb, const T* in, T* out, hipStream_t s) {
+  if constexpr (kSweepLds<T, E>) {
+    if (opt(OPT_BICG_SWEEP_LDS) != 0) {
+      bi_sweep_lds<T, E, true><<<gb, kBlock, 0, s>>>(aL, in, aL.y);
+      bi_sweep_lds<T, E, false><<<gb, kBlock, 0, s>>>(aU, aU.y, out);
+      return;
+    }
+  }
   bi_sweep<T, E, true><<<gb, kBlock, 0, s>>>(aL, in, aL.y);
   bi_sweep<T, E, false><<<gb, kBlock, 0, s>>>(aU, aU.y, out);
 }
@@ -743,10 +986,11 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   const Geo& g = a.g;
   const size_t ntot = slab_rows ? (size_t)a.M.n_u + a.M.n_v : (size_t)g.n[0] + g.n[1];
   Arena ar(ws, ws_bytes);
-  a.cS = ar.take<T>(ntot); a.cW = ar.take<T>(ntot); a.cC = ar.take<T>(ntot); a.cE = ar.take<T>(ntot); a.cN = ar.take<T>(ntot);
-  a.dinv = ar.take<T>(ntot); a.LW = ar.take<T>(ntot); a.LS = ar.take<T>(ntot); a.UE = ar.take<T>(ntot); a.UN = ar.take<T>(ntot);
-  a.r = ar.take<T>(ntot); a.rh = ar.take<T>(ntot); a.p = ar.take<T>(ntot); a.v = ar.take<T>(ntot); a.t = ar.take<T>(ntot);
-  a.y = ar.take<T>(ntot); a.ph = ar.take<T>(ntot); a.sh = ar.take<T>(ntot);
+  auto tk = [&](size_t n) { return ar.take<T>(n); };
+  a.cS = tk(ntot); a.cW = tk(ntot); a.cC = tk(ntot); a.cE = tk(ntot); a.cN = tk(ntot);
+  a.L = reinterpret_cast<Pair<T>*>(tk(2 * ntot)); a.U = reinterpret_cast<Tri<T>*>(tk(3 * ntot));
+  a.r = tk(ntot); a.rh = tk(ntot); a.p = tk(ntot); a.v = tk(ntot); a.t = tk(ntot);
+  a.y = tk(ntot); a.ph = tk(ntot); a.sh = tk(ntot);
   a.ecol = ar.take<int>((size_t)(g.F[0] + g.F[1]) * kExcSlots);
   a.eval = ar.take<T>((size_t)(g.F[0] + g.F[1]) * kExcSlots);
   T* const pbuf0 = ar.take<T>(2 * 2 * 4 * kBiParts);                      // two buffers of partial sums (see BiArgs::parts_in)
