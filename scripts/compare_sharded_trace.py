@@ -28,15 +28,16 @@ def short(n):
 
 one, r1 = load(sys.argv[1]), load(sys.argv[2])
 print("""How to read this table
+* Round 5: a rank's tensors hold its STORED rows only (owned rows + halo rows, piso_slab_t in include/piso_hip.h).
 * Kernels whose grid follows the problem size (bi_sweep, bi_spmv, bi_factor, csr_matvec, cg_k2, cg_setup_coeffs, cg_init, ...) launch
-  HALF the workgroups on rank 1: they work on the rank's rows only.
-* Kernels with a FIXED grid (assemble_kernel 8192, bi_update_* / bi_residual_init / bi_convert 2048, cg_k1 1024, laplace_kernel 4096,
-  face / divergence / gradient kernels 2048: grid-stride loops) show the same workgroup count on both sides; their loops run over
-  the row window [rb, re) of the rank (piso_set_row_window; a.rb / a.re in bicgstab.hip) - compare their time per launch, with a grain
-  of salt: the two ranks of this run SHARE one GPU, so rank 1's kernels compete with rank 0's.
-* The at::native kernels are torch's element-wise copies / adds / fills between the library's kernels.  The sharded step keeps its
-  arrays GLOBALLY indexed (only the rank's rows + halo rows are ever valid), so these ~60 small launches per step still touch the
-  whole box on every rank: replicated element-wise work, ~3 % of a 2048^2-per-GPU step at N = 8 (DESIGN.md 6).
+  HALF the workgroups on rank 1.
+* Kernels with a FIXED grid (bi_update_* / bi_residual_init / bi_convert 2048, cg_k1 1024, laplace_kernel 4096, face / divergence /
+  gradient kernels 2048: grid-stride loops) show the same workgroup count on both sides; their loops run over the rank's owned rows
+  (the *_slab entry points) - compare their time per launch, with a grain of salt: the two ranks of this run SHARE one GPU, so
+  rank 1's kernels compete with rank 0's.
+* The at::native kernels are torch's element-wise copies / adds / fills between the library's kernels: on tensors of the rank's
+  stored rows their workgroup counts are ~(ny / N + 4 ... 6) / ny of the one-GPU run's (0.33 - 0.56 here; rounds 3 - 4, with globally
+  indexed arrays: 1.00).
 * peer_* / slab_collapse / bi_flags_allreduce: the mailbox traffic of the sharded run (halo rows, all-reduced dot products); their
   time per launch is mostly waiting for the other rank, which here runs on the same GPU.
 * The CG of this shared-GPU run iterates on the two-kernel path (two persistent kernels cannot be resident side by side on one GPU);
