@@ -142,7 +142,38 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
   const T* val = val_all + k0;
   const int* col = col_all + k0;
   bool nan_seen = false, bad = false;
-  for (int row = a.rb[c] + blockIdx.x * kBlock + threadIdx.x; row < a.re[c]; row += gridDim.x * kBlock) {
+  // One GPU: the CSR entries of the block's 256 rows are one run of the arrays.  They are fetched by element (coalesced, all loads of
+  // the chunk in flight at once) and wait in LDS for the thread that owns their row: a thread walking its own row's entries makes one
+  // dependent round trip to memory per entry.
+  constexpr int kPer = 6;                                    // staged entries per thread (5 per row + slack)
+  constexpr int kStage = kPer * kBlock;
+  __shared__ int lcol[kStage];
+  __shared__ T lval[kStage];
+  const bool stage_ok = !M.on;
+  for (int base = a.rb[c] + blockIdx.x * kBlock; base < a.re[c]; base += gridDim.x * kBlock) {
+    const int row = base + (int)threadIdx.x;
+    int q0 = 0;
+    bool staged = false;
+    if (stage_ok) {
+      q0 = rp[base];
+      const int q1 = rp[min(base + kBlock, a.re[c])];
+      staged = q1 - q0 <= kStage;
+      __syncthreads();                                       // (the block's previous chunk has been read)
+      if (staged) {
+        int tc[kPer];
+        T tv[kPer];
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) {
+          const int q = q0 + u * kBlock + (int)threadIdx.x;
+          tc[u] = q < q1 ? col[q] : 0;
+          tv[u] = q < q1 ? val[q] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < kPer; ++u) { lcol[u * kBlock + threadIdx.x] = tc[u]; lval[u * kBlock + threadIdx.x] = tv[u]; }
+      }
+      __syncthreads();
+    }
+    if (row >= a.re[c]) continue;
     const int i = row % W, j = row / W;
     const int fo = frame_ordinal(i, j, W, H);
     T s = 0, w = 0, cc = 0, e = 0, nn = 0;
@@ -152,8 +183,8 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
     // classify the entries of A's own row (also validates the pattern in transpose mode)
     const int rl = a.rpx(c, row);
     for (int q = rp[rl]; q < rp[rl + 1]; ++q) {
-      const int cq = col[q];
-      const T vq = sgn * val[q];
+      const int cq = staged ? lcol[q - q0] : col[q];
+      const T vq = sgn * (staged ? lval[q - q0] : val[q]);
       nan_seen |= is_nan(vq);
       int kind;   // 0..4 near slots, 5 exception
       if (cq == row) kind = 2;
