@@ -84,6 +84,8 @@ struct BiArgs {
   CompScalars<T>* sc;             // [2]: the scalars this launch works with
   const CompScalars<T>* sc_prev;  // fold != 0: the record BEFORE the folded stages (`sc` is then written by block 0, read by nobody)
   int fold;                       // scalar stages the blocks of this launch apply themselves before they start (see folded_scalars)
+  int fuse_p;                     // forward sweep only: its input is the direction update p = r + beta (p - omega v) (:316-318), formed (and
+                                  // stored to p) on the way in - bi_update_p's pass over three vectors and its launch are saved
   int* flags;                     // [0]: unsupported pattern, [1]: NaN seen
   float tol;
   int nparts;                     // blocks per component that write partial records (<= kBiParts; the rest stays zero)
@@ -457,12 +459,14 @@ template <typename T>
 __device__ __forceinline__ CompScalars<T> folded_scalars(const BiArgs<T>& a, int c, T* smem);   // (with the scalar stages, below)
 
 template <typename T, int E, bool FWD>
-__global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restrict__ in, T* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* in, T* __restrict__ out) {
   __shared__ Affine<T> smem[4];
   __shared__ T smem_fold[16];
   const int c = blockIdx.y;
   const Geo& g = a.g;
-  if (folded_scalars(a, c, smem_fold).done) return;         // (folded, forward sweep of s: the ||s|| test)
+  const CompScalars<T> sc = folded_scalars(a, c, smem_fold);  // (folded: the ||s|| test in front of s_hat; ||r|| test, rho / beta in front of p_hat)
+  if (sc.done) return;
+  const bool fuse = FWD && a.fuse_p;
   const int band = a.bb[c] + blockIdx.x;
   if (band >= a.be[c]) return;
   const int W = g.W[c], H = g.H[c];
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
   for (int e = 0; e < E; ++e) prev[e] = 0;
   // The rows of a band are sequential (y(k) needs y(k-W)), but what a row READS from memory does not depend on the
   // recurrence: the inputs of row jj+1 are loaded while row jj is scanned (a row is latency-, not bandwidth-bound).
-  T nv[E], na[E], nb[E], nd[E];
+  T nv[E], na[E], nb[E], nd[E], n2[E], n3[E];
   auto load_row = [&](int jj) __attribute__((always_inline)) {
     const int j = FWD ? j0 + jj : j1 - 1 - jj;
     const int kb = a.kx(c, j * W);
@@ -484,10 +488,11 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
     for (int e = 0; e < E; ++e) {
       const int s = i0 + e;
       const int i = FWD ? s : W - 1 - s;
-      nv[e] = 0; na[e] = 0; nb[e] = 0; nd[e] = 0;
+      nv[e] = 0; na[e] = 0; nb[e] = 0; nd[e] = 0; n2[e] = 0; n3[e] = 0;
       if (s < W && jj < j1 - j0) {
         const int k = kb + i;
         nv[e] = in[k];
+        if (fuse) { n2[e] = a.v[k]; n3[e] = a.r[k]; }
         if (FWD) { const Pair<T> cf = cl[k]; na[e] = cf.a; nb[e] = cf.b; }
         else { const Tri<T> cf = cu[k]; nd[e] = cf.d; na[e] = cf.a; nb[e] = cf.b; }      // (y / d is formed where the row is consumed: a product
                                                                                         // here would wait for the loads BEFORE the scan they hide behind)
@@ -505,7 +510,8 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
       const int s = i0 + e;                       // position along the scan
       m[e] = 0; cst[e] = 0;
       if (s < W) {
-        const T v = FWD ? nv[e] : nv[e] * nd[e];
+        T v = FWD ? nv[e] : nv[e] * nd[e];
+        if (fuse) { v = (nv[e] - sc.omega * n2[e]) * sc.beta + n3[e]; a.p[kb + s] = v; }
         cst[e] = v - nb[e] * prev[e];
         m[e] = -na[e];
         f = Affine<T>::then(f, Affine<T>{m[e], cst[e]});
@@ -536,14 +542,16 @@ __global__ __launch_bounds__(kBlock) void bi_sweep(BiArgs<T> a, const T* __restr
 // barrier per row; the arithmetic, the scan and therefore every result are bitwise bi_sweep's.  2048^2, per sweep: forward 47 -> 29 us,
 // backward 68 -> 33 us (of which 59 -> 33 by forming y / d behind the scan instead of in front of it, see load_row).
 template <typename T, int E, bool FWD>
-__global__ __launch_bounds__(kBlock) void bi_sweep_lds(BiArgs<T> a, const T* __restrict__ in, T* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void bi_sweep_lds(BiArgs<T> a, const T* in, T* __restrict__ out) {
   constexpr int kRow = E * kBlock + E * 8;
   __shared__ Affine<T> smem[4];
   __shared__ T smem_fold[16];
   __shared__ T bv[kRow], ba[kRow], bb[kRow], by[kRow];
   const int c = blockIdx.y;
   const Geo& g = a.g;
-  if (folded_scalars(a, c, smem_fold).done) return;
+  const CompScalars<T> sc = folded_scalars(a, c, smem_fold);
+  if (sc.done) return;
+  const bool fuse = FWD && a.fuse_p;
   const int band = a.bb[c] + blockIdx.x;
   if (band >= a.be[c]) return;
   const int W = g.W[c], H = g.H[c];
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void bi_sweep_lds(BiArgs<T> a, const T* __r
   T prev[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) prev[e] = 0;
-  T nv[E], na[E], nb[E], nd[E];
+  T nv[E], na[E], nb[E], nd[E], n2[E], n3[E];
   // memory side: column i = e * kBlock + thread (ascending addresses in both directions); its place along the scan is i (forward) or
   // W - 1 - i (backward)
   auto load_row = [&](int jj) __attribute__((always_inline)) {
@@ -563,28 +571,32 @@ __global__ __launch_bounds__(kBlock) void bi_sweep_lds(BiArgs<T> a, const T* __r
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int i = e * kBlock + threadIdx.x;
-      nv[e] = 0; na[e] = 0; nb[e] = 0; nd[e] = 0;
+      nv[e] = 0; na[e] = 0; nb[e] = 0; nd[e] = 0; n2[e] = 0; n3[e] = 0;
       if (i < W && jj < j1 - j0) {
         const int k = kb + i;
         nv[e] = in[k];
+        if (fuse) { n2[e] = a.v[k]; n3[e] = a.r[k]; }
         if (FWD) { const Pair<T> cf = cl[k]; na[e] = cf.a; nb[e] = cf.b; }
         else { const Tri<T> cf = cu[k]; nd[e] = cf.d; na[e] = cf.a; nb[e] = cf.b; }      // (y / d is formed where the row is consumed: a product
                                                                                         // here would wait for the loads BEFORE the scan they hide behind)
       }
     }
   };
-  auto stage_row = [&]() __attribute__((always_inline)) {
+  auto stage_row = [&](int jj) __attribute__((always_inline)) {      // the row load_row(jj) asked for
+    const int kb = a.kx(c, (FWD ? j0 + jj : j1 - 1 - jj) * W);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int i = e * kBlock + threadIdx.x;
       if (i < W) {
         const int q = sweep_slot<E>(FWD ? i : W - 1 - i);
-        bv[q] = FWD ? nv[e] : nv[e] * nd[e]; ba[q] = na[e]; bb[q] = nb[e];
+        T v = FWD ? nv[e] : nv[e] * nd[e];
+        if (fuse && jj < j1 - j0) { v = (nv[e] - sc.omega * n2[e]) * sc.beta + n3[e]; a.p[kb + i] = v; }
+        bv[q] = v; ba[q] = na[e]; bb[q] = nb[e];
       }
     }
   };
   load_row(0);
-  stage_row();
+  stage_row(0);
   __syncthreads();
   for (int jj = 0; jj < j1 - j0; ++jj) {
     const int j = FWD ? j0 + jj : j1 - 1 - jj;
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void bi_sweep_lds(BiArgs<T> a, const T* __r
         yl = y;
       }
     }
-    stage_row();                                  // row jj + 1
+    stage_row(jj + 1);
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -1026,7 +1038,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   a.eval = ar.take<T>((size_t)(g.F[0] + g.F[1]) * kExcSlots);
   T* const pbuf0 = ar.take<T>(2 * 2 * 4 * kBiParts);                      // two buffers of partial sums (see BiArgs::parts_in)
   CompScalars<T>* const scbuf0 = ar.take<CompScalars<T>>(2 * 2);         // two scalar records (see BiArgs::sc_prev)
-  a.parts = pbuf0; a.parts_in = pbuf0; a.sc = scbuf0; a.sc_prev = scbuf0; a.fold = 0;
+  a.parts = pbuf0; a.parts_in = pbuf0; a.sc = scbuf0; a.sc_prev = scbuf0; a.fold = 0; a.fuse_p = 0;
   a.flags = ar.take<int>(2);
   a.rhs = rhs; a.x = x_out; a.tol = tol;
   if (!ar.ok()) { set_error_msg("piso_multi_bicgstab_ilu: workspace too small"); return PISO_ERR_INVALID_ARG; }
@@ -1176,8 +1188,10 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   else launch_factor<T, 32>(a, grid_b, stream);
   PISO_LAUNCH_CHECK();
 
-  auto precond = [&](const T* in, T* out, int fold) {           // (fold: scalar stages the blocks of the forward sweep apply first)
-    const BiArgs<T> aL = next(fold, false), aU = next(0, false);
+  auto precond = [&](const T* in, T* out, int fold, int fuse_p) {       // (fold: scalar stages the blocks of the forward sweep apply first)
+    BiArgs<T> aL = next(fold, false);
+    aL.fuse_p = fuse_p;
+    const BiArgs<T> aU = next(0, false);
     if (need <= 1) launch_sweeps<T, 1>(aL, aU, grid_b, in, out, stream);
     else if (need <= 2) launch_sweeps<T, 2>(aL, aU, grid_b, in, out, stream);
     else if (need <= 3) launch_sweeps<T, 3>(aL, aU, grid_b, in, out, stream);
@@ -1193,6 +1207,8 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   // iteration (606 -> 590 us, round 5), more on smaller grids.  Option bicg_fold: 0 never.
   const bool fold_ok = !slab && opt(OPT_BICG_FOLD) != 0;
   auto F = [&](int stage) -> int { return fold_ok ? stage + 1 : 0; };
+  // p = r + beta (p - omega v) inside the forward sweep of p_hat (BiArgs::fuse_p): 9 -> 8 launches per iteration.  Option bicg_fuse_p 0: never.
+  const int fuse_p = opt(OPT_BICG_FUSE_P) != 0;
 
   BiHost<T> host;
   auto fetch = [&]() -> int {
@@ -1224,13 +1240,16 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
           if (fold_ok) fold_p = q > 0 ? (F(ST_CHECK_R) | (F(ST_RHO_BETA) << 4)) : F(ST_RHO_BETA);
           else { const int rc = scalar(ST_RHO_BETA); if (rc != PISO_OK) return rc; }
         }
-        bi_update_p<T><<<grid_v, kBlock, 0, stream>>>(next(fold_p, false));
-        precond(a.p, a.ph, 0);
+        if (fuse_p) precond(a.p, a.ph, fold_p, 1);
+        else {
+          bi_update_p<T><<<grid_v, kBlock, 0, stream>>>(next(fold_p, false));
+          precond(a.p, a.ph, 0, 0);
+        }
         { const int rc = spmv(0, a.ph, a.v); if (rc != PISO_OK) return rc; }
         if (!fold_ok) { const int rc = scalar(ST_ALPHA); if (rc != PISO_OK) return rc; }
         bi_update_xr<T, 0><<<grid_v, kBlock, 0, stream>>>(next(F(ST_ALPHA), true));
         if (!fold_ok) { const int rc = scalar(ST_CHECK_S); if (rc != PISO_OK) return rc; }
-        precond(a.r, a.sh, F(ST_CHECK_S));
+        precond(a.r, a.sh, F(ST_CHECK_S), 0);
         { const int rc = spmv(1, a.sh, a.t); if (rc != PISO_OK) return rc; }
         if (!fold_ok) { const int rc = scalar(ST_OMEGA); if (rc != PISO_OK) return rc; }
         bi_update_xr<T, 1><<<grid_v, kBlock, 0, stream>>>(next(F(ST_OMEGA), true));

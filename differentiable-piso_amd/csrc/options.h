@@ -23,6 +23,7 @@ enum Opt {
   OPT_CONV_LDS,            // 0: the closure's forward / input-gradient convolutions read their operands straight from L2 (default: staged through LDS)
   OPT_BICG_FOLD,           // 0: the BiCGStab scalar stages always run as launches of their own (default: folded into their consumers on one GPU)
   OPT_BICG_SWEEP_LDS,      // 0: the triangular sweeps address memory in scan order (bi_sweep) instead of staging rows through LDS (bi_sweep_lds)
+  OPT_BICG_FUSE_P,         // 0: the direction update of BiCGStab runs as a launch of its own (bi_update_p) instead of inside the forward sweep that reads it
   OPT_SLAB_FORCE,          // 1: a communicator of ONE rank still runs the slab code paths (ring of one: halo messages and sums to itself; tests)
   OPT_SLAB_HOP_TICKS,      // measurements only: the persistent slab kernel's cross-GPU records leave this many 10 ns ticks late (an emulated link latency)
   OPT_COUNT

@@ -73,7 +73,8 @@ int piso_device_count(void);
  * cg_persist_half (0: small regions never run with one working wave per SIMD and twice the workgroups; 1: wherever that fits the
  * chip, also where it pushes a grid out of one XCD),
  * bicg_fold (0: the scalar stages of BiCGStab always run as launches of their own; default: folded into the kernels that consume
- * them on one GPU),
+ * them on one GPU), bicg_sweep_lds (0: sweeps and factorisation address memory in scan order instead of staging rows through LDS),
+ * bicg_fuse_p (0: the direction update of BiCGStab is a launch of its own instead of part of the forward sweep that reads it),
  * slab_force (1: a communicator of ONE rank still runs the slab code paths - a ring with itself; tests), conv_lds (0: the closure's
  * forward / input-gradient convolutions read their operands straight from L2 instead of staging them through LDS),
  * cg_segment (iterations per persistent launch),

@@ -341,6 +341,38 @@ def test_bicgstab_folded_scalar_stages_are_bitwise_neutral(name, shape, transpos
         assert max(out[0][1]) < max_it and np.abs(out[0][0]).max() > 0
 
 
+_KERNEL_VARIANT_CASES = [("periodic", (40, 36), False, 1e-5, 200), ("cavity", (40, 36), True, 1e-30, 5), ("spatial_ml", (40, 36), False, 1e-30, 3),
+                         ("periodic", (64, 1300), False, 1e-6, 50), ("xper_ywall", (48, 1280), True, 1e-30, 4),      # rows of > 1 024 faces: bi_sweep_lds
+                         ("periodic", (16, 2304), False, 1e-30, 3)]                                                # E = 10 -> the 16-element instance (padded LDS slots)
+
+
+@pytest.mark.parametrize("name,shape,transpose,tol,max_it", _KERNEL_VARIANT_CASES)
+def test_bicgstab_kernel_variants_are_bitwise_neutral(name, shape, transpose, tol, max_it, piso_option):
+    """Round 5's kernel variants change HOW memory is walked, not what is computed: the sweeps / the factorisation that stage rows through
+    LDS (bi_sweep_lds, bi_factor_lds; option bicg_sweep_lds) and the direction update inside the forward sweep (BiArgs::fuse_p; option
+    bicg_fuse_p) must give bitwise the solution and the iteration counts of the kernels they replace."""
+    from diffpiso.solvers import multi_bicgstab_ilu_native
+    ny, nx = shape
+    c = make_case(name, ny, nx, seed=3)
+    s = oracle_setup(c)
+    beta = float(np.prod(c["dx_yx"])) / c["dt"]
+    val, rp, col, _, _ = R.advection_matrix(s, c["vel"], beta)
+    rhs = np.random.default_rng(5).standard_normal(s.n_u + s.n_v).astype(f32)
+    x0 = R.flatten_staggered(c["vel"], True)
+    out = []
+    for lds, fuse in ((0, 0), (1, 0), (0, 1), (-1, -1)):
+        piso_option("bicg_sweep_lds", lds)
+        piso_option("bicg_fuse_p", fuse)
+        warn = torch.zeros(1, dtype=torch.uint8, device="cuda")
+        x, its = multi_bicgstab_ilu_native(dev(-val), dev(rp), dev(col), dev(rhs), dev(x0), nx, ny, tol, max_it, transpose, 0, warn)
+        out.append((x.cpu().numpy(), [int(i) for i in its], int(warn.item())))
+    for x, its, w in out[1:]:
+        assert its == out[0][1] and w == out[0][2]
+        np.testing.assert_array_equal(x, out[0][0])
+    if tol > 1e-10:
+        assert max(out[0][1]) < max_it and np.abs(out[0][0]).max() > 0
+
+
 def test_bicgstab_failure_and_nan_semantics():
     from diffpiso.solvers import multi_bicgstab_ilu_native
     c = make_case("periodic", 12, 12, seed=2)
