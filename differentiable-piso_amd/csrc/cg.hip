@@ -97,7 +97,7 @@ template <typename T, typename CT, bool RECON, bool SYMV>
 constexpr bool kHas16 = (sizeof(T) == 8 && sizeof(CT) == 4) || (sizeof(T) == 4 && sizeof(CT) == 4 && RECON && SYMV);
 
 template <typename T, typename CT, bool RECON, bool SYMV>
-static const void* persist_kernel(int R, bool ragged = false) {
+static const void* persist_kernel(int R, bool ragged = false, int NQ = 0) {
   if constexpr (sizeof(T) == 8 && RECON && SYMV) {
     if (ragged) {
       switch (R) {
@@ -106,6 +106,9 @@ static const void* persist_kernel(int R, bool ragged = false) {
         default: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 16, 1, RECON, SYMV, false, true>);
       }
     }
+  }
+  if constexpr (sizeof(T) == 8 && sizeof(CT) == 4 && SYMV) {
+    if (R == 2 && NQ == 1) return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 1, RECON, SYMV>);
   }
   switch (R) {
     case 2: return reinterpret_cast<const void*>(&cg_persist1<T, CT, 2, 2, RECON, SYMV>);
@@ -203,6 +206,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     // (measured at 2048^2-class work per workgroup: regions of 4 rows to make a 64-workgroup grid fit one XCD lose more in the row
     // loops than the shorter exchange wins - 512^2: 6.2 against 4.5 us per iteration; 256^2, 16 workgroups either way: 3.8 against 4.3)
     persist_R = shape.R; persist_NQ = shape.NQ; persist_grid = shape.grid; pc.nreg = shape.nreg; pc.ntx = shape.ntx;
+
     // Small regions: ONE wave with work per SIMD instead of two (waves 4-7 of a workgroup own nothing), twice the workgroups, wherever
     // the doubled grid still fits the chip: a wave then never waits at the exchange's first barrier for the wave it shares a SIMD
     // with (0.6 us of a ~4 us iteration).  Measured: 256^2 3.80 -> 3.47 us per iteration, 512^2 4.45 -> 4.08, 1024 x 256 4.48 -> 4.08,
@@ -219,6 +223,19 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
       }
     }
     xcd_local = local_ok && (persist_R == 2 || persist_R == 4) && persist_grid <= kXcdCus;
+    // Regions of 2 rows on a grid that runs chip-wide anyway (more than one XCD's worth of workgroups): ONE region per wave, all eight
+    // waves of a workgroup at work - the row work per SIMD of the half-occupancy shape (two waves x one region instead of one wave
+    // x two) with half its workgroups in the exchange.  Round 5, A/B on one box: 1024 x 256 (config 4) 3.73 -> 3.57 us per iteration,
+    // 512^2 3.72 -> 3.60; 256^2 stays on its XCD (2.69 against 3.41).  Option cg_persist_nq: 0 never, 1 wherever the chip holds it.
+    {
+      constexpr bool kHasNq1 = sizeof(T) == 8 && sizeof(CT) == 4;
+      const int nq = opt(OPT_CG_PERSIST_NQ);
+      if (kHasNq1 && symmetric && nq != 0 && persist_R == 2 && !a.nx_true && (!xcd_local || nq == 1) &&
+          (shape.nreg + kPersistWaves - 1) / kPersistWaves <= cus) {
+        persist_NQ = 1; pc.waves = kPersistWaves; xcd_local = false;
+        persist_grid = (shape.nreg + kPersistWaves - 1) / kPersistWaves;
+      }
+    }
     if (persist_R && n < 16384 && force != 1 && !a.nx_true) persist_R = 0;    // tiny grids: two-kernel path (a padded grid is here BECAUSE it is small)
   }
   const bool ragged = a.nx_true != 0;
@@ -239,7 +256,7 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     // their registers only with rebuilt diagonals.)
     constexpr bool kCanSymO = sizeof(CT) == 4 && (RECON || sizeof(T) == 8);
     const void* kfn = persist_kernel<T, CT, RECON, false>(persist_R);
-    if constexpr (kCanSymO) { if (symmetric) kfn = persist_kernel<T, CT, RECON, true>(persist_R, ragged); }
+    if constexpr (kCanSymO) { if (symmetric) kfn = persist_kernel<T, CT, RECON, true>(persist_R, ragged, persist_NQ); }
     int per_cu = 0, dev = 0, cus = 0;
     PISO_HIP_CHECK(hipGetDevice(&dev));
     PISO_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -290,6 +307,9 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     }
 #define PISO_PERSIST_LAUNCH(SYMV)                                                                                            \
     do {                                                                                                                     \
+      if constexpr (sizeof(T) == 8 && sizeof(CT) == 4 && SYMV) {                                                             \
+        if (persist_R == 2 && persist_NQ == 1) { cg_persist1<T, CT, 2, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0); break; } \
+      }                                                                                                                      \
       if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);        \
       else if (persist_R == 4) cg_persist1<T, CT, 4, 2, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);   \
       else if constexpr (kHas16<T, CT, RECON, SYMV>) cg_persist1<T, CT, 16, 1, RECON, SYMV><<<persist_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);  \

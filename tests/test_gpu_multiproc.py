@@ -94,7 +94,7 @@ def test_slab_cg_config5_slab_shape_four_row_regions_over_two_processes():
             assert r[label]["fixed_run_diffs"][4] <= 1e-7, (label, r[label])
             ita, itb = r[label]["converged_its"]
             assert (ita == itb == 20000) or (ita < 20000 and itb < 20000 and abs(ita - itb) <= max(10, 0.1 * ita)), (label, ita, itb)
-        assert r["persistent"]["fixed_run_diffs"][4] <= 5 * max(r["two_kernel"]["fixed_run_diffs"][4], 1e-12), r
+        assert r["persistent"]["fixed_run_diffs"][4] <= 5 * max(r["two_kernel"]["fixed_run_diffs"][4], 1e-9), r      # (a rank whose rows happen to agree to 1e-12 on one path compares noise)
         assert r["stats"]["persistent_iterations"] > 150 and r["stats"]["persistent_fallbacks"] == 0, r["stats"]
         assert r["stats"]["solves_verified"] >= 5 and r["stats"]["verification_failures"] == 0, r["stats"]
 
