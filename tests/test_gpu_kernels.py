@@ -156,11 +156,13 @@ def _persist_iterations():
 
 
 @pytest.mark.parametrize("name", CASES)
-@pytest.mark.parametrize("shape,reset,segment,rows", [((16, 128), 1000, 7, 2), ((64, 256), 200, 16, 4), ((36, 384), 1000, 1000, 2),
-                                                      ((32, 128), 1000, 30, 4), ((16, 256), 25, 1000, 2),
-                                                      ((32, 128), 1000, 9, 16), ((64, 256), 300, 1000, 16),
-                                                      ((256, 512), 1000, 1000, 2)])      # 32 full workgroups on ONE XCD (config 3's grid)
-def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, piso_option):
+@pytest.mark.parametrize("shape,reset,segment,rows,nq", [((16, 128), 1000, 7, 2, -1), ((64, 256), 200, 16, 4, -1), ((36, 384), 1000, 1000, 2, -1),
+                                                         ((32, 128), 1000, 30, 4, -1), ((16, 256), 25, 1000, 2, -1),
+                                                         ((32, 128), 1000, 9, 16, -1), ((64, 256), 300, 1000, 16, -1),
+                                                         ((256, 512), 1000, 1000, 2, -1),    # 32 full workgroups on ONE XCD (config 3's grid)
+                                                         # ONE region of 2 rows per wave (the instance of grids that run chip-wide: 1024 x 256, 512^2)
+                                                         ((16, 128), 1000, 7, 2, 1), ((36, 384), 200, 16, 2, 1), ((256, 512), 1000, 1000, 2, 1)])
+def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, nq, piso_option):
     """The persistent segment kernel (cg_persist1.h: r / p in registers, x in LDS, ONE grid-wide exchange per iteration instead of launches)
     is the path the 2048^2 benchmark runs; force it on small grids and hold it to the same bar as the two-kernel path:
     round-off level agreement with the oracle along the trajectory, across segment boundaries and residual resets, and the
@@ -172,6 +174,7 @@ def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, 
     piso_option("cg_persist", 1)
     piso_option("cg_segment", segment)
     piso_option("cg_persist_r", rows)     # region height (2 / 4 / 16 rows): three kernel instantiations
+    piso_option("cg_persist_nq", nq)
     N.lib.piso_cg_profile_enable(1, 8)
     try:
         for nit in (2, 3, 9, 23, 47):
