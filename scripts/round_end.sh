@@ -1,0 +1,16 @@
+#!/bin/bash
+# What the driver runs at round end, plus the profiling recipe, in ONE gpurun call: the whole GPU suite (per-test timeouts), then
+# profile_bench.sh <tag> (kernel stats, PMC passes, traffic.json, the bench line), prof_small.sh 256 and prof_config4.sh.
+#   gpurun --timeout 3000 -- 'bash scripts/round_end.sh r05_x'      then copy gpurun_out/prof/<tag>_* into profiles/
+R=$GRAFT_REPO_ROOT
+TAG=${1:-rXX}
+mkdir -p $R/gpurun_out
+cd $R
+timeout 1500 python -m pytest tests/ -q -m gpu --timeout 500 --maxfail 8 -p no:cacheprovider > gpurun_out/full_suite.log 2>&1
+echo "rc $?" >> gpurun_out/full_suite.log
+grep -a "passed\|failed\|^FAILED\|^ERROR" gpurun_out/full_suite.log | tail -12 | cut -c1-300
+timeout 1500 bash scripts/profile_bench.sh $TAG
+echo "profile rc $?"
+cd $R
+timeout 300 bash scripts/prof_small.sh 256 > gpurun_out/prof_small.log 2>&1; echo "prof_small rc $?"
+timeout 400 bash scripts/prof_config4.sh > gpurun_out/prof_config4.log 2>&1; echo "prof_config4 rc $?"
