@@ -748,7 +748,10 @@ constexpr int kEdgeRows = 2;
 // rows - five coefficients, five values of `in` at clamped addresses, the dot product's partner - are issued before anything is
 // consumed, the store of a row cannot stand between the loads of the next (round 5: with one row per pass, a division per row and the
 // stores in between the kernel moved 2.85 TB/s at 2048^2).  The row's sum keeps stencil_row's order: S, W, C, E, N, exceptions.
-constexpr int kSpmvRows = 4;
+#ifndef PISO_SPMV_ROWS
+#define PISO_SPMV_ROWS 4
+#endif
+constexpr int kSpmvRows = PISO_SPMV_ROWS;
 // emit(k, o, d): row at place k of the vectors, o = (B in)(row), d = extra[k] (loaded with the row's other operands)
 template <typename T, typename Emit>
 __device__ __forceinline__ void stencil_rows(const BiArgs<T>& a, int c, const T* __restrict__ in, const T* __restrict__ extra, int part,
@@ -759,7 +762,18 @@ __device__ __forceinline__ void stencil_rows(const BiArgs<T>& a, int c, const T*
   const int begin = part == 1 ? a.rb[c] + eb : (part == 2 ? 0 : a.rb[c]);
   const int end = part == 1 ? a.re[c] - eb : (part == 2 ? 2 * eb : a.re[c]);
   const float inv_w = 1.0f / (float)W;
-  for (int base = begin + blockIdx.x * (kSpmvRows * kBlock); base < end; base += gridDim.x * (kSpmvRows * kBlock)) {
+  // Which chunk of kSpmvRows * 256 rows a block takes: workgroups are dealt to the eight XCDs round-robin, and a row's neighbours
+  // k - W / k + W sit two chunks away at 2048^2 - with chunks dealt round-robin too, every XCD's L2 fetched `in` three times (its own
+  // chunks and both neighbours').  A grid of a multiple of 8 workgroups gives every XCD one contiguous eighth of the rows instead.
+  constexpr int kChunk = kSpmvRows * kBlock;
+  const int nchunk = (end - begin + kChunk - 1) / kChunk;
+  const bool by_xcd = (gridDim.x & 7) == 0 && part != 2;
+  const int per = by_xcd ? (nchunk + 7) / 8 : nchunk;                       // chunks of one XCD's eighth
+  const int first = by_xcd ? (int)(blockIdx.x & 7) * per : 0;
+  const int step = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  for (int cidx = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; cidx < per; cidx += step) {
+    const int base = begin + (first + cidx) * kChunk;
+    if (base >= end) break;
     int k[kSpmvRows], fo[kSpmvRows];
     bool on[kSpmvRows], hs[kSpmvRows], hw[kSpmvRows], he[kSpmvRows], hn[kSpmvRows];
     T cs[kSpmvRows], cw[kSpmvRows], cc[kSpmvRows], ce[kSpmvRows], cn[kSpmvRows];
@@ -1135,6 +1149,7 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
   const int own0 = a.re[0] - a.rb[0], own1 = a.re[1] - a.rb[1];
   const int nmax = own0 > own1 ? own0 : own1;
   int gv = (nmax + kBlock * 4 - 1) / (kBlock * 4);
+  gv = (gv + 7) & ~7;                                       // (a multiple of the XCD count: stencil_rows deals the rows by XCD)
   if (gv > kBiParts) gv = kBiParts;
   if (gv < 1) gv = 1;
   // slab mode: a product is two launches (interior, edge rows) that write the partial slots [0, gv) and [gv, gv + ge); every other
