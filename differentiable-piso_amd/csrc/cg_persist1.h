@@ -480,7 +480,10 @@ __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[
       // (branch-free passes: all eight loads every time, records beyond the XCD's count masked by one compare against a scalar -
       // per-record arrival flags are eight lane masks = sixteen SGPRs the row loops then spill)
       u64 w[8];
-      const int lim = nmine * kX1RecWords;                    // words of the XCD's block that belong to records in play
+      // (opaque: left visible, the eight bounds lim - 64 i are constants of the launch that live in SGPRs across the row loops - spilled,
+      // and a spilled SGPR comes back through v_readlane; recomputed here they are eight scalar subtractions per exchange)
+      int lim = nmine * kX1RecWords;                          // words of the XCD's block that belong to records in play
+      asm volatile("" : "+s"(lim));
       unsigned spins = spin0;
       while (true) {
 #pragma unroll
