@@ -37,10 +37,11 @@ constexpr bool kPersistDiag = false;
 #endif
 constexpr int kPersistMaxGrid = 256;   // workgroups (one per CU); the exchange keeps kPersistMaxGrid / 64 records per lane in registers
 // workspace of the exchanges, in 4-byte words: level-1 records [2 parities][kPersistMaxGrid] x 128 B, then the eight XCD records of
-// the tree's second level [2][8] x 128 B (cg_persist1.h: grid_exchange8_hier), then 64 control words (XCD arrival counters,
-// error flag, verification scratch).  Records and arrival counters are zeroed before every launch (kPersistZeroBytes).
+// the tree's second level [2][8] x 128 B (cg_persist1.h: grid_exchange8_hier), then the control words (XCD arrival counters at 0,
+// the workgroups' XCDs at kPersistXcdTable, the error flag 16 words from the end).  Records and arrival counters are zeroed before every launch (kPersistZeroBytes).
 constexpr size_t kPersistRecWords = (size_t)2 * kPersistMaxGrid * 32 + (size_t)2 * 8 * 32;
-constexpr size_t kPersistWsWordsAll = kPersistRecWords + 64;
+constexpr int kPersistXcdTable = 16;    // word offset (from PersistCtl::xcd) of the table "XCD of workgroup b", kPersistMaxGrid entries (hier_enter)
+constexpr size_t kPersistWsWordsAll = kPersistRecWords + 64 + kPersistMaxGrid;
 constexpr size_t kPersistZeroBytes = kPersistRecWords * 4 + 16 * sizeof(int);
 constexpr int kPersistMaxDepth = 4;     // coefficient rows in flight per wave: deeper spills registers, and spills cost more than latency (measured 3..16)
 

@@ -388,17 +388,22 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
 __device__ __forceinline__ unsigned long long* hier_level2(const PersistCtl& c) {
   return c.rec + (size_t)2 * kPersistMaxGrid * kX1RecWords;                 // right behind the level-1 records (kPersistRecWords)
 }
-// entry of a chip-wide launch: which XCD am I on, which arrival there, how many workgroups does every XCD hold?  One returning
+// entry of a chip-wide launch: which XCD am I on, how many workgroups does every XCD hold, and which of them am I?  One returning
 // atomic per workgroup, then everybody waits for everybody ONCE per launch (c.xcd[0..7] arrivals per XCD, [9] arrivals in all;
-// zeroed by the host before the launch).
+// zeroed by the host before the launch).  My place among my XCD's workgroups is my place by WORKGROUP INDEX, not by arrival: the
+// leader adds the records in that order, so two launches that the hardware deals to the XCDs the same way add in the same order
+// and a solve is reproducible bit for bit from run to run (by arrival order the forward solves of the 2048^2 benchmark took
+// 325 - 360 iterations on the same input, now and then 1 005).  Every workgroup leaves its XCD in a table before it counts itself in.
 __device__ __forceinline__ unsigned hier_enter(const PersistCtl& c, int* lds2) {      // lds2: [0] hx, [1] launch cannot run, [2] sticky flag of the exchanges
+  int* const table = c.xcd + kPersistXcdTable;
   if (threadIdx.x == 0) {
     const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7);       // HW_REG_XCC_ID[3:0]
-    const int rank = __hip_atomic_fetch_add(c.xcd + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(c.xcd + 9, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(table + blockIdx.x, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int arrival = __hip_atomic_fetch_add(c.xcd + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(c.xcd + 9, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);     // (release: my table entry is out before I count)
     unsigned spins = 0;
-    bool ok = rank < 32;
-    while (ok && __hip_atomic_load(c.xcd + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
+    bool ok = arrival < 32;
+    while (ok && __hip_atomic_load(c.xcd + 9, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
       if (++spins > (1u << 22)) { ok = false; break; }
       __builtin_amdgcn_s_sleep(2);
     }
@@ -410,9 +415,19 @@ __device__ __forceinline__ unsigned hier_enter(const PersistCtl& c, int* lds2) {
       if (x == xcc) mine = (unsigned)n;
     }
     if (!ok) *c.err = 1;
-    lds2[0] = (int)((unsigned)xcc | ((unsigned)(rank & 63) << 3) | ((mine & 63u) << 9) | (present << 15));
+    lds2[0] = (int)((unsigned)xcc | ((mine & 63u) << 9) | (present << 15));
     lds2[1] = ok ? 0 : 1;
     lds2[2] = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && !lds2[1]) {                        // wave 0: the workgroups of my XCD with a smaller index
+    const int xcc = lds2[0] & 7;
+    int before = 0;
+    for (int b = (int)threadIdx.x; b < (int)gridDim.x; b += 64)
+      before += (b < (int)blockIdx.x && __hip_atomic_load(table + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    if (threadIdx.x == 0) lds2[0] |= (before & 63) << 3;
   }
   __syncthreads();
   return (unsigned)__builtin_amdgcn_readfirstlane(lds2[0]);

@@ -61,6 +61,30 @@ def test_persistent_cg_equals_two_kernel_path_2048(walls, piso_option):
     assert Nn.lib.piso_cg_persist_fallbacks() == f0, "a grid exchange timed out and the solve fell back to the two-kernel path"
 
 
+@pytest.mark.parametrize("shape", [(2048, 2048), (1024, 256), (512, 512)])
+def test_persistent_cg_is_reproducible_bit_for_bit_from_run_to_run(shape, piso_option):
+    """The exchange adds the workgroups' records of an XCD in the order of their workgroup INDEX (cg_persist1.h: hier_enter), not in
+    the order they happened to arrive at the launch: the same solve on the same input gives the same bits, and - the stopping test of
+    the shifted system being as sensitive as it is - the same iteration count.  (By arrival order the 2048^2 benchmark's forward solves
+    took 325 - 360 iterations on one input.)  Covers the 16-row instance and the one-region-per-wave instance of the mid-size grids."""
+    from tests.cases import pressure_system
+    from diffpiso.solvers import cg_solve_native
+    nx, ny = shape
+    L, b = pressure_system(nx, ny)
+    piso_option("cg_persist", 1)
+    import diffpiso._native as Nn
+    f0 = Nn.lib.piso_cg_persist_fallbacks()
+    x0, it0 = cg_solve_native(nx, ny, True, True, L, b, 1e-30, 400, True, 1000)
+    for rep in range(3):
+        x1, it1 = cg_solve_native(nx, ny, True, True, L, b, 1e-30, 400, True, 1000)
+        assert it1 == it0 == 400
+        assert torch.equal(x0, x1), "rep %d: %.3e" % (rep, float((x0 - x1).abs().max()))
+    xa, ita = cg_solve_native(nx, ny, True, True, L, b, 1e-3, 3000, True, 1000)      # (with the stopping test and a restart in play)
+    xb, itb = cg_solve_native(nx, ny, True, True, L, b, 1e-3, 3000, True, 1000)
+    assert ita == itb and torch.equal(xa, xb), (ita, itb)
+    assert Nn.lib.piso_cg_persist_fallbacks() == f0
+
+
 def test_persistent_cg_first_iterations_back_to_back_launches_2048(piso_option):
     """Short solves queued back to back (no host synchronisation in between, device copies in flight when the persistent kernel
     starts) against the two-kernel iteration after 3, 4 and 6 iterations: agreement to round-off (measured 2e-16 .. 5e-16).
