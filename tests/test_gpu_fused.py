@@ -199,3 +199,22 @@ def test_forward_step_launches_outside_the_solver_iterations():
         print("%5.1f per step  %s" % (n / 3.0, k[:110]))
     print("launches per forward step outside the solver iterations: %.1f (library glue + torch)" % per_step)
     assert per_step <= 30, per_step                         # (measured 23.3: 11 library launches, ~12 torch copies / adds / fills)
+
+
+@pytest.mark.parametrize("n", [512, 1024])
+def test_unrolled_step_forward_and_reverse_is_reproducible_bit_for_bit(n):
+    """Two runs of the benchmark's workload (two unrolled steps forward, the reverse sweep of L = 1/2 |u_2|^2) on the same input give
+    the same loss and the same dL/du_0 to the last bit: every reduction on the path adds in a fixed order - the assembly has none, the
+    BiCGStab's partial sums live in fixed slots, the CG's exchange adds an XCD's records by workgroup index (cg_persist1.h: hier_enter),
+    the one-XCD mode by region slot, the glue kernels have no reductions."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    P = bench.build_problem(n, torch.device("cuda"), 1e-6, 2000, 1000)
+    g0, loss0, _ = bench.run_unrolled(P, 2, backward=True)
+    its0 = (int(P["ps"].last_iterations), int(P["ps"].last_adjoint_iterations))
+    for rep in range(2):
+        g1, loss1, _ = bench.run_unrolled(P, 2, backward=True)
+        assert (int(P["ps"].last_iterations), int(P["ps"].last_adjoint_iterations)) == its0
+        assert loss1 == loss0
+        assert torch.equal(g0, g1), float((g0 - g1).abs().max())
