@@ -9,6 +9,7 @@ cd $R
 timeout 1500 python -m pytest tests/ -q -m gpu --timeout 500 --maxfail 8 -p no:cacheprovider > gpurun_out/full_suite.log 2>&1
 echo "rc $?" >> gpurun_out/full_suite.log
 grep -a "passed\|failed\|^FAILED\|^ERROR" gpurun_out/full_suite.log | tail -12 | cut -c1-300
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 1500 bash scripts/profile_bench.sh $TAG
 echo "profile rc $?"
 cd $R
