@@ -177,6 +177,9 @@ __device__ __forceinline__ F karg(unsigned off) {
 #ifndef PISO_PERSIST1_POLL_DELAY2_NOAHEAD
 #define PISO_PERSIST1_POLL_DELAY2_NOAHEAD 8     // ... where no rows are computed ahead in front of it (small regions on mid-size grids: 24 -> 8: 4.27 -> 4.15 us at 512^2 / 1024 x 256, 0: 4.22)
 #endif
+#ifndef PISO_PERSIST1_POLL_DELAY2_XG
+#define PISO_PERSIST1_POLL_DELAY2_XG 8          // ... of the slab instance's node level: ONE wave per rank polls there, an early pass queues in front of nobody (2048^2 in a ring of one: 40 -> 8 units 10.05 -> 9.67 us per iteration; 0 / 16 / 24: 9.67 / 9.72 / 9.78; 48 / 80: 10.2 / 11.4)
+#endif
 #ifndef PISO_PERSIST1_LOCAL_DELAY
 #define PISO_PERSIST1_LOCAL_DELAY 8             // XCD-local exchange with one working wave per SIMD: s_sleep units in front of the first polling pass
 #endif
@@ -1406,7 +1409,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         }
       }
     };
-    if constexpr (kHier) healthy = grid_exchange8_hier<T, (kAhead > 0 ? PISO_PERSIST1_POLL_DELAY2 : PISO_PERSIST1_POLL_DELAY2_NOAHEAD), SLAB>(c, sD, epoch, smem, hx, hier_s + 2, z_ahead, (kPersistDiag && c.timing) ? tsub : nullptr, sl_off, smem + 2 * kX1Sm);
+    if constexpr (kHier) healthy = grid_exchange8_hier<T, (SLAB ? PISO_PERSIST1_POLL_DELAY2_XG : (kAhead > 0 ? PISO_PERSIST1_POLL_DELAY2 : PISO_PERSIST1_POLL_DELAY2_NOAHEAD)), SLAB>(c, sD, epoch, smem, hx, hier_s + 2, z_ahead, (kPersistDiag && c.timing) ? tsub : nullptr, sl_off, smem + 2 * kX1Sm);
     else if constexpr (kLocalAll) healthy = grid_exchange8_local<T>(c, sD, epoch, smem, slot, nslots, hier_s + 2, (kPersistDiag && c.timing) ? tsub : nullptr);
     else healthy = grid_exchange8<T, LOCAL>(c, sD, epoch, smem, slot, nslots, NoPrefetch(), (kPersistDiag && c.timing) ? tsub : nullptr);
     tick(1);
