@@ -177,6 +177,9 @@ __device__ __forceinline__ F karg(unsigned off) {
 #ifndef PISO_PERSIST1_POLL_DELAY2_NOAHEAD
 #define PISO_PERSIST1_POLL_DELAY2_NOAHEAD 8     // ... where no rows are computed ahead in front of it (small regions on mid-size grids: 24 -> 8: 4.27 -> 4.15 us at 512^2 / 1024 x 256, 0: 4.22)
 #endif
+#ifndef PISO_PERSIST1_RZ_KARG
+#define PISO_PERSIST1_RZ_KARG 1                 // the z' buffer of an iteration's parity: its address from the kernarg segment (an s_load per iteration) instead of two descriptors' bases in SGPRs across the loop
+#endif
 #ifndef PISO_PERSIST1_POLL_DELAY2_XG
 #define PISO_PERSIST1_POLL_DELAY2_XG 8          // ... of the slab instance's node level: ONE wave per rank polls there, an early pass queues in front of nobody (2048^2 in a ring of one: 40 -> 8 units 10.05 -> 9.67 us per iteration; 0 / 16 / 24: 9.67 / 9.72 / 9.78; 48 / 80: 10.2 / 11.4)
 #endif
@@ -1334,7 +1337,16 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   for (; k < k_end && healthy && !st.done; ++k) {
     // consecutive iterations alternate buffers: a neighbour's loads of z'_k are consumed before it publishes its record k + 1,
     // which everybody needs before writing the same buffer again in iteration k + 2
-    const rsrc_t Rz = (k & 1) ? Rz1 : Rz0;
+    rsrc_t Rz;
+    // (16-row regions and the slab instances are short of scalar registers: the buffer's address comes from the kernarg segment, not
+    // from four SGPRs held across the loop - 83 -> 58 spilled SGPRs in the 16-row slab instance, 28 -> 23 in the plain one.  Small
+    // regions keep the descriptors: their iteration is a latency chain and the scalar load sits on it - 256^2 2.70 -> 2.79 us)
+    if constexpr (SLAB || (PISO_PERSIST1_RZ_KARG != 0 && NT == 16)) {
+      typedef CgArgs<T> A;
+      Rz = make_rsrc(karg<T*>((unsigned)offsetof(KArgs, a) + (unsigned)offsetof(A, zp) + 8u * (unsigned)(k & 1)), nbytesT);
+    } else {
+      Rz = (k & 1) ? Rz1 : Rz0;
+    }
     // ---- D(k): p = r + beta p on my cells and on the ring; z' = L p; sums; the perimeter of z' goes out
     T sD[kX1Values] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (has[0]) {
