@@ -349,8 +349,9 @@ _KERNEL_VARIANT_CASES = [("periodic", (40, 36), False, 1e-5, 200), ("cavity", (4
                          ("periodic", (16, 2304), False, 1e-30, 3)]                                                # E = 10 -> the 16-element instance (padded LDS slots)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("name,shape,transpose,tol,max_it", _KERNEL_VARIANT_CASES)
-def test_bicgstab_kernel_variants_are_bitwise_neutral(name, shape, transpose, tol, max_it, piso_option):
+def test_bicgstab_kernel_variants_are_bitwise_neutral(name, shape, transpose, tol, max_it, dtype, piso_option):
     """Round 5's kernel variants change HOW memory is walked, not what is computed: the sweeps / the factorisation that stage rows through
     LDS (bi_sweep_lds, bi_factor_lds; option bicg_sweep_lds) and the direction update inside the forward sweep (BiArgs::fuse_p; option
     bicg_fuse_p) must give bitwise the solution and the iteration counts of the kernels they replace."""
@@ -363,6 +364,7 @@ def test_bicgstab_kernel_variants_are_bitwise_neutral(name, shape, transpose, to
     rhs = np.random.default_rng(5).standard_normal(s.n_u + s.n_v).astype(f32)
     x0 = R.flatten_staggered(c["vel"], True)
     out = []
+    val, rhs, x0 = val.astype(dtype), rhs.astype(dtype), x0.astype(dtype)      # (float64: the cast_to_double solver's instances of the same kernels)
     for lds, fuse in ((0, 0), (1, 0), (0, 1), (-1, -1)):
         piso_option("bicg_sweep_lds", lds)
         piso_option("bicg_fuse_p", fuse)
