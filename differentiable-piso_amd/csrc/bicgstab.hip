@@ -184,9 +184,8 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
     T ev[kExcSlots];
     // classify the entries of A's own row (also validates the pattern in transpose mode)
     const int rl = a.rpx(c, row);
-    for (int q = rp[rl]; q < rp[rl + 1]; ++q) {
-      const int cq = staged ? lcol[q - q0] : col[q];
-      const T vq = sgn * (staged ? lval[q - q0] : val[q]);
+    const int qb = rp[rl], qe = rp[rl + 1];
+    auto classify = [&](int cq, T vq) __attribute__((always_inline)) {
       nan_seen |= is_nan(vq);
       int kind;   // 0..4 near slots, 5 exception
       if (cq == row) kind = 2;
@@ -203,10 +202,29 @@ __global__ __launch_bounds__(kBlock) void bi_convert(BiArgs<T> a, const T* __res
       if (!transpose) {
         if (kind == 0) s = vq; else if (kind == 1) w = vq; else if (kind == 2) cc = vq;
         else if (kind == 3) e = vq; else if (kind == 4) nn = vq;
-        else if (ne < kExcSlots) { ec[ne] = cq; ev[ne] = vq; ++ne; }
+        else if (ne < kExcSlots) {
+#pragma unroll
+          for (int x = 0; x < kExcSlots; ++x) if (ne == x) { ec[x] = cq; ev[x] = vq; }
+          ++ne;
+        }
         else bad = true;
       } else if (kind == 2) cc = vq;
+    };
+    // (a row of these matrices has at most five entries: they are fetched together and classified without a loop; the loop behind
+    // them only runs on a foreign pattern - which the flags above reject anyway)
+    {
+      int cq5[5];
+      T vq5[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int q = qb + u < qe ? qb + u : qb;               // (a row has at least its diagonal)
+        cq5[u] = staged ? lcol[q - q0] : col[q];
+        vq5[u] = sgn * (staged ? lval[q - q0] : val[q]);
+      }
+#pragma unroll
+      for (int u = 0; u < 5; ++u) if (qb + u < qe) classify(cq5[u], vq5[u]);
     }
+    for (int q = qb + 5; q < qe; ++q) classify(staged ? lcol[q - q0] : col[q], sgn * (staged ? lval[q - q0] : val[q]));
     if (transpose) {
       T vq;
       if (i >= 1 && csr_find(rp, col, val, row - 1, row, &vq, M, c)) w = sgn * vq;            // A(k-1, k)
