@@ -28,6 +28,9 @@ struct HostPoll {
 };
 static std::atomic<unsigned> g_persist_launches{0};   // persistent launches so far: the high half of their exchange tags
 static int g_persist_fallbacks = 0;            // solves that were restarted on the two-kernel path after an exchange timed out
+// option cg_xcd_map 1 (tests): the XCD every workgroup of the solve's LAST chip-wide persistent launch ran on (cg_persist1.h: hier_enter)
+static thread_local int tl_xcd_map[kPersistMaxGrid];
+static thread_local int tl_xcd_map_n = 0;
 static long long g_tiny_solves = 0;            // solves that ran inside one workgroup (cg_tiny.h)
 static bool g_xcd_local_failed = false;        // an XCD-local launch gave up once (the device does not behave as assumed): not tried again
 static long long g_verify_runs = 0;            // solves whose final state was checked against the true residual (cg_verify_gap)
@@ -432,6 +435,13 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
     if (r > 0) finished = true;
   }
   PISO_HIP_CHECK(hipStreamSynchronize(stream));
+  if (opt(OPT_CG_XCD_MAP) == 1) {
+    tl_xcd_map_n = 0;
+    if (segments_run > 0 && persist_R && !xcd_local && persist_grid <= kPersistMaxGrid) {
+      PISO_HIP_CHECK(hipMemcpy(tl_xcd_map, pc.xcd + kPersistXcdTable, (size_t)persist_grid * sizeof(int), hipMemcpyDeviceToHost));
+      tl_xcd_map_n = persist_grid;
+    }
+  }
   if (segments_run > 0 && allow_persist) {                 // (segments whose host look was deferred: did one of them give up?)
     int herr = 0;
     PISO_HIP_CHECK(hipMemcpy(&herr, pc.err, sizeof(int), hipMemcpyDeviceToHost));
@@ -702,6 +712,11 @@ void piso_cg_profile_enable(int enable, int stride) {
 }
 
 int piso_cg_persist_fallbacks(void) { return g_persist_fallbacks; }
+int piso_cg_last_xcd_map(int* out, int capacity) {
+  const int n = tl_xcd_map_n < capacity ? tl_xcd_map_n : capacity;
+  for (int i = 0; i < n; ++i) out[i] = tl_xcd_map[i];
+  return tl_xcd_map_n;
+}
 long long piso_cg_tiny_solves(void) { return g_tiny_solves; }
 void piso_cg_verify_stats(long long* runs_out, int* failures_out) {
   if (runs_out) *runs_out = g_verify_runs;

@@ -21,6 +21,7 @@ enum Opt {
   OPT_CG_PAD,              // 0: never embed a small wall-bounded grid in a padded one for the persistent kernel (default: on)
   OPT_CG_XCD_LOCAL,        // 0: never run a small grid's persistent solve on the workgroups of ONE XCD (default: on)
   OPT_CG_TINY,             // 0: never solve a tiny grid (<= 4 608 cells) inside one workgroup (cg_tiny.h; default: on)
+  OPT_CG_XCD_MAP,          // 1 (tests): keep the XCD of every workgroup of a solve's last chip-wide persistent launch for piso_cg_last_xcd_map
   OPT_CONV_LDS,            // 0: the closure's forward / input-gradient convolutions read their operands straight from L2 (default: staged through LDS)
   OPT_BICG_FOLD,           // 0: the BiCGStab scalar stages always run as launches of their own (default: folded into their consumers on one GPU)
   OPT_BICG_SWEEP_LDS,      // 0: the triangular sweeps address memory in scan order (bi_sweep) instead of staging rows through LDS (bi_sweep_lds)

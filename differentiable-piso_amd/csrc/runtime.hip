@@ -11,7 +11,7 @@ void set_error(const char* what, hipError_t err) {
 void set_error_msg(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
 
 static const char* const kOptNames[OPT_COUNT] = {"cg_persist", "cg_persist_r", "cg_persist_half", "cg_persist_nq", "cg_segment", "cg_persist_timing",
-                                                 "cg_rpw", "cg_maxblocks", "cg_nt", "cg_no_compact", "cg_no_recon", "cg_no_sym", "cg_verify", "cg_pad", "cg_xcd_local", "cg_tiny", "conv_lds", "bicg_fold", "bicg_sweep_lds", "bicg_fuse_p", "slab_force", "slab_hop_ticks"};
+                                                 "cg_rpw", "cg_maxblocks", "cg_nt", "cg_no_compact", "cg_no_recon", "cg_no_sym", "cg_verify", "cg_pad", "cg_xcd_local", "cg_tiny", "cg_xcd_map", "conv_lds", "bicg_fold", "bicg_sweep_lds", "bicg_fuse_p", "slab_force", "slab_hop_ticks"};
 struct Options {
   int v[OPT_COUNT];
   Options() {                                      // the environment is read here, once, and never again

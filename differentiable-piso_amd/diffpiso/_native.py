@@ -31,6 +31,8 @@ lib.piso_set_option.restype = _i
 lib.piso_get_option.argtypes = [C.c_char_p, _ip]
 lib.piso_get_option.restype = _i
 lib.piso_cg_persist_fallbacks.restype = _i
+lib.piso_cg_last_xcd_map.argtypes = [_ip, _i]
+lib.piso_cg_last_xcd_map.restype = _i
 lib.piso_cg_tiny_solves.restype = C.c_longlong
 lib.piso_cg_verify_stats.argtypes = [C.POINTER(C.c_longlong), _ip]
 lib.piso_cg_verify_stats.restype = None
@@ -203,3 +205,10 @@ def workspace(nbytes, device, tag):
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
+
+
+def cg_last_xcd_map():
+    """The XCD of every workgroup of this thread's last chip-wide persistent CG launch (option cg_xcd_map = 1), as a tuple; () if none."""
+    buf = (C.c_int * 256)()
+    n = lib.piso_cg_last_xcd_map(buf, 256)
+    return tuple(buf[i] for i in range(min(n, 256)))

@@ -261,6 +261,11 @@ void piso_cg_profile_read(double* ms_sum, long long* count);
 /* Solves (since load) that were restarted on the two-kernel path because a grid-wide exchange of the persistent kernel timed
  * out (workgroups not co-resident: CU mask, another process on the GPU).  0 on a dedicated GPU. */
 int piso_cg_persist_fallbacks(void);
+/* With option "cg_xcd_map" = 1: the XCD (0-7) that every workgroup of the calling thread's last solve's LAST chip-wide persistent launch
+ * ran on, out[0 .. min(return value, capacity)); returns the number of workgroups (0: the solve ran no such launch).  The exchange adds
+ * an XCD's records in workgroup order, so two solves of the same input are bit-for-bit equal whenever the hardware dealt the workgroups
+ * to the XCDs the same way - which it does on an otherwise idle GPU; the reproducibility tests check exactly that precondition. */
+int piso_cg_last_xcd_map(int* out, int capacity);
 /* Solves of grids of at most 4 608 cells run inside ONE workgroup, one launch for the whole solve (csrc/cg_tiny.h: the lid-driven
  * cavity of BASELINE.json's config 1); same iteration and control flow as the chip-wide paths.  Option "cg_tiny": 0 = never. */
 long long piso_cg_tiny_solves(void);
