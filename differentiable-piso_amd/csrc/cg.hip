@@ -239,6 +239,16 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
         persist_grid = (shape.nreg + kPersistWaves - 1) / kPersistWaves;
       }
     }
+    {
+      // ... and inside ONE XCD as well, where that needs no more than its 32 workgroups: 256^2 (config 2) 2.74 -> 2.59 us per iteration
+      // (eight working waves x one region instead of four x two; 512 x 256 would need 64 workgroups and keeps two regions per wave)
+      constexpr bool kHasNq1L = sizeof(T) == 8 && sizeof(CT) == 4 && RECON;
+      if (kHasNq1L && opt(OPT_CG_PERSIST_NQ) != 0 && xcd_local && persist_R == 2 && persist_NQ == 2 && !a.nx_true &&
+          (shape.nreg + kPersistWaves - 1) / kPersistWaves <= kXcdCus) {
+        persist_NQ = 1; pc.waves = kPersistWaves;
+        persist_grid = (shape.nreg + kPersistWaves - 1) / kPersistWaves;
+      }
+    }
     if (persist_R && n < 16384 && force != 1 && !a.nx_true) persist_R = 0;    // tiny grids: two-kernel path (a padded grid is here BECAUSE it is small)
   }
   const bool ragged = a.nx_true != 0;
@@ -294,7 +304,8 @@ static int cg_run(CgArgs<T> a, unsigned* persist_ws, bool symmetric, float accur
           if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, true, false, true, true><<<launch_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
           else cg_persist1<T, CT, 4, 2, RECON, true, false, true, true><<<launch_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
         } else {
-          if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, true, false, false, true><<<launch_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
+          if (persist_R == 2 && persist_NQ == 1) cg_persist1<T, CT, 2, 1, RECON, true, false, false, true><<<launch_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
+          else if (persist_R == 2) cg_persist1<T, CT, 2, 2, RECON, true, false, false, true><<<launch_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
           else cg_persist1<T, CT, 4, 2, RECON, true, false, false, true><<<launch_grid, kPersistThreads, 0, stream>>>(a, pc, kb, ke, sv, pending ? 1 : 0);
         }
         PISO_LAUNCH_CHECK();

@@ -8,7 +8,7 @@ enum Opt {
   OPT_CG_PERSIST = 0,      // 0 forbid / 1 force the persistent CG kernel (default: by grid size)
   OPT_CG_PERSIST_R,        // rows per region of the persistent kernel: 2 | 4 | 16
   OPT_CG_PERSIST_HALF,     // 0: never run small regions with ONE working wave per SIMD and twice the workgroups (default: where the chip holds them)
-  OPT_CG_PERSIST_NQ,       // regions of 2 rows, ONE per wave instead of two: 0 never, 1 wherever the chip holds them (default: grids that leave one XCD anyway)
+  OPT_CG_PERSIST_NQ,       // regions of 2 rows, ONE per wave instead of two: 0 never, 1 wherever the chip holds them (default: grids that leave one XCD anyway, and one-XCD grids of at most 256 regions)
   OPT_CG_SEGMENT,          // CG iterations per persistent launch
   OPT_CG_PERSIST_TIMING,   // per-phase clocks of the persistent kernel (diagnostic builds only)
   OPT_CG_RPW,              // two-kernel path: rows per wave of K1

@@ -73,7 +73,7 @@ int piso_device_count(void);
  * cg_persist_half (0: small regions never run with one working wave per SIMD and twice the workgroups; 1: wherever that fits the
  * chip, also where it pushes a grid out of one XCD),
  * cg_persist_nq (regions of 2 rows, ONE per wave instead of two: 0 never, 1 wherever the chip holds them; default: grids that need
- * more than one XCD's worth of workgroups),
+ * more than one XCD's worth of workgroups, and grids of at most 256 regions, which stay on one XCD either way),
  * bicg_fold (0: the scalar stages of BiCGStab always run as launches of their own; default: folded into the kernels that consume
  * them on one GPU), bicg_sweep_lds (0: sweeps and factorisation address memory in scan order instead of staging rows through LDS),
  * bicg_fuse_p (0: the direction update of BiCGStab is a launch of its own instead of part of the forward sweep that reads it),

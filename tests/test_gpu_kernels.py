@@ -161,7 +161,9 @@ def _persist_iterations():
                                                          ((32, 128), 1000, 9, 16, -1), ((64, 256), 300, 1000, 16, -1),
                                                          ((256, 512), 1000, 1000, 2, -1),    # 32 full workgroups on ONE XCD (config 3's grid)
                                                          # ONE region of 2 rows per wave (the instance of grids that run chip-wide: 1024 x 256, 512^2)
-                                                         ((16, 128), 1000, 7, 2, 1), ((36, 384), 200, 16, 2, 1), ((256, 512), 1000, 1000, 2, 1)])
+                                                         ((16, 128), 1000, 7, 2, 1), ((36, 384), 200, 16, 2, 1), ((256, 512), 1000, 1000, 2, 1),
+                                                         # two regions per wave on one XCD (what the default no longer picks for grids of <= 256 regions)
+                                                         ((16, 128), 1000, 7, 2, 0), ((256, 256), 1000, 1000, 2, 0), ((256, 256), 300, 40, 2, -1)])
 def test_cg_persistent_segments_match_oracle(name, shape, reset, segment, rows, nq, piso_option):
     """The persistent segment kernel (cg_persist1.h: r / p in registers, x in LDS, ONE grid-wide exchange per iteration instead of launches)
     is the path the 2048^2 benchmark runs; force it on small grids and hold it to the same bar as the two-kernel path:
