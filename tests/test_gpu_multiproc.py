@@ -55,7 +55,9 @@ def run_ranks(world, nx, ny, walls, timeout=600, worker="slab_worker.py", extra=
 
 
 @pytest.mark.parametrize("world,nx,ny,walls", [(2, 1024, 1024, False), (2, 2048, 2048, False), (2, 2048, 2048, True),
-                                               (4, 2048, 2048, False)])
+                                               (4, 2048, 2048, False),
+                                               # eight ranks x 32 workgroups = every CU of the one GPU: all eight waves of a workgroup poll a rank each
+                                               (8, 2048, 2048, False)])
 def test_slab_cg_over_processes(world, nx, ny, walls):
     res = run_ranks(world, nx, ny, walls)
     for r in res:
