@@ -101,6 +101,22 @@ def test_slab_cg_config5_slab_shape_four_row_regions_over_two_processes():
         assert r["stats"]["solves_verified"] >= 5 and r["stats"]["verification_failures"] == 0, r["stats"]
 
 
+def test_slab_cg_four_row_regions_over_eight_processes():
+    """Regions of FOUR rows, two per wave (config 5's instance) with EIGHT ranks: a 1024 x 1024 grid, slabs of 128 rows = 16 workgroups
+    per rank, all eight persistent kernels side by side on the one GPU; every wave of a workgroup polls a rank of its own."""
+    res = run_ranks(8, 1024, 1024, False, extra=["1024", "1024", "0", "1", "4"])
+    for r in res:
+        assert r["ok"], r
+        for label in ("persistent", "two_kernel"):
+            assert max(r[label]["fixed_run_diffs"]) <= 2e-10, (label, r[label])
+            ita, itb = r[label]["converged_its"]
+            assert (ita == itb == 20000) or (ita < 20000 and itb < 20000 and abs(ita - itb) <= max(10, 0.1 * ita)), (label, ita, itb)
+            assert r[label]["converged_diff"] <= 1e-3
+        assert r["stats"]["persistent_iterations"] > 150 and r["stats"]["persistent_fallbacks"] == 0, r["stats"]
+        assert r["stats"]["solves_verified"] >= 5 and r["stats"]["verification_failures"] == 0, r["stats"]
+    assert len({tuple(r["persistent"]["converged_its"]) for r in res}) == 1
+
+
 def test_bench_two_ranks_on_one_gpu():
     """bench.py's N > 1 path end to end (torch.distributed.run, max-over-ranks timing, the slab self-check inside the JSON line)
     with two ranks sharing the box's one GPU (PISO_BENCH_SHARE_GPU=1: gloo instead of RCCL for torch.distributed, the library's
