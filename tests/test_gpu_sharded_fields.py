@@ -149,14 +149,14 @@ def _one_gpu_peak_bytes(case):
 @pytest.mark.parametrize("world", [2, 4, pytest.param(8, marks=pytest.mark.eight_ranks)])
 def test_sharded_benchmark_workload_1024_fields_vs_one_gpu_and_oracle_fixture(world):
     """The benchmark's workload at 1024^2 with converged solves, ONE grid cut into 2 / 4 / 8 slabs: every kernel of the step on the
-    rank's rows, persistent slab CG (8 ranks on the one GPU: two-kernel iteration), slab ILU(0)-BiCGStab.  Fields against the one-GPU
+    rank's rows, persistent slab CG (also with 8 ranks: their 8 x 16 workgroups share the one GPU), slab ILU(0)-BiCGStab.  Fields against the one-GPU
     product (1e-6) and the oracle fixture (1e-5).  LOCAL storage: a rank's peak device memory is 1 / ranks of the one-GPU run's
     (+ 15 %: halo rows, the fixed-size exchange records)."""
     from tests.test_gpu_golden_configs import _check, _load
     case = "fixture:bench1024_tight_step.npz"
     # (the ranks FIRST: eight rank processes want the GPU's eight hardware contexts for themselves - conftest.py - and this process
     # creates its own context only with the one-GPU runs below)
-    res, out = _spawn(world, case + (":persist0" if world == 8 else ""))
+    res, out = _spawn(world, case)
     u, p, du, dp, edges = _gather(out, world, 1024, 1024)
     mem_one = _one_gpu_peak_bytes(case)
     if world == 8:
@@ -183,6 +183,8 @@ def test_sharded_benchmark_workload_1024_fields_vs_one_gpu_and_oracle_fixture(wo
     for r in res:
         assert r["warn"] == 0 and r["stats"]["verification_failures"] == 0 and r["halo_exchanges"] > 0, r
         assert r["bicgstab_iterations"] == its1[2], (r["bicgstab_iterations"], its1[2])
+        # the pressure iterations ran inside the persistent slab kernel (eight ranks: 16 workgroups each, side by side on the one GPU)
+        assert r["stats"]["persistent_iterations"] > 100 and r["stats"]["persistent_fallbacks"] == 0, r["stats"]
     # (b) the oracle fixture: the same bounds the one-GPU run is held to
     stride = int(d["stride"])
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a))[None]
