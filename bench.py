@@ -213,7 +213,9 @@ def bicgstab_fixed_work(P, n, iters=10, reps=3, real=True):
     rows = x0.numel()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     best, its = None, (0, 0)
+    fixed_solves = 0
     for r in range(reps + 1):
+        fixed_solves += 1
         ev[0].record()
         x, its = multi_bicgstab_ilu_native(val, rp, col, rhs, x0, n, n, 0.0, iters, False, 0, warn, negate=True)
         ev[1].record()
@@ -243,6 +245,11 @@ def bicgstab_fixed_work(P, n, iters=10, reps=3, real=True):
                                       "no early-return launches, host look every 2 iterations included" % total_its,
             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_over_algorithmic": (traffic / nbytes) if traffic else None, "traffic_source": pmc_src,
+            # physical: the PMC bytes of the same solve over its time - the fraction of the HBM peak the fabric really carried (`frac` is
+            # the ALGORITHMIC bytes of SURVEY 8(d) over the same time: the two differ by traffic_over_algorithmic)
+            "physical_achieved": (traffic / (best * 1e-3) / 1e9) if traffic else None,
+            "physical_frac": (traffic / (best * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "fixed_work_solves_run": fixed_solves, "real_solves_run": 3 if real else 0, "iterations_per_fixed_solve": total_its,
             "ms_per_solve": best, "us_per_iteration": 1e3 * best / max(total_its, 1), "rows": rows,
             "algorithmic_bytes_per_solve": nbytes, "bytes_per_row_iteration": BICG_BYTES_PER_ROW_ITER,
             "solve_to_1e-6": {"iterations": list(real_its), "ms": real_best, "algorithmic_GBs": real_bytes / (real_best * 1e-3) / 1e9,

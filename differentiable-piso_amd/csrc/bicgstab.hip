@@ -1050,6 +1050,12 @@ static int bi_solve(const T* val, const int* rowptr, const int* col, const T* rh
     set_error_msg("piso_multi_bicgstab_ilu: invalid argument (need nx, ny >= 4 and non-NULL arrays)");
     return PISO_ERR_INVALID_ARG;
   }
+  // `transpose` is a set of flags (bit 0: A^T, bit 1: the matrix is -csr_val); a caller that still means "any non-zero = transpose"
+  // (2, -1, ...) would silently get a different system: everything outside the two bits is refused
+  if ((transpose & ~3) != 0) {
+    set_error_msg("piso_multi_bicgstab_ilu: transpose must be a combination of bit 0 (A^T) and bit 1 (negated matrix)");
+    return PISO_ERR_INVALID_ARG;
+  }
   if (ws_bytes < bi_workspace_bytes<T>(nx, ny, slab_rows)) {
     set_error_msg("piso_multi_bicgstab_ilu: workspace too small");
     return PISO_ERR_INVALID_ARG;

@@ -76,8 +76,17 @@ def flat_faces(x):
     if isinstance(x, SlabStaggered):
         return x.flat
     flat = getattr(x, "_flat_ufirst", None)
-    if flat is not None:                                     # a grid the step itself made (faces_to_grid): its components are views of this vector
-        return flat
+    if flat is not None:
+        # a grid the step itself made (faces_to_grid): its components are views of this vector - unless somebody rebound them since
+        # (a forcing_fn or user code assigning grid.data / a component's .data): the shortcut only holds while they still ARE the views
+        try:
+            v, u = x.data[0].data, x.data[1].data
+            n_u = u.numel()
+            if (u.data_ptr() == flat.data_ptr() and v.data_ptr() == flat.data_ptr() + n_u * flat.element_size()
+                    and n_u + v.numel() == flat.numel() and u.is_contiguous() and v.is_contiguous()):
+                return flat
+        except (AttributeError, IndexError, TypeError):
+            pass
     grid = x if isinstance(x, StaggeredGrid) else StaggeredGrid(x)
     v, u = grid.data[0].data, grid.data[1].data
     return torch.cat([u.reshape(-1), v.reshape(-1)])

@@ -117,15 +117,14 @@ def assemble_from_padded(vel_pad, nx, ny, dx_yx, per_x, per_y, dirichlet_mask_fl
         csr_row = torch.empty(n_u + n_v + 2, dtype=torch.int32, device=dev)
         diag = torch.empty(n_u + n_v, dtype=torch.float32, device=dev)
     else:
-        if sharding.pattern is None:
+        if sharding.pattern_for(per_x, per_y) is None:
             csr_col = torch.zeros(nnz, dtype=torch.int32, device=dev)
             csr_row = torch.zeros(n_u + n_v + 2, dtype=torch.int32, device=dev)
             st = N.lib.piso_assemble_csr_slab(None, None, N.ptr(csr_col), N.ptr(csr_row), None, None, None, None, 0, nx, ny, int(per_x), int(per_y),
                                               C.c_float(cell_area[0]), C.c_float(cell_area[1]), C.c_float(grid_spacing[0]),
                                               C.c_float(grid_spacing[1]), None, C.c_float(0.0), N.stream_ptr(), sharding.slab_ptr, 1)
             N.check(st, "piso_assemble_csr_slab (pattern)")
-            sharding.set_pattern(csr_col, csr_row, nnz_u)
-            sharding.nnz = (nnz_u, nnz_v)
+            sharding.set_pattern(csr_col, csr_row, nnz_u, per_xy=(per_x, per_y), nnz=(nnz_u, nnz_v))
         csr_col, csr_row = sharding.pattern
         csr_val = torch.zeros(nnz, dtype=torch.float32, device=dev)
         diag = torch.zeros(n_u + n_v, dtype=torch.float32, device=dev)

@@ -22,6 +22,7 @@ return instead of StaggeredGrid / CenteredGrid when `simulation_physics.sharding
 array (host or device) into the rank's stored rows, `owned_*` pick the rows a rank owns out of a stored array.
 """
 import ctypes as C
+import zlib
 
 import numpy as np
 import torch
@@ -94,6 +95,7 @@ class StepSharding(object):
         self.exchanges = 0
         self._sim_cache = {}
         self._scatter_cache = {}
+        self._patterns = {}                          # (per_x, per_y) -> (pattern, msgs_csr, nnz)
         self.periodic_xy = (False, False)            # (x, y) periodicity of the velocity: set by the step (the CSR numbering needs it)
         comm.sharded = True
         comm.step_sharding = self                    # the solvers reach the row map through their communicator
@@ -113,8 +115,16 @@ class StepSharding(object):
         return dict(nnz_u=int(out[4]), nnz_v=int(out[5]), mask_rows=int(out[6]))
 
     # ------------------------------------------------------------------------------------------------ pattern of the two matrices
-    def set_pattern(self, col_indices, row_pointers, nnz_u):
-        """col / rowptr of the STORED rows (one pattern-only assembly at set-up: they depend on the geometry only) and, from the
+    def pattern_for(self, per_x, per_y):
+        """The cached (col, rowptr, msgs_csr, (nnz_u, nnz_v)) of this periodicity, or None.  The stored nnz and the segments of the value
+        array depend on (per_x, per_y): one entry per periodicity the sharding has been stepped with - never a pattern of another one."""
+        hit = self._patterns.get((bool(per_x), bool(per_y)))
+        if hit is not None:
+            self.pattern, self.msgs_csr, self.nnz = hit[0], hit[1], hit[2]
+        return hit
+
+    def set_pattern(self, col_indices, row_pointers, nnz_u, per_xy=None, nnz=None):
+        """col / rowptr of the STORED rows (one pattern-only assembly per periodicity: they depend on the geometry only) and, from the
         row pointers, the segments of the stored value array that hold a block of face rows."""
         nx = self.nx
         nxu = nx + 1
@@ -131,6 +141,10 @@ class StepSharding(object):
             flat += _msg(segs(self._rows[key]))
         self.msgs_csr = (C.c_int * 28)(*flat)
         self.pattern = (col_indices, row_pointers)
+        if nnz is not None:
+            self.nnz = tuple(nnz)
+        if per_xy is not None:
+            self._patterns[(bool(per_xy[0]), bool(per_xy[1]))] = (self.pattern, self.msgs_csr, self.nnz)
 
     # ------------------------------------------------------------------------------------------------ halo exchanges (in place)
     def _exchange(self, t, msgs):
@@ -215,39 +229,48 @@ class StepSharding(object):
 
     # ------------------------------------------------------------------------------------------------ the simulation's constants, stored rows only
     def sim_tensors(self, sim, device):
-        """active / accessible masks, Dirichlet mask, no-slip mask of `sim` cut to this rank's stored rows (cached per sim object)."""
+        """active / accessible masks, Dirichlet mask, no-slip mask of `sim` cut to this rank's stored rows.  Cached per sim OBJECT (the
+        entry holds the object: an id() reused after a collection cannot hit) and per content stamp of its four arrays: replaced arrays and
+        in-place edits of arrays up to 1 MB (tensors: of any size) cut them again; larger numpy masks are constants of the sim object,
+        as they are on the one-GPU path (SimulationParameters._cached keys its device copies by the array's identity)."""
         key = (id(sim), str(device))
-        c = self._sim_cache.get(key)
-        if c is None:
-            c = dict(active=self.scatter_mask(_host(sim.active_mask), torch.float32, device),
-                     accessible=self.scatter_mask(_host(sim.accessible_mask), torch.float32, device),
-                     dmask=self.scatter_staggered(_host(sim.dirichlet_mask).astype(np.float32), torch.float32, device).ne(0).to(torch.uint8).contiguous(),
-                     no_slip=None)
-            if sim.no_slip_mask is not None:
-                c["no_slip"] = self.scatter_mask(_host(sim.no_slip_mask).astype(np.float32), torch.float32, device).ne(0).to(torch.uint8).contiguous()
-            self._sim_cache[key] = c
+        stamp = tuple(_stamp(a, big="identity") for a in (sim.active_mask, sim.accessible_mask, sim.dirichlet_mask, sim.no_slip_mask))
+        hit = self._sim_cache.get(key)
+        if hit is not None and hit[0] is sim and hit[1] == stamp:
+            return hit[2]
+        if len(self._sim_cache) > 8:
+            self._sim_cache.clear()
+        c = dict(active=self.scatter_mask(_host(sim.active_mask), torch.float32, device),
+                 accessible=self.scatter_mask(_host(sim.accessible_mask), torch.float32, device),
+                 dmask=self.scatter_staggered(_host(sim.dirichlet_mask).astype(np.float32), torch.float32, device).ne(0).to(torch.uint8).contiguous(),
+                 no_slip=None)
+        if sim.no_slip_mask is not None:
+            c["no_slip"] = self.scatter_mask(_host(sim.no_slip_mask).astype(np.float32), torch.float32, device).ne(0).to(torch.uint8).contiguous()
+        self._sim_cache[key] = (sim, stamp, c)
         return c
 
-    def cached_scatter_staggered(self, tensor):
-        """scatter_staggered of a constant of the simulation (Dirichlet values): cut once per object."""
-        key = ("st", id(tensor))
+    def _cached(self, kind, obj, cut):
+        """`cut(obj)` once per object AND content: identity + checksum for numpy arrays, identity + tensor._version for tensors (an
+        array updated in place - a dirichlet_update_fn that returns the same array, a viscosity field edited between steps - is cut
+        again; the one-GPU path re-uploads in exactly these cases, grids.device_constant).  Numpy arrays above 1 MB are not cached."""
+        key = (kind, id(obj))
+        stamp = _stamp(obj)
+        if stamp is None:                              # a numpy array above 1 MB: cut every time (the one-GPU path uploads it every time)
+            return cut(obj)
         hit = self._scatter_cache.get(key)
-        if hit is None or hit[0] is not tensor:
+        if hit is None or hit[0] is not obj or hit[1] != stamp:
             if len(self._scatter_cache) > 32:
                 self._scatter_cache.clear()
-            hit = (tensor, self.scatter_staggered(_host(tensor).astype(np.float32)))
+            hit = (obj, stamp, cut(obj))
             self._scatter_cache[key] = hit
-        return hit[1]
+        return hit[2]
+
+    def cached_scatter_staggered(self, tensor):
+        """scatter_staggered of a constant of the simulation (Dirichlet values)."""
+        return self._cached("st", tensor, lambda t: self.scatter_staggered(_host(t).astype(np.float32)))
 
     def cached_scatter_faces(self, flat):
-        key = ("fl", id(flat))
-        hit = self._scatter_cache.get(key)
-        if hit is None or hit[0] is not flat:
-            if len(self._scatter_cache) > 32:
-                self._scatter_cache.clear()
-            hit = (flat, self.scatter_faces(torch.as_tensor(_host(flat).reshape(-1)), dtype=torch.float32))
-            self._scatter_cache[key] = hit
-        return hit[1]
+        return self._cached("fl", flat, lambda f: self.scatter_faces(torch.as_tensor(_host(f).reshape(-1)), dtype=torch.float32))
 
     # ------------------------------------------------------------------------------------------------ fields
     def staggered_grid(self, flat, box, extrapolation):
@@ -263,6 +286,20 @@ class StepSharding(object):
     def close(self):
         self.comm.sharded = False
         self.comm.step_sharding = None
+
+
+def _stamp(x, big=None):
+    """What changes when the CONTENT of a cached input changes: tensor._version for tensors (bumped by every in-place op), an adler32
+    checksum for numpy arrays up to 1 MB (the bound of grids.device_constant; ~1 ms per MB).  Above that: None ("do not cache"), or with
+    big="identity" the array's address and shape (constants of a simulation object)."""
+    if x is None:
+        return ("none",)
+    if isinstance(x, torch.Tensor):
+        return ("v", x._version, tuple(x.shape), x.data_ptr())
+    a = np.asarray(x)
+    if a.nbytes > (1 << 20):
+        return ("i", a.__array_interface__["data"][0], a.shape, str(a.dtype)) if big == "identity" else None
+    return ("c", zlib.adler32(a if a.flags.c_contiguous else np.ascontiguousarray(a)), a.shape, str(a.dtype))
 
 
 def _host(x):

@@ -121,7 +121,8 @@ int piso_slab_sizes(const piso_slab_t* slab, int nx, int ny, int periodic_x, int
  *   csr_*      the concatenated two-matrix CSR produced by piso_assemble_csr (values possibly negated by the caller)
  *   rhs, x0    [n_u + n_v];  x_out [n_u + n_v]
  *   tol        absolute ||r||_2 tolerance; max_it per restart; transpose: bit 0 = solve with A^T (adjoint), bit 1 = the system matrix
- *              is -csr_val (the reference hands the op `-matrix_values`, piso_tf.py:41: the sign is applied where the values are read)
+ *              is -csr_val (the reference hands the op `-matrix_values`, piso_tf.py:41: the sign is applied where the values are read);
+ *              any other bit set: PISO_ERR_INVALID_ARG (a caller meaning "non-zero = transpose" with 2 or -1 must not get another system)
  *   band_rows  rows of faces per preconditioner block: < 0  = one block (global structured ILU0),
  *              0 = automatic (8 rows from ny = 2048 on, 4 from 1024, 2 from 256, 8 below), > 0 = that many.  See DESIGN.md "structured block ILU0".
  *   warning    device byte, set to 1 on NaN input (never cleared);  iterations_out: host int[2] or NULL

@@ -58,7 +58,15 @@ if len(sys.argv) > 3:
     for m in re.finditer(r"^(\S.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*(\d+) mean=([0-9.e+]+) sum=([0-9.e+]+)", btxt, re.M):
         if "bi_" in m.group(1):
             tot[m.group(2)] += float(m.group(5))
-    fixed_its, fixed_solves = 20, 4                                    # bench.bicgstab_fixed_work under PISO_BICG_PROFILE=1: 4 solves of 2 x 10 iterations
+    # how many solves the profiled run made and how long each was: printed by scripts/bench_bicg.py itself (the JSON line in the run log,
+    # argument 4); the PMC passes must run under PISO_BICG_PROFILE=1 (fixed-work solves only: real_solves_run == 0)
+    fixed_its, fixed_solves = 20, 4
+    if len(sys.argv) > 4:
+        line = [l for l in open(sys.argv[4]).read().splitlines() if l.startswith("{") and "fixed_work_solves_run" in l]
+        rec = json.loads(line[-1])
+        if rec.get("real_solves_run", 0) != 0:
+            raise SystemExit("the BiCGStab PMC pass also ran solves to tolerance: run it under PISO_BICG_PROFILE=1")
+        fixed_its, fixed_solves = int(rec["iterations_per_fixed_solve"]), int(rec["fixed_work_solves_run"])
     share = 1.0
     rb = tot["FETCH_SIZE"] * 1024 * (cal["read_16B_per_lane"] or 1.0) / fixed_solves
     wb = tot["WRITE_SIZE"] * 1024 * (cal["write_16B_per_lane"] or 1.0) / fixed_solves

@@ -6,7 +6,7 @@
 #   4. rocprofv3 --kernel-trace --stats of a fixed-work BiCGStab run (scripts/bench_bicg.py)  -> <tag>_bicgstab2048_kernel_stats.csv
 #   5. scripts/make_traffic_json.py condenses 2 + 3 into traffic.json (with the sha of the kernel sources it was measured on)
 # Raw traces stay in /tmp on the box; only summaries are copied to gpurun_out/prof/ (64 MiB cap).  Usage: profile_bench.sh <tag>
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the snapshot's root)}
 TAG=${1:-rXX}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT $R/scripts/_bin
@@ -27,7 +27,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/bicg_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/bicg_write -o bicg -- python3 $R/scripts/bench_bicg.py 2048 > $OUT/${TAG}_bicg_write_run.log 2>&1
 unset PISO_BICG_PROFILE
 python3 $R/scripts/summarize_pmc.py /tmp/bicg_fetch /tmp/bicg_write > $OUT/${TAG}_bicgstab2048_pmc_fetch_write_summary.txt 2>&1
-python3 $R/scripts/make_traffic_json.py $OUT/${TAG}_bench2048_pmc_fetch_write_summary.txt $TAG $OUT/${TAG}_bicgstab2048_pmc_fetch_write_summary.txt > $OUT/traffic.json 2> $OUT/${TAG}_traffic.log
+python3 $R/scripts/make_traffic_json.py $OUT/${TAG}_bench2048_pmc_fetch_write_summary.txt $TAG $OUT/${TAG}_bicgstab2048_pmc_fetch_write_summary.txt $OUT/${TAG}_bicg_fetch_run.log > $OUT/traffic.json 2> $OUT/${TAG}_traffic.log
 # 6. the bench line of the SAME sources with the traffic record just taken (bench.py reads profiles/traffic.json and uses it only if the
 #    sha of the kernel sources matches): fail loudly if it does not
 cp $OUT/traffic.json $R/profiles/traffic.json

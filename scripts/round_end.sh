@@ -2,7 +2,8 @@
 # What the driver runs at round end, plus the profiling recipe, in ONE gpurun call: the whole GPU suite (per-test timeouts), then
 # profile_bench.sh <tag> (kernel stats, PMC passes, traffic.json, the bench line), prof_small.sh 256 and prof_config4.sh.
 #   gpurun --timeout 3000 -- 'bash scripts/round_end.sh r05_x'      then copy gpurun_out/prof/<tag>_* into profiles/
-R=$GRAFT_REPO_ROOT
+set -u
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the snapshot's root)}
 TAG=${1:-rXX}
 mkdir -p $R/gpurun_out
 cd $R

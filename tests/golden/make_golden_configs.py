@@ -18,6 +18,7 @@ algorithm and control flow, deterministic reductions).  Nothing of /root/referen
                               pressure / fp32 advection): one forward step + its reverse sweep
   bench1024_tight_step.npz    the same workload at 1024^2 with converged solves (pressure 1e-12, advection 1e-9)
   bench2048_tight_step.npz    ... and at the benchmark's own size (~1 h on 8 cores)
+  bench512_tight_unroll16.npz the same workload at 512^2 unrolled 16 steps forward and differentiated back through all of them, converged solves
 """
 import json
 import os
@@ -215,6 +216,43 @@ def make_bench2048(n=2048, solver=BENCH_SOLVER, name="bench%d_step"):
     print("bench", meta)
 
 
+def make_bench_unrolled(n=512, steps=16, solver=None, name="bench%d_tight_unroll%d"):
+    """The metric workload (periodic decaying turbulence, bench.py's velocity and time step) unrolled `steps` steps forward and
+    differentiated back through all of them (L = 1/2 |u_N|^2) with CONVERGED solves: the north star's "fwd + 16-step adjoint within 1e-5"
+    on the workload the metric is quoted on (run_piso_steps, combined_training_integrated.py:396-478)."""
+    solver = dict(solver or TIGHT_SOLVER)
+    import bench
+    t0 = time.time()
+    vel = bench.turbulence_velocity(n)
+    dx = 2 * np.pi / n
+    dt = 0.5 * dx / float(np.abs(vel).max())
+    st = (1, n + 1, n + 1, 2)
+    ones = np.ones((1, n + 2, n + 2, 1), f32)
+    p_tol_adjoint = solver.pop("p_tol_adjoint", None)
+    s = R.OracleSetup(n, n, (dx, dx), (True, True), np.zeros(st, bool), ones, ones, viscosity=1e-3, **solver)
+    dv = np.zeros(st, f32)
+    vel_k, p_k, tapes = vel, np.zeros((n, n), f32), []
+    for k in range(steps):
+        vel_k, p_k, tape = R.piso_step(s, vel_k, p_k, dt, dv, None)
+        tapes.append(tape)
+        print("unroll%d fwd step %d" % (n, k), tape["it1"], tape["it2"], tape["lin_its"], "%.0fs" % (time.time() - t0), flush=True)
+    if p_tol_adjoint is not None:
+        s.p_tol = p_tol_adjoint
+    d_vel, d_p = vel_k.copy(), np.zeros_like(p_k)
+    for k in range(steps - 1, -1, -1):
+        g = R.piso_step_backward(s, tapes[k], d_vel, d_p)
+        d_vel, d_p = g["d_vel"], g["d_p"]
+        print("unroll%d bwd step %d" % (n, k), tapes[k]["adjoint_its"], "%.0fs" % (time.time() - t0), flush=True)
+    meta = dict(grid=n, steps=steps, solver=dict(solver, **({"p_tol_adjoint": p_tol_adjoint} if p_tol_adjoint is not None else {})),
+                seconds=time.time() - t0, cg_iterations_fwd=[[t["it1"], t["it2"]] for t in tapes],
+                cg_iterations_adjoint=[t["adjoint_its"] for t in tapes], bicgstab_iterations=[t["lin_its"] for t in tapes],
+                warn=[bool(t["warn"]) for t in tapes])
+    np.savez_compressed(os.path.join(OUT, (name % (n, steps)) + ".npz"), meta=json.dumps(meta), stride=STRIDE, in_vel_norm=nrm(vel), dt=dt,
+                        vel_sub=sub(vel_k), vel_norm=nrm(vel_k), p_sub=sub(p_k), p_norm=nrm(p_k),
+                        d_vel_sub=sub(d_vel), d_vel_norm=nrm(d_vel), d_p_sub=sub(d_p), d_p_norm=nrm(d_p))
+    print("unroll", meta)
+
+
 if __name__ == "__main__":
     R.USE_OMP_CG = True          # (only when run as the generator: importing this module for its case builders changes nothing)
     which = sys.argv[1:] or ["cfg3", "cfg4", "bench2048", "bench1024_tight"]
@@ -230,5 +268,9 @@ if __name__ == "__main__":
         make_bench2048(2048, TIGHT_SOLVER_2048, "bench%d_tight_step")
     if "bench512_tight" in which:
         make_bench2048(512, TIGHT_SOLVER, "bench%d_tight_step")
+    if "bench512_unroll16" in which:     # the metric workload, 16 steps forward + reverse, converged solves
+        make_bench_unrolled(512, 16)
+    if "bench1024_unroll16" in which:
+        make_bench_unrolled(1024, 16)
     if "bench512" in which:       # quick look at the workload at a small size (not committed)
         make_bench2048(512)

@@ -175,3 +175,73 @@ def test_step_sharding_halo_messages_are_consistent():
             assert z["mask_rows"] == sh[r].mr and z["nnz_u"] == 5 * sh[r].n_u and z["nnz_v"] == 5 * sh[r].n_v      # (periodic: 5 entries per row)
             z = sh[r].sizes(False, False)
             assert 0 < z["nnz_u"] <= 5 * sh[r].n_u and 0 < z["nnz_v"] <= 5 * sh[r].n_v
+
+
+def test_step_sharding_caches_follow_the_content_not_only_the_identity():
+    """The sharded step's caches (StepSharding.cached_scatter_* / sim_tensors) are keyed like grids.device_constant: identity AND a
+    content stamp.  An array updated in place (a dirichlet_update_fn returning the same numpy array, a tensor edited between steps) is
+    cut again; a new sim object never finds another object's masks even if id() is reused; the CSR pattern is kept per periodicity."""
+    import numpy as np
+    import torch
+    from diffpiso.sharding import StepSharding
+
+    class FakeComm(object):
+        def __init__(self, rank, world):
+            self.rank, self.world, self.handle, self.sharded, self.device = rank, world, None, False, torch.device("cpu")
+
+    nx, ny = 12, 16
+    sh = StepSharding(FakeComm(1, 2), nx, ny)
+    dv = np.zeros((1, ny + 1, nx + 1, 2), np.float32)
+    a = sh.cached_scatter_staggered(dv)
+    assert sh.cached_scatter_staggered(dv) is a                                   # same object, same content: the cached rows
+    dv[0, 10, :, 1] = 3.0                                                         # updated IN PLACE
+    b = sh.cached_scatter_staggered(dv)
+    assert b is not a and float(b.abs().max()) == 3.0
+    np.testing.assert_array_equal(b.numpy(), sh.scatter_staggered(dv).numpy())
+    t = torch.zeros((nx + 1) * ny + nx * (ny + 1))
+    f0 = sh.cached_scatter_faces(t)
+    assert sh.cached_scatter_faces(t) is f0
+    t[5] = 1.0                                                                    # tensor._version moves
+    assert sh.cached_scatter_faces(t) is not f0
+
+    class Sim(object):
+        def __init__(self, fill):
+            self.active_mask = np.full((1, ny + 2, nx + 2, 1), fill, np.float32)
+            self.accessible_mask = np.ones((1, ny + 2, nx + 2, 1), np.float32)
+            self.dirichlet_mask = np.zeros((1, ny + 1, nx + 1, 2), bool)
+            self.no_slip_mask = None
+
+    s1 = Sim(1.0)
+    c1 = sh.sim_tensors(s1, torch.device("cpu"))
+    assert sh.sim_tensors(s1, torch.device("cpu")) is c1
+    s1.active_mask[0, 9, :, 0] = 0.0                                              # in place
+    c1b = sh.sim_tensors(s1, torch.device("cpu"))
+    assert c1b is not c1 and float(c1b["active"].min()) == 0.0
+    # an entry only answers for the object it was made from (a recycled id() must not return another simulation's masks)
+    key = (id(s1), str(torch.device("cpu")))
+    s2 = Sim(0.5)
+    sh._sim_cache[(id(s2), str(torch.device("cpu")))] = sh._sim_cache[key]       # what a recycled id would look like
+    assert float(sh.sim_tensors(s2, torch.device("cpu"))["active"].max()) == 0.5
+    # CSR pattern: one entry per periodicity, never another periodicity's
+    assert sh.pattern_for(True, True) is None
+    rp = torch.arange(sh.n_u + sh.n_v + 2, dtype=torch.int32)
+    sh.set_pattern(torch.zeros(4, dtype=torch.int32), rp, 7, per_xy=(True, True), nnz=(7, 9))
+    assert sh.pattern_for(True, False) is None and sh.pattern_for(True, True) is not None and sh.nnz == (7, 9)
+
+
+def test_flat_faces_shortcut_only_while_the_components_are_views_of_the_flat_vector():
+    import torch
+    import diffpiso as dp
+    from diffpiso import fused
+
+    class Geom(object):
+        sh, nx, ny = None, 5, 4
+        n_u = 4 * 6
+
+    flat = torch.arange(4 * 6 + 5 * 5, dtype=torch.float32)
+    grid = fused.faces_to_grid(flat, Geom, None, "boundary")
+    assert fused.flat_faces(grid) is flat
+    grid.data[1].data = grid.data[1].data * 2.0                                   # user code rebinds a component between two steps
+    got = fused.flat_faces(grid)
+    assert got is not flat
+    assert torch.equal(got[:Geom.n_u], 2.0 * flat[:Geom.n_u]) and torch.equal(got[Geom.n_u:], flat[Geom.n_u:])

@@ -153,6 +153,54 @@ def _bench_step(fixture, tols):
     assert not bad, bad
 
 
+def _bench_unrolled(fixture, tols):
+    """The metric workload unrolled N steps forward + the reverse sweep through all of them (L = 1/2 |u_N|^2) against the oracle fixture."""
+    import bench
+    import diffpiso as dp
+    d, meta = _load(fixture)
+    n, steps, sv = meta["grid"], meta["steps"], meta["solver"]
+    P = bench.build_problem(n, torch.device("cuda"), sv["p_tol"], sv["p_max_it"], sv["p_reset"])
+    P["lin"].accuracy, P["lin"].max_iterations = sv["lin_tol"], sv["lin_max_it"]
+    assert abs(np.linalg.norm(P["vel"].astype(np.float64)) - float(d["in_vel_norm"])) < 1e-6 * float(d["in_vel_norm"])
+    assert abs(P["dt"] - float(d["dt"])) < 1e-12
+    stride = int(d["stride"])
+    vel_t = P["vel_t"].clone().requires_grad_(True)
+    p_t = P["p_t"].clone().requires_grad_(True)
+    ext = dp.Material.extrapolation_mode(P["domain"].boundaries)
+    velocity = dp.StaggeredGrid(vel_t, P["domain"].box, extrapolation=ext)
+    pressure = dp.CenteredGrid(p_t, P["domain"].box, dp.pressure_extrapolation(P["domain"].boundaries))
+    va, pa, vn, pn, warn = dp.unroll_piso_steps(velocity, pressure, P["dt"], P["sim"], step_count=steps)
+    assert float(sum(float(w.detach().sum()) for w in warn)) == 0
+    print("%s: CG iterations of the last forward solve %s, oracle (last step) %s" % (fixture, P["ps"].last_iterations, meta["cg_iterations_fwd"][-1]))
+    bad = []
+    _check("u_%d" % steps, vn.staggered_tensor(), d["vel_sub"], float(d["vel_norm"]), stride, tols["u"], bad)
+    _check("p_%d" % steps, pn.data, d["p_sub"], float(d["p_norm"]), stride, tols["p"], bad)
+    if "p_tol_adjoint" in sv:
+        P["ps"].accuracy = sv["p_tol_adjoint"]
+    (0.5 * (vn.staggered_tensor() ** 2).sum()).backward()
+    print("%s: CG iterations of the last adjoint solve %s, oracle (step 0) %s" % (fixture, P["ps"].last_adjoint_iterations, meta["cg_iterations_adjoint"][0]))
+    _check("dL/du_0", vel_t.grad, d["d_vel_sub"], float(d["d_vel_norm"]), stride, tols["du"], bad)
+    dx = 2 * np.pi / n
+    summands = np.sqrt(2.0) * float(d["dt"]) / dx * float(d["d_vel_norm"])          # (see _bench_step: what dL/dp_0 is a cancelling sum of)
+    _check("dL/dp_0", p_t.grad, d["d_p_sub"], float(d["d_p_norm"]), stride, tols["dp"], bad, scale_norm=max(summands, float(d["d_p_norm"])))
+    assert not bad, bad
+
+
+def test_benchmark_workload_512_sixteen_steps_converged():
+    """The north star's "fwd + 16-step adjoint within 1e-5" on the workload the metric is quoted on (periodic decaying turbulence,
+    bench.py's velocity and time step) at 512^2: 16 unrolled steps forward, the reverse sweep through all 16
+    (run_piso_steps, combined_training_integrated.py:396-478), converged solves (pressure 1e-12, advection 1e-9)."""
+    _bench_unrolled("bench512_tight_unroll16.npz", _TIGHT)
+
+
+def test_benchmark_workload_1024_sixteen_steps_converged():
+    """... and at 1024^2 (the oracle needs ~25 min on 8 threads for this fixture)."""
+    import os
+    if not os.path.isfile(os.path.join(HERE, "golden", "bench1024_tight_unroll16.npz")):
+        pytest.skip("fixture not generated")
+    _bench_unrolled("bench1024_tight_unroll16.npz", _TIGHT)
+
+
 # Converged fixtures (round 3: pressure solves to max|r| < 1e-12, advection 1e-9): velocity, PRESSURE and both back-propagated
 # gradients are held to the north star's 1e-5 (dL/dp_0 against the size of its summands, see _bench_step).  At the round-2
 # tolerance of 1e-8 two correct solvers still differed by 3e-3 .. 1e-2 in the pressure's smoothest modes (tolerance / smallest
