@@ -152,9 +152,10 @@ def build_mixing_layer(ny, nx, device, tol, max_it, reset):
                 dt=dt, lin=lin, ps=ps)
 
 
-def run_unrolled(P, steps, backward=True, clock=None, keep=None):
+def run_unrolled(P, steps, backward=True, clock=None, keep=None, adjoint_accuracy=None):
     """K steps forward through the reference-signature run_piso_steps, then the reverse sweep of L = 1/2 |u_K|^2.
-    clock (optional dict): 'fwd_s' / 'bwd_s' accumulate wall time with a device synchronisation between the two sweeps."""
+    clock (optional dict): 'fwd_s' / 'bwd_s' accumulate wall time with a device synchronisation between the two sweeps.
+    adjoint_accuracy (optional): the pressure solver's tolerance for the reverse sweep (`accuracy` is read at every solve)."""
     import torch
     import diffpiso as dp
     ext = dp.Material.extrapolation_mode(P["domain"].boundaries)
@@ -184,6 +185,8 @@ def run_unrolled(P, steps, backward=True, clock=None, keep=None):
         t1 = time.perf_counter()
         clock["fwd_s"] = clock.get("fwd_s", 0.0) + t1 - t0
     if backward:
+        if adjoint_accuracy is not None:
+            P["ps"].accuracy = adjoint_accuracy
         loss.backward()
         if clock is not None:
             torch.cuda.synchronize()
@@ -191,6 +194,40 @@ def run_unrolled(P, steps, backward=True, clock=None, keep=None):
     if keep is not None:          # (--dump-fields: the fields behind the loss, for the field-level parity tests of the sharded step)
         keep.update(u=vn.staggered_tensor().detach(), p=out[4].data.detach(), du=vel_t.grad, dp=p_t.grad)
     return vel_t.grad, float(loss.detach()), warn
+
+
+# tests/golden/make_golden_configs.py::TIGHT_SOLVER_2048: the settings at which two correct implementations agree to 1e-5 on this workload
+CONVERGED = dict(lin_tol=1e-9, lin_max_it=300, p_tol=1e-12, p_tol_adjoint=1e-10, p_max_it=200000, p_reset=1000)
+
+
+def converged_solves_figure(n, device):
+    """The SAME workload and step with CONVERGED solves, timed beside the headline (N = 1, after the timed region).  The headline's
+    settings are the reference scripts' (absolute max-norm tolerance 1e-6, 10 000 iterations): its adjoint pressure solves stop at
+    the iteration cap, unconverged, and what the step then returns is reproducible between two correct implementations only to
+    ~1e-4 (config.parity_at_bench_settings).  At these settings every solve converges and the fields / gradients are held to 1e-5
+    against the oracle (tests/test_gpu_golden_configs.py::test_benchmark_workload_2048_converged_solves_forward_and_reverse)."""
+    import torch
+    c = CONVERGED
+    P = build_problem(n, device, c["p_tol"], c["p_max_it"], c["p_reset"])
+    P["lin"].accuracy, P["lin"].max_iterations = c["lin_tol"], c["lin_max_it"]
+    run_unrolled(P, 1, adjoint_accuracy=c["p_tol_adjoint"])                       # warm-up (allocations, workspaces)
+    P["ps"].accuracy = c["p_tol"]
+    for st in (P["ps"].stats, P["lin"].stats):
+        for k in st:
+            st[k] = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, loss, warn = run_unrolled(P, 1, adjoint_accuracy=c["p_tol_adjoint"])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ps = P["ps"].stats
+    its = ps["iterations"] + ps["adjoint_iterations"]
+    return {"steps_per_s": 1.0 / el, "ms_per_step": 1e3 * el, "settings": c,
+            "cg_iterations_per_step": {"forward": ps["iterations"], "adjoint": ps["adjoint_iterations"]},
+            "us_per_cg_iteration_incl_everything_else": 1e6 * el / max(its, 1),
+            "solves_at_iteration_cap": int(ps["iterations"] >= c["p_max_it"]) + int(ps["adjoint_iterations"] >= 2 * c["p_max_it"]),
+            "warn": float(sum(float(w.detach().sum()) for w in warn)), "loss": loss,
+            "parity": "u, p, dL/du_0, dL/dp_0 within 1e-5 of the oracle at exactly these settings (tests/golden/bench2048_tight_step.npz)"}
 
 
 def bicgstab_fixed_work(P, n, iters=10, reps=3, real=True):
@@ -427,7 +464,7 @@ def cpu_baseline_pricing_check(tol, max_it, reset, n=256):
     a0 = ((np.float32(1) / (np.float32(beta) - A_t)) * np.float32(1.0)).astype(np.float32)
     L = O.laplace_matrix(n, n, s.active, s.accessible, R.flatten_staggered(a0, False))
     div = R.fv_divergence(R.stagger_flattened(x, n, n, True), s.dx_yx).astype(np.float64).ravel()
-    sample = 2000
+    sample = 2000 if n <= 512 else 400
     t0 = time.perf_counter()
     O.cg_solve_omp(n, n, True, True, L, div, 1e-30, sample, True, 1000)
     t_cg = (time.perf_counter() - t0) / sample
@@ -482,6 +519,18 @@ def measured_traffic(n, kernel):
         return e, e.get("source")
     except Exception as ex:
         return None, "no PMC record (%s)" % type(ex).__name__
+
+
+def measured_sq_counters(n):
+    """The persistent CG kernel's SQ counters (scripts/profile_sq.sh -> profiles/sq_counters.json): only if taken on THIS version of
+    the kernel sources."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "sq_counters.json")))[str(n)]
+        if e.get("kernel_source_sha") != kernel_source_sha():
+            return None, "profiles/sq_counters.json was measured on another version of the kernel sources"
+        return e, e.get("source")
+    except Exception as ex:
+        return None, "no SQ-counter record (%s)" % type(ex).__name__
 
 
 def slab_self_check(n, device, rank, world, iters=300, share_gpu=False, settings=None, replica_steps_per_s=None):
@@ -903,8 +952,13 @@ def main():
             if VALU_INSTR_PER_CELL.get(exchanges):   # what THIS instruction stream needs (not a floor of the algorithm: reported beside them)
                 floors["valu_issue_of_the_compiled_loop"] = VALU_INSTR_PER_CELL[exchanges] * ncell / 256 / 64 / 4 * 4.5 / (CLOCK_GHZ * 1e3)
             serial_floor = floors["fp64_valu_issue"] + floors["grid_exchanges"]   # the exchange cannot overlap the arithmetic it feeds
-            roofline = {"bound": "hbm",       # (the contract's enum: the roofline `frac` is priced against; what BINDS the kernel is `binds`)
+            sq, sq_src = measured_sq_counters(n)
+            roofline = {# what the kernel's own SQ counters show (profiles/sq_counters.json, scripts/profile_sq.sh): the VALU pipes are
+                        # busy ~62 % of the time, the waves parked (exchange, waitcnt) ~43 % of theirs - NOT an HBM-bound kernel.
+                        # `achieved` / `peak` / `frac` stay the contract's HBM figure: fabric bytes (PMC) per second over the HBM peak
+                        "bound": "valu+latency", "bound_enum_of_the_contract": "hbm (what `frac` is priced against)",
                         "binds": "valu_issue+exchange",
+                        "sq_counters": sq, "sq_counters_source": sq_src,
                         "kernel": "cg_persist1 (one launch = %.0f CG iterations: r, p in registers, x in LDS, float coefficients "
                                   "streamed, %d grid exchange%s per iteration, fp64)" % (its, exchanges, "" if exchanges == 1 else "s"),
                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -978,7 +1032,16 @@ def main():
                        "grid": [ny_grid, n], "last_cg_iterations_fwd": P["ps"].last_iterations or 0,
                        "last_cg_iterations_adjoint": P["ps"].last_adjoint_iterations or 0,
                        "last_bicgstab_iterations": list(P["lin"].last_iterations or ()),
-                       "loss": loss, "grad_norm": grad_norm, "warn": float(sum(float(w.detach().sum()) for w in warn))},
+                       "loss": loss, "grad_norm": grad_norm, "warn": float(sum(float(w.detach().sum()) for w in warn)),
+                       # what the benchmark IS: the reference scripts' solver settings leave the adjoint pressure solves unconverged ...
+                       "solves_at_iteration_cap": phases["cg_solves_at_iteration_cap"],
+                       # ... so the step's outputs are reproducible between two correct implementations only this far (HIP vs oracle,
+                       # tests/golden/bench2048_step.npz, tests/test_gpu_golden_configs.py::..._bench_settings_...); the north star's
+                       # 1e-5 is met - and tested - with converged solves: see `converged_solves` beside `value`
+                       "parity_at_bench_settings": ({"u_1": 1.2e-4, "p_1": 1.9e-2, "dL/du_0": 1.2e-5, "dL/dp_0": 8.6e-4,
+                                                     "what": "rel-L2 HIP vs CPU oracle at THESE settings (2048^2, one step); bounded in the test at "
+                                                             "5e-4 / 5e-2 / 1e-4 / 5e-3; with converged solves all four are < 1e-5"}
+                                                    if (n == 2048 and ny_grid == n and args.tol == 1e-6 and args.max_iterations == 10000) else None)},
             "roofline": roofline, "phases": phases,
         }
         if sharded_info is not None:
@@ -996,13 +1059,23 @@ def main():
                 out["other_configs"] = other_configs(device)
             except Exception as e:
                 out["other_configs"] = {"error": repr(e)}
+            try:
+                out["converged_solves"] = converged_solves_figure(n, device)
+            except Exception as e:
+                out["converged_solves"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and ny_grid == n:
             try:
                 out["cpu_baseline"] = cpu_baseline(P, n, args.tol, int(round(cg_per_step)) or 4000)
                 try:
-                    out["cpu_baseline"]["pricing_check"] = cpu_baseline_pricing_check(args.tol, args.max_iterations, args.residual_reset)
+                    # a WHOLE oracle step (forward + reverse sweep, the bench's solver settings) TIMED for real at 1024^2 - the largest
+                    # size at which that takes about a minute - with the pricing formula of the 2048^2 figure evaluated beside it
+                    ts = cpu_baseline_pricing_check(args.tol, args.max_iterations, args.residual_reset, n=1024)
+                    ts["steps_per_s"] = 1.0 / ts["measured_s_per_step"]
+                    ts["kind"] = "timed (not priced): one fwd + adjoint PISO step of the C oracle at 1024^2, OpenMP CG on %d threads" % out["cpu_baseline"]["cores"]
+                    out["cpu_baseline"]["timed_step"] = ts
+                    out["cpu_baseline"]["value_is"] = "priced from timed samples at 2048^2 (see sample); timed_step is a whole step timed at 1024^2"
                 except Exception as e:
-                    out["cpu_baseline"]["pricing_check"] = {"error": repr(e)}
+                    out["cpu_baseline"]["timed_step"] = {"error": repr(e)}
             except Exception as e:   # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     rc = 0

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ-counter passes of the persistent CG kernel itself (what binds an iteration: VALU issue, parked waves, issue stalls, LDS conflicts).
 # One --pmc group per pass, --kernel-trace only, the program directly after "--" (gpurun refuses anything else).
-#   gpurun -- 'bash scripts/profile_sq.sh r06 2048'    -> gpurun_out/prof/<tag>_cg_persist1_<n>_sq_counters.txt  (copy into profiles/)
+#   gpurun -- 'bash scripts/profile_sq.sh r06 2048'    -> gpurun_out/prof/<tag>_cg_persist1_<n>_sq_counters.txt + sq_counters.json (copy both into profiles/)
 R=${GRAFT_REPO_ROOT:?run through gpurun}
 TAG=${1:-rXX}
 N=${2:-2048}
@@ -20,5 +20,5 @@ for P in "$P1" "$P2" "$P3" "$P4"; do
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/sq_$i -o sq -- python3 $R/scripts/bench_cg.py $N > $OUT/${TAG}_sq_pass${i}_run.log 2>&1
   echo "pass $i rc $?"
 done
-python3 $R/scripts/summarize_sq.py $N /tmp/sq_1 /tmp/sq_2 /tmp/sq_3 /tmp/sq_4 > $OUT/${TAG}_cg_persist1_${N}_sq_counters.txt 2>&1
+python3 $R/scripts/summarize_sq.py $N /tmp/sq_1 /tmp/sq_2 /tmp/sq_3 /tmp/sq_4 --json $OUT/sq_counters.json > $OUT/${TAG}_cg_persist1_${N}_sq_counters.txt 2>&1
 cat $OUT/${TAG}_cg_persist1_${N}_sq_counters.txt

@@ -9,6 +9,11 @@ import os
 import sys
 
 n = int(sys.argv[1])
+json_out = None
+if "--json" in sys.argv:
+    k = sys.argv.index("--json")
+    json_out = sys.argv[k + 1]
+    del sys.argv[k:k + 2]
 ITERS = 300                                        # scripts/bench_cg.py: iterations per timed launch pair (warm-up + timed)
 vals = collections.defaultdict(lambda: [0.0, 0])
 names = collections.Counter()
@@ -50,3 +55,25 @@ if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
 if g("SQ_WAVE_CYCLES") and g("SQ_WAVES"):
     # quad-cycles per wave and iteration -> shader cycles per iteration (a wave lives for the whole launch)
     print("shader cycles per iteration (4 x SQ_WAVE_CYCLES / waves / iterations): %.0f" % (4 * g("SQ_WAVE_CYCLES") / g("SQ_WAVES") / ITERS))
+
+if json_out and g("SQ_WAVE_CYCLES") and g("SQ_WAVES"):
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    wc, w = g("SQ_WAVE_CYCLES"), g("SQ_WAVES")
+    rec = {"grid": n, "kernel": names.most_common(1)[0][0][:100], "kernel_source_sha": bench.kernel_source_sha(), "iterations_per_launch": ITERS,
+           "waves": w, "waves_per_simd": 2,
+           "wave_cycle_fractions": {k: (g(v) / wc if g(v) is not None else None) for k, v in (
+               ("valu_issue", "SQ_ACTIVE_INST_VALU"), ("any_issue", "SQ_ACTIVE_INST_ANY"), ("parked_waitcnt_barrier_sleep", "SQ_WAIT_ANY"),
+               ("issue_stall", "SQ_WAIT_INST_ANY"), ("lds_issue", "SQ_ACTIVE_INST_LDS"), ("scalar_issue", "SQ_ACTIVE_INST_SCA"),
+               ("vmem_issue", "SQ_ACTIVE_INST_VMEM"))},
+           "valu_pipe_busy": 2 * g("SQ_ACTIVE_INST_VALU") / wc if g("SQ_ACTIVE_INST_VALU") else None,
+           "per_wave_and_iteration": {k: (g(k) / w / ITERS if g(k) is not None else None) for k in (
+               "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")},
+           "valu_cycles_per_instruction": 4 * g("SQ_ACTIVE_INST_VALU") / g("SQ_INSTS_VALU") if g("SQ_INSTS_VALU") else None,
+           "shader_cycles_per_iteration": 4 * wc / w / ITERS,
+           "lds_bank_conflict_share": (g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")) if g("SQ_LDS_IDX_ACTIVE") else None,
+           "source": "scripts/profile_sq.sh: rocprofv3 --kernel-trace --pmc <one SQ group per pass> -- python3 scripts/bench_cg.py %d" % n,
+           "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves; fractions are of a wave's life, "
+                    "valu_pipe_busy = 2 waves per SIMD x valu_issue"}
+    json.dump({str(n): rec}, open(json_out, "w"), indent=1)          # profiles/sq_counters.json (bench.py: roofline.sq_counters)
