@@ -910,7 +910,31 @@ def main():
         dist.all_reduce(tot)                         # loss and |dL/du_0|^2 are sums of the ranks' parts; how many ranks took part
         loss, grad_norm = float(tot[0]), float(tot[2]) ** 0.5
         st_ = P["ps"].slab_comm.stats()
+        # the hop every exchange pays, MEASURED on this node: one tagged word through the mailboxes, there and back, between every pair
+        # of ranks (pair by pair, everybody else idle); what slab_kernel_loopback.latency_sweep of the N = 1 line is to be read against
+        hop, hop_err = None, None
+        if st_["transport"] == "peer":
+            try:
+                hop = P["ps"].slab_comm.hop_matrix(2000)
+            except Exception as e:
+                hop_err = repr(e)
+        off_diag = [hop[a][b] for a in range(world) for b in range(world) if a != b] if hop else []
+        ring = [hop[r][(r + 1) % world] for r in range(world)] if hop else []
+        try:
+            p2p = [[bool(a == b or torch.cuda.can_device_access_peer(a, b)) for b in range(torch.cuda.device_count())] for a in range(torch.cuda.device_count())]
+        except Exception:
+            p2p = None
         sharded_info = {"ranks_seen": int(round(float(tot[1]))), "rows_per_rank": ny_grid // world, "halo_exchanges": P["sharding"].exchanges,
+                        "peer_map": getattr(P["ps"].slab_comm, "peer_map", None),
+                        "hop_us_matrix": hop, "hop_us_matrix_error": hop_err,
+                        "hop_us": {"what": "one-way microseconds (half a round trip of one tagged 8-byte word through the peer-mapped mailboxes), "
+                                           "rank a -> rank b; diagonal: a rank's own mailbox",
+                                   "ring_neighbours_max": max(ring) if ring else None, "all_pairs_max": max(off_diag) if off_diag else None,
+                                   "all_pairs_min": min(off_diag) if off_diag else None,
+                                   "read_against": "slab_kernel_loopback.latency_sweep of the N = 1 line: 0.75 is lost at ~1.9 us (2048^2) "
+                                                   "/ ~1.7 us (4096 x 512) of hop BEYOND the ring-of-one figure"},
+                        "devices_visible": torch.cuda.device_count(), "p2p_access_matrix": p2p,
+                        "env": {k: os.environ.get(k) for k in ("HSA_ENABLE_IPC_MODE_LEGACY", "PISO_PEER_MAP", "NCCL_DEBUG", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES")},
                         "max_memory_allocated_bytes_rank0": int(torch.cuda.max_memory_allocated(device)),
                         "transport": st_["transport"],
                         "persistent_slab_iterations": st_["persistent_iterations"], "persistent_fallbacks": st_["persistent_fallbacks"],

@@ -655,9 +655,18 @@ int piso_comm_destroy(void* comm) {
     if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
   } else {
     (void)hipDeviceSynchronize();
-    for (int r = 0; r < c->world; ++r)
-      if (r != c->rank && c->mbox[r]) (void)hipIpcCloseMemHandle(c->mbox[r]);
-    if (c->mbox[c->rank]) (void)hipFree(c->mbox[c->rank]);
+    if (c->vmm) {
+      for (int r = 0; r < c->world; ++r) {
+        if (!c->mbox[r]) continue;
+        (void)hipMemUnmap(c->mbox[r], c->vmm_bytes);
+        (void)hipMemAddressFree(c->mbox[r], c->vmm_bytes);
+        if (c->vmm_handle[r]) (void)hipMemRelease(c->vmm_handle[r]);
+      }
+    } else {
+      for (int r = 0; r < c->world; ++r)
+        if (r != c->rank && c->mbox[r]) (void)hipIpcCloseMemHandle(c->mbox[r]);
+      if (c->mbox[c->rank]) (void)hipFree(c->mbox[c->rank]);
+    }
     if (c->err) (void)hipFree(c->err);
   }
   delete c;
@@ -704,6 +713,113 @@ int piso_comm_peer_connect(void* comm, const void* ipc_handles64_all_ranks) {
     c->mbox[r] = static_cast<char*>(p);
   }
   c->connected = true;
+  return PISO_OK;
+}
+
+// ---- the same mailboxes through the virtual-memory API, for nodes whose driver refuses hipIpcGetMemHandle across ranks: the allocation
+// is created exportable (hipMemCreate, uncached type), exported as a POSIX file descriptor, handed to the other ranks by the caller
+// (a Unix socket with SCM_RIGHTS: diffpiso/distributed.py) and imported + mapped there.  Everything else of the transport is unchanged.
+static int vmm_map(PisoComm* c, int r, hipMemGenericAllocationHandle_t h, int dev) {
+  void* p = nullptr;
+  hipError_t e = hipMemAddressReserve(&p, c->vmm_bytes, 0, nullptr, 0);
+  if (e != hipSuccess) { set_error("hipMemAddressReserve(mailbox)", e); return PISO_ERR_HIP; }
+  e = hipMemMap(p, c->vmm_bytes, 0, h, 0);
+  if (e != hipSuccess) { set_error("hipMemMap(mailbox)", e); (void)hipMemAddressFree(p, c->vmm_bytes); return PISO_ERR_HIP; }
+  hipMemAccessDesc acc{};
+  acc.location.type = hipMemLocationTypeDevice;
+  acc.location.id = dev;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  e = hipMemSetAccess(p, c->vmm_bytes, &acc, 1);
+  if (e != hipSuccess) { set_error("hipMemSetAccess(mailbox)", e); (void)hipMemUnmap(p, c->vmm_bytes); (void)hipMemAddressFree(p, c->vmm_bytes); return PISO_ERR_HIP; }
+  c->mbox[r] = static_cast<char*>(p);
+  c->vmm_handle[r] = h;
+  return PISO_OK;
+}
+
+int piso_comm_peer_create_fd(int rank, int world, int row_capacity, void** comm_out, int* fd_out) {
+  if (!comm_out || !fd_out || world < 1 || world > kMaxRanks || rank < 0 || rank >= world || row_capacity < 1) {
+    set_error_msg("piso_comm_peer_create_fd: invalid argument (at most 8 ranks: the GPUs of one node)");
+    return PISO_ERR_INVALID_ARG;
+  }
+  int dev = 0;
+  PISO_HIP_CHECK(hipGetDevice(&dev));
+  PisoComm* c = new PisoComm;
+  c->rank = rank; c->world = world; c->transport = TRANSPORT_PEER; c->vmm = 1;
+  c->row_cap = align_up((size_t)row_capacity, 32);
+  c->mbox_bytes = PeerLayout::bytes(c->row_cap);
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypeUncached;               // (as hipDeviceMallocUncached: a peer's write is visible to my system-scope loads)
+  prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+  if (e != hipSuccess || gran == 0) { set_error("hipMemGetAllocationGranularity(mailbox)", e); delete c; return PISO_ERR_HIP; }
+  c->vmm_bytes = align_up(c->mbox_bytes, gran);
+  hipMemGenericAllocationHandle_t h{};
+  e = hipMemCreate(&h, c->vmm_bytes, &prop, 0);
+  if (e != hipSuccess) { set_error("hipMemCreate(mailbox, uncached, exportable)", e); delete c; return PISO_ERR_HIP; }
+  int rc = vmm_map(c, rank, h, dev);
+  if (rc != PISO_OK) { (void)hipMemRelease(h); delete c; return rc; }
+  int fd = -1;
+  e = hipMemset(c->mbox[rank], 0, c->mbox_bytes);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->err), sizeof(int));
+  if (e == hipSuccess) e = hipMemset(c->err, 0, sizeof(int));
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemExportToShareableHandle(&fd, h, hipMemHandleTypePosixFileDescriptor, 0);
+  if (e != hipSuccess) { set_error("piso_comm_peer_create_fd", e); (void)piso_comm_destroy(c); return PISO_ERR_HIP; }
+  *fd_out = fd;                                           // the caller closes it once every peer has received its copy
+  c->connected = (world == 1);
+  *comm_out = c;
+  return PISO_OK;
+}
+
+int piso_comm_peer_connect_fd(void* comm, const int* fds_all_ranks) {
+  PisoComm* c = static_cast<PisoComm*>(comm);
+  if (!c || c->transport != TRANSPORT_PEER || !c->vmm || !fds_all_ranks) { set_error_msg("piso_comm_peer_connect_fd: invalid argument"); return PISO_ERR_INVALID_ARG; }
+  int dev = 0;
+  PISO_HIP_CHECK(hipGetDevice(&dev));
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank || c->mbox[r]) continue;
+    hipMemGenericAllocationHandle_t h{};
+    // (this runtime reads the descriptor THROUGH the pointer - handing the integer over as the pointer's value, as the CUDA driver API
+    // takes it, makes it dereference address `fd`)
+    int fd = fds_all_ranks[r];
+    hipError_t e = hipMemImportFromShareableHandle(&h, static_cast<void*>(&fd), hipMemHandleTypePosixFileDescriptor);
+    if (e != hipSuccess) { set_error("hipMemImportFromShareableHandle(mailbox)", e); return PISO_ERR_HIP; }
+    const int rc = vmm_map(c, r, h, dev);
+    if (rc != PISO_OK) { (void)hipMemRelease(h); return rc; }
+  }
+  c->connected = true;
+  return PISO_OK;
+}
+
+// Round-trip time of one tagged word between ranks a and b through the mailboxes (`iters` round trips; a == b: a rank's own mailbox).
+// EVERY rank calls it with the same arguments; ranks other than a and b return at once.  us_out (host float, written on rank a only):
+// microseconds per round trip, timed with events around the initiator's kernel; the one-way hop is half of it.
+int piso_comm_pingpong(void* comm, int a, int b, int iters, float* us_out, piso_stream_t stream_) {
+  PisoComm* pc = static_cast<PisoComm*>(comm);
+  if (!pc || pc->transport != TRANSPORT_PEER || !pc->connected || a < 0 || b < 0 || a >= pc->world || b >= pc->world || iters < 1) {
+    set_error_msg("piso_comm_pingpong: needs a connected peer communicator and two of its ranks");
+    return PISO_ERR_INVALID_ARG;
+  }
+  const unsigned seq0 = pc->seq_pp + 1;
+  pc->seq_pp += (unsigned)iters + 1;                      // (advances identically on every rank: all of them make every call)
+  if (pc->rank != a && pc->rank != b) return PISO_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const PeerView pv = make_view(pc, true);
+  hipEvent_t e0, e1;
+  PISO_HIP_CHECK(hipEventCreate(&e0));
+  PISO_HIP_CHECK(hipEventCreate(&e1));
+  PISO_HIP_CHECK(hipEventRecord(e0, stream));
+  peer_pingpong<<<1, 64, 0, stream>>>(pv, a, b, iters, seq0, pc->err);
+  PISO_HIP_CHECK(hipEventRecord(e1, stream));
+  PISO_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0;
+  PISO_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (us_out && pc->rank == a) *us_out = 1e3f * ms / (float)iters;
+  PISO_LAUNCH_CHECK();
   return PISO_OK;
 }
 

@@ -29,7 +29,9 @@ struct PeerLayout {
   static constexpr size_t ex_flag(int parity, int side) { return (size_t)2 * kMaxRanks * kRecBytes + ((size_t)parity * 2 + side) * 128; }
   // persistent kernel: the records of the XCD leaders of EVERY rank (round 5: the leaders store straight into the peers' mailboxes -
   // no "GPU total" level between the chip's exchange and the node's), [2 parities][kMaxRanks][kPeerXcds] records of 128 bytes
-  static constexpr size_t kXcdRecs = (size_t)2 * kMaxRanks * kRecBytes + 4 * 128;
+  // two words for the ping-pong of piso_comm_pingpong: [0] where the initiator receives, [1] where the responder receives
+  static constexpr size_t pp_flag(int which) { return (size_t)2 * kMaxRanks * kRecBytes + (4 + (size_t)which) * 128; }
+  static constexpr size_t kXcdRecs = (size_t)2 * kMaxRanks * kRecBytes + 6 * 128;
   static constexpr size_t xcd_rec(int parity, int src, int xcd) { return kXcdRecs + (((size_t)parity * kMaxRanks + src) * kPeerXcds + xcd) * kRecBytes; }
   static constexpr size_t kXcdRecBytes = (size_t)2 * kMaxRanks * kPeerXcds * kRecBytes;
   static constexpr size_t kRows = kXcdRecs + kXcdRecBytes;
@@ -96,6 +98,28 @@ __global__ void peer_agree_on_error(PeerView pv, int* err, unsigned seq) {
   bool good = true;
   const double acc = peer_wave_sum(pv, lane < 2 ? (double)*err : 0.0, 2, 0, seq, &good);
   if (lane == 0 && (!good || acc != 0.0)) *err = 1;
+}
+
+// Mailbox ping-pong between ranks a (initiator) and b (responder): `iters` round trips of one tagged 8-byte word, written straight into
+// the other rank's mailbox and polled locally - the hop every exchange of the slab solvers pays (bench.py: sharded.hop_us_matrix).
+// a == b: the rank talks to its own mailbox (the cost of the uncached access path without a link).  One thread.
+template <int kUnused = 0>
+__global__ void peer_pingpong(PeerView pv, int a, int b, int iters, unsigned seq0, int* err) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const bool init = pv.rank == a;
+  const int other = init ? b : a;
+  const peer_u64* mine = reinterpret_cast<const peer_u64*>(pv.mbox[pv.rank] + PeerLayout::pp_flag(init ? 0 : 1));
+  peer_u64* theirs = reinterpret_cast<peer_u64*>(pv.mbox[other] + PeerLayout::pp_flag(init ? 1 : 0));
+  if (a == b) theirs = reinterpret_cast<peer_u64*>(pv.mbox[pv.rank] + PeerLayout::pp_flag(0));     // (ring of one: my own word, there and back)
+  for (int i = 0; i < iters; ++i) {
+    const peer_u64 tag = (peer_u64)(seq0 + (unsigned)i);
+    if (init) peer_store(theirs, tag);
+    unsigned spins = 0;
+    while (peer_load(mine) != tag) {
+      if (++spins > kPeerSpinLimit) { *err = 1; return; }
+    }
+    if (!init) peer_store(theirs, tag);
+  }
 }
 
 // Segments of a globally indexed vector that cross a slab edge (element offsets into the vector; at most 3 segments per message)

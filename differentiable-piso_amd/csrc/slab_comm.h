@@ -15,6 +15,12 @@ struct PisoComm {
   char* mbox[kMaxRanks] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool connected = false;
   size_t row_cap = 0, mbox_bytes = 0;
+  // how the mailboxes were mapped: 0 = hipIpc handles (piso_comm_peer_create), 1 = virtual-memory allocations shared as POSIX file
+  // descriptors (piso_comm_peer_create_fd: hipMemCreate / hipMemExportToShareableHandle / hipMemImportFromShareableHandle)
+  int vmm = 0;
+  hipMemGenericAllocationHandle_t vmm_handle[kMaxRanks] = {};
+  size_t vmm_bytes = 0;
+  unsigned seq_pp = 0;                // ping-pong tags (piso_comm_pingpong)
   unsigned seq_ar = 0, seq_ex = 0;    // sequence numbers of the host-level collectives (advance identically on every rank)
   unsigned launches = 0;              // persistent slab launches so far: the high half of their exchange tags
   int* err = nullptr;                 // device flag: a wait on a peer gave up

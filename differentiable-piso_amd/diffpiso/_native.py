@@ -108,6 +108,12 @@ lib.piso_comm_peer_create.argtypes = [_i, _i, _i, C.POINTER(_vp), _vp]
 lib.piso_comm_peer_create.restype = _i
 lib.piso_comm_peer_connect.argtypes = [_vp, _vp]
 lib.piso_comm_peer_connect.restype = _i
+lib.piso_comm_peer_create_fd.argtypes = [_i, _i, _i, C.POINTER(_vp), _ip]
+lib.piso_comm_peer_create_fd.restype = _i
+lib.piso_comm_peer_connect_fd.argtypes = [_vp, _ip]
+lib.piso_comm_peer_connect_fd.restype = _i
+lib.piso_comm_pingpong.argtypes = [_vp, _i, _i, _i, C.POINTER(C.c_float), _vp]
+lib.piso_comm_pingpong.restype = _i
 lib.piso_comm_stats.argtypes = [_vp, C.POINTER(C.c_longlong)]
 lib.piso_comm_stats.restype = _i
 

@@ -61,6 +61,52 @@ def all_gather_bytes(payload, rank, world, device):
     return b"".join(bytes(t.cpu().tolist()) for t in parts)
 
 
+def exchange_fds(my_fd, rank, world, device, timeout_s=60.0):
+    """Every rank hands a duplicate of its file descriptor to every other rank: a Unix-domain socket per rank (abstract namespace, name
+    agreed through torch.distributed), descriptors as SCM_RIGHTS ancillary data.  Returns ([fd received from rank r, -1 for myself], None)
+    or ([...], error text).  The received descriptors belong to the caller (close them after the import)."""
+    import os
+    import socket
+    import threading
+    got = [-1] * world
+    if world == 1:
+        return got, None
+    name = ("\0piso_fd_%d_%s" % (rank, os.urandom(8).hex())).encode()
+    srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    err = []
+    try:
+        srv.bind(name)
+        srv.listen(world)
+        srv.settimeout(timeout_s)
+
+        def serve():
+            try:
+                for _ in range(world - 1):
+                    conn, _addr = srv.accept()
+                    with conn:
+                        socket.send_fds(conn, [b"fd"], [my_fd])
+            except Exception as e:       # noqa: BLE001  (reported below, on every rank)
+                err.append("serving: %r" % (e,))
+        th = threading.Thread(target=serve, daemon=True)
+        th.start()
+        names = all_gather_bytes(name.ljust(64, b"\0"), rank, world, device)     # (after listen(): a connect cannot come too early)
+        for r in range(world):
+            if r == rank:
+                continue
+            try:
+                with socket.socket(socket.AF_UNIX, socket.SOCK_STREAM) as c:
+                    c.settimeout(timeout_s)
+                    c.connect(b"\0" + names[64 * r + 1:64 * (r + 1)].rstrip(b"\0"))
+                    _msg, fds, _flags, _addr = socket.recv_fds(c, 16, 1)
+                    got[r] = fds[0]
+            except Exception as e:       # noqa: BLE001
+                err.append("receiving from rank %d: %r" % (r, e))
+        th.join(timeout_s)
+    finally:
+        srv.close()
+    return got, ("; ".join(err) if err else None)
+
+
 def max_over_ranks(value, device):
     """The bench contract's timing rule: every rank reports the slowest rank's time."""
     import torch.distributed as dist
@@ -86,35 +132,23 @@ class SlabCommunicator(object):
         self.handle = None
         handle = C.c_void_p()
         if transport == "peer":
-            # Setting the transport up is a collective: a rank where a step fails (hipIpc handles or peer access refused by the
-            # environment) still takes part in the exchanges below, and EVERY rank raises - nobody is left waiting for a peer that gave up.
-            mine = (C.c_ubyte * 64)()
-            failure = None
-            with torch.cuda.device(device):
-                import os
-                if os.environ.get("PISO_TEST_REFUSE_PEER", "0") == "1" and rank == world - 1:      # test knob: ONE rank's environment says no
-                    failure = "piso_comm_peer_create: refused (PISO_TEST_REFUSE_PEER)"
-                else:
-                    status = N.lib.piso_comm_peer_create(rank, world, int(row_capacity), C.byref(handle), mine)
-                    if status != 0:
-                        failure = "piso_comm_peer_create failed with status %d: %s" % (status, N.lib.piso_last_error_string().decode())
-                    else:
-                        self.handle = handle
-                everybody = all_gather_bytes(bytes(mine) + bytes([1 if failure else 0]), rank, world, device)
-                failed = [r for r in range(world) if everybody[65 * r + 64]]
-                if not failed:
-                    raw = (C.c_ubyte * (64 * world)).from_buffer_copy(b"".join(everybody[65 * r:65 * r + 64] for r in range(world)))
-                    status = N.lib.piso_comm_peer_connect(handle, raw)
-                    if status != 0:
-                        failure = "piso_comm_peer_connect failed with status %d: %s" % (status, N.lib.piso_last_error_string().decode())
-                    # (also the barrier: nobody writes into a mailbox that is not mapped everywhere yet)
-                    if max_over_ranks(1.0 if failure else 0.0, device) > 0:
-                        failed = [-1]
-            if failed:
-                if self.handle:                     # (no barrier here: the ranks whose mailbox never existed would not join it)
-                    N.lib.piso_comm_destroy(self.handle)
-                    self.handle = None
-                raise N.PisoNativeError(failure or "the peer transport could not be set up on rank(s) %s" % (failed,))
+            # Two ways to map the mailboxes into every rank, tried in this order (PISO_PEER_MAP = "ipc" / "fd" picks one):
+            #   "ipc"  hipIpcGetMemHandle / hipIpcOpenMemHandle (64-byte handles through torch.distributed)
+            #   "fd"   exportable virtual-memory allocations, their POSIX file descriptors handed over Unix sockets (SCM_RIGHTS) - for
+            #          nodes whose driver refuses hipIpc handles across ranks
+            # Setting the transport up is a collective: a rank where a step fails still takes part in the exchanges, and EVERY rank
+            # moves on to the next mechanism (or raises) together - nobody is left waiting for a peer that gave up.
+            import os
+            want = os.environ.get("PISO_PEER_MAP", "auto")
+            self.peer_map, reasons = None, []
+            for how in (("ipc", "fd") if want == "auto" else (want,)):
+                failure = self._peer_setup(how, rank, world, device, int(row_capacity))
+                if failure is None:
+                    self.peer_map = how
+                    break
+                reasons.append("%s: %s" % (how, failure))
+            if self.peer_map is None:
+                raise N.PisoNativeError("the peer transport could not be set up (" + "; ".join(reasons) + ")")
         elif transport == "rccl":
             uid = exchange_unique_id(rank, world, device)
             raw = (C.c_ubyte * 128)(*[int(v) for v in uid.tolist()])
@@ -122,6 +156,85 @@ class SlabCommunicator(object):
             self.handle = handle
         else:
             raise ValueError("transport must be 'peer' or 'rccl'")
+
+    def _peer_setup(self, how, rank, world, device, row_capacity):
+        """One attempt at mapping the mailboxes (collective).  Returns None on success (self.handle set), else what failed - the same
+        verdict on every rank."""
+        import os
+        handle = C.c_void_p()
+        failure, created = None, False
+        mine64, my_fd = (C.c_ubyte * 64)(), C.c_int(-1)
+        with torch.cuda.device(device):
+            if os.environ.get("PISO_TEST_REFUSE_PEER", "0") in ("1", how) and rank == world - 1:      # test knob: ONE rank's environment says no
+                failure = "refused (PISO_TEST_REFUSE_PEER)"
+            else:
+                if how == "ipc":
+                    status = N.lib.piso_comm_peer_create(rank, world, row_capacity, C.byref(handle), mine64)
+                else:
+                    status = N.lib.piso_comm_peer_create_fd(rank, world, row_capacity, C.byref(handle), C.byref(my_fd))
+                if status != 0:
+                    failure = "create failed with status %d: %s" % (status, N.lib.piso_last_error_string().decode())
+                else:
+                    created = True
+            try:
+                everybody = all_gather_bytes(bytes(mine64) + bytes([1 if failure else 0]), rank, world, device)
+                failed = [r for r in range(world) if everybody[65 * r + 64]]
+                if not failed:
+                    if how == "ipc":
+                        raw = (C.c_ubyte * (64 * world)).from_buffer_copy(b"".join(everybody[65 * r:65 * r + 64] for r in range(world)))
+                        status = N.lib.piso_comm_peer_connect(handle, raw)
+                    else:
+                        fds, err = exchange_fds(my_fd.value, rank, world, device)
+                        try:
+                            if err is None:
+                                status = N.lib.piso_comm_peer_connect_fd(handle, (C.c_int * world)(*fds))
+                        finally:
+                            for f in fds:
+                                if f >= 0:
+                                    os.close(f)
+                        if err is not None:
+                            status, failure = -1, "passing the file descriptors failed: " + err
+                    if status != 0 and failure is None:
+                        failure = "connect failed with status %d: %s" % (status, N.lib.piso_last_error_string().decode())
+                    # (also the barrier: nobody writes into a mailbox that is not mapped everywhere yet)
+                    if max_over_ranks(1.0 if failure else 0.0, device) > 0:
+                        failed = [-1]
+            finally:
+                if my_fd.value >= 0:
+                    os.close(my_fd.value)
+        if failed:
+            if created:                             # (no barrier here: the ranks whose mailbox never existed would not join it)
+                N.lib.piso_comm_destroy(handle)
+            return failure or "failed on rank(s) %s" % (failed,)
+        self.handle = handle
+        return None
+
+    def pingpong_us(self, a, b, iters=2000):
+        """Round-trip microseconds of one tagged word between ranks a and b through the mailboxes (collective: every rank calls it;
+        the value is returned on rank a, None elsewhere).  a == b: a rank's own mailbox."""
+        us = C.c_float(0.0)
+        N.check(N.lib.piso_comm_pingpong(self.handle, int(a), int(b), int(iters), C.byref(us), N.stream_ptr()), "piso_comm_pingpong")
+        return float(us.value) if self.rank == a else None
+
+    def hop_matrix(self, iters=2000):
+        """hop[a][b] = one-way microseconds (half a round trip) between every pair of ranks, measured pair by pair with everybody else
+        idle; the diagonal is a rank's own mailbox.  Collective; every rank returns the full matrix."""
+        import torch.distributed as dist
+        m = torch.zeros((self.world, self.world), dtype=torch.float64)
+        for a in range(self.world):
+            for b in range(a, self.world):
+                if self.world > 1:
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                us = self.pingpong_us(a, b, iters)
+                if us is not None:
+                    m[a, b] = m[b, a] = 0.5 * us
+        if self.world > 1:
+            dev = _comm_device(self.device)
+            md = m.to(dev)
+            dist.all_reduce(md)                      # (every entry was written by exactly one rank)
+            m = md.cpu()
+        return [[float(v) for v in row] for row in m]
 
     def stats(self):
         out = (C.c_longlong * 6)()

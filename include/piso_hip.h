@@ -304,8 +304,9 @@ int piso_leaky_relu_backward(const float* grad_out, const float* out, float* gra
  * Slab-decomposed pressure CG (no counterpart in the reference, which is single-GPU).
  * The grid is cut along y into `world` slabs of ny_local rows, one rank (process) per GPU.  Two transports:
  *
- *  PEER (piso_comm_peer_create / _connect; the GPUs of one node, world <= 8): every rank owns a peer-mapped MAILBOX (uncached
- *  device memory exported with hipIpcGetMemHandle and mapped by all ranks).  Step 1 creates the mailbox and returns its 64-byte
+ *  PEER (piso_comm_peer_create / _connect, or piso_comm_peer_create_fd / _connect_fd; the GPUs of one node, world <= 8): every rank
+ *  owns a peer-mapped MAILBOX (uncached device memory exported with hipIpcGetMemHandle - or as a POSIX file descriptor of a
+ *  virtual-memory allocation - and mapped by all ranks).  Step 1 creates the mailbox and returns its 64-byte
  *  handle; the caller distributes the handles of all ranks by any means (torch.distributed all_gather, MPI, a pipe); step 2 maps
  *  them.  Reductions and halo rows are written by kernels straight into the consumers' mailboxes (tagged words / release-acquire
  *  at system scope), never through the host.  The NORMAL iterations run inside the persistent kernel: the slab's r, p, x stay on
@@ -331,6 +332,15 @@ int piso_leaky_relu_backward(const float* grad_out, const float* out, float* gra
  * ------------------------------------------------------------------------------------------------------------- */
 int piso_comm_peer_create(int rank, int world, int row_capacity, void** comm_out, void* ipc_handle64_out);
 int piso_comm_peer_connect(void* comm, const void* ipc_handles64_all_ranks);
+/* The same mailboxes for nodes that refuse hipIpc handles across ranks: exportable virtual-memory allocations (hipMemCreate, uncached
+ * type) shared as POSIX file descriptors.  Step 1 creates and maps the rank's mailbox and returns a file descriptor; the caller hands a
+ * copy to every other rank (a Unix socket with SCM_RIGHTS; diffpiso/distributed.py) and closes its own; step 2 takes the descriptors
+ * received from the other ranks (fds_all_ranks[r] for r != rank), imports and maps them.  Everything else is the peer transport above. */
+int piso_comm_peer_create_fd(int rank, int world, int row_capacity, void** comm_out, int* fd_out);
+int piso_comm_peer_connect_fd(void* comm, const int* fds_all_ranks);
+/* Mailbox ping-pong: `iters` round trips of one tagged 8-byte word between ranks a (initiator) and b; a == b: a rank's own mailbox.
+ * Called by EVERY rank with the same arguments (others return at once); us_per_round_trip_out is written on rank a. */
+int piso_comm_pingpong(void* comm, int a, int b, int iters, float* us_per_round_trip_out, piso_stream_t stream);
 int piso_comm_stats(void* comm, long long* out6);
 /* The slab-decomposed STEP (new design): the *_slab twins of piso_assemble_csr, piso_pad_velocity, piso_a0_vfirst,
  * piso_face_forward / _backward, piso_divergence(_adjoint), piso_h_contribution(_adjoint), piso_laplace_matrix_* and piso_csr_matvec_f32

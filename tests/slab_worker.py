@@ -59,6 +59,8 @@ def main():
                            "converged_diff": float((xa[own] - xb).abs().max() / xa.abs().max())}
         out.update(runs)
         out["stats"] = comm.stats()
+        out["peer_map"] = comm.peer_map                # how the mailboxes were mapped: "ipc" (hipIpc handles) or "fd" (shared file descriptors)
+        out["hop_us_matrix"] = comm.hop_matrix(iters=500)
         # timing of the persistent slab iteration (all ranks together)
         N.set_option("cg_persist", -1)
         N.set_option("cg_segment", -1)

@@ -47,6 +47,21 @@ def _worker(rank, world, port, q):
             cover[a0:a1] += 1
             cover[b0:b1] += 1
         assert bool((cover == 1).all())
+        # the second way to map the mailboxes hands FILE DESCRIPTORS from rank to rank (Unix sockets, SCM_RIGHTS): every rank ends up
+        # with a descriptor of the other rank's file - here an anonymous temporary file that names its owner
+        import tempfile
+        from diffpiso.distributed import exchange_fds
+        with tempfile.TemporaryFile() as f:
+            f.write(b"mailbox of rank %d" % rank)
+            f.flush()
+            fds, err = exchange_fds(f.fileno(), rank, world, torch.device("cpu"))
+            assert err is None, err
+            assert fds[rank] == -1
+            for r, fd in enumerate(fds):
+                if r != rank:
+                    assert fd >= 0 and fd != f.fileno()
+                    assert os.pread(fd, 64, 0) == b"mailbox of rank %d" % r
+                    os.close(fd)
         uid = exchange_unique_id(rank, world, torch.device("cpu"),
                                  make_id=lambda: torch.arange(128, dtype=torch.uint8) * 3 + 1)
         rows = slab_rows(rank, world, 64)

@@ -25,12 +25,12 @@ def _free_parent_gpu_memory():
 
 
 
-def run_ranks(world, nx, ny, walls, timeout=600, worker="slab_worker.py", extra=None):
+def run_ranks(world, nx, ny, walls, timeout=600, worker="slab_worker.py", extra=None, env_extra=None):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     _free_parent_gpu_memory()
     tail = [str(nx), str(ny), str(int(walls)), "1"] if extra is None else extra
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker), str(r), str(world), str(port)] + tail,
@@ -49,7 +49,8 @@ def run_ranks(world, nx, ny, walls, timeout=600, worker="slab_worker.py", extra=
         res.append(json.loads(lines[-1][len("SLAB_WORKER "):]))
     # a box that cannot map device memory across processes (hipIpc refused) cannot run these tests at all: skipped, not failed
     for r in res:
-        if not r.get("ok") and ("piso_comm_peer_create" in r.get("error", "") or "piso_comm_peer_connect" in r.get("error", "")):
+        if not r.get("ok") and ("piso_comm_peer_create" in r.get("error", "") or "piso_comm_peer_connect" in r.get("error", "")
+                                or "the peer transport could not be set up" in r.get("error", "")):
             pytest.skip("peer transport unavailable here: %s" % r["error"][:300])
     return sorted(res, key=lambda r: r["rank"])
 
@@ -76,6 +77,29 @@ def test_slab_cg_over_processes(world, nx, ny, walls):
         assert r["stats"]["solves_verified"] >= 5 and r["stats"]["verification_failures"] == 0, r["stats"]   # r == b - A^ x checked per solve
     # every rank took the same decisions
     assert len({tuple(r["persistent"]["converged_its"]) for r in res}) == 1
+
+
+@pytest.mark.parametrize("env,expect", [({"PISO_PEER_MAP": "fd"}, "fd"),                       # the second mechanism on its own
+                                        ({"PISO_TEST_REFUSE_PEER": "ipc"}, "fd"),              # ONE rank's hipIpc attempt fails: everybody moves on to it
+                                        ({}, "ipc")])
+def test_slab_cg_over_processes_mailboxes_mapped_through_file_descriptors(env, expect):
+    """The peer transport's SECOND way to map the mailboxes (for nodes that refuse hipIpc handles across ranks): exportable
+    virtual-memory allocations (hipMemCreate, uncached), shared as POSIX file descriptors over Unix sockets, imported and mapped by the
+    other rank - then the very same kernels: persistent slab CG, verified solves, and the mailbox ping-pong of the hop matrix."""
+    res = run_ranks(2, 1024, 1024, False, env_extra=env)
+    for r in res:
+        assert r["ok"], r
+        assert r["peer_map"] == expect, r["peer_map"]
+        for label in ("persistent", "two_kernel"):
+            assert max(r[label]["fixed_run_diffs"]) <= 2e-10, (label, r[label])
+        assert r["stats"]["transport"] == "peer" and r["stats"]["persistent_iterations"] > 150 and r["stats"]["persistent_fallbacks"] == 0
+        assert r["stats"]["verification_failures"] == 0
+        m = r["hop_us_matrix"]
+        print(expect, "hop matrix [us, one way]:", m)
+        assert len(m) == 2 and all(len(row) == 2 for row in m)
+        assert all(0.05 < m[a][b] < 200.0 for a in range(2) for b in range(2)), m       # measured, symmetric by construction
+        assert m[0][1] == m[1][0]
+    assert res[0]["hop_us_matrix"] == res[1]["hop_us_matrix"]                              # every rank holds the same matrix
 
 
 def test_slab_cg_config5_slab_shape_four_row_regions_over_two_processes():
@@ -139,6 +163,10 @@ def test_bench_two_ranks_on_one_gpu():
     # rank; the replicas figure stands beside it
     assert d.get("sharded_run") is None, d.get("sharded_run")
     assert d["sharded"]["ranks_seen"] == 2 and d["sharded"]["halo_exchanges"] > 0 and d["sharded"]["verification_failures"] == 0
+    # the first record from a multi-GPU node diagnoses itself: how the mailboxes were mapped and the measured hop between every pair
+    assert d["sharded"]["peer_map"] in ("ipc", "fd") and d["sharded"]["hop_us_matrix_error"] is None
+    hop = d["sharded"]["hop_us_matrix"]
+    assert len(hop) == 2 and 0.05 < hop[0][1] == hop[1][0] < 200 and d["sharded"]["hop_us"]["ring_neighbours_max"] == hop[0][1]
     assert d["config"]["grid"] == [2048, 1024] and d["replicas"]["value"] > 0 and d["parallel_efficiency_vs_replicas"] > 0
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     chk = d["slab_cg_self_check"]
@@ -213,7 +241,8 @@ def test_bench_reports_a_refused_peer_transport_instead_of_failing():
     d = _bench({"PISO_BENCH_SHARE_GPU": "1", "PISO_BENCH_SLAB_CHECK": "0", "PISO_TEST_REFUSE_PEER": "1"},
                ["--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "256", "--no-cpu-baseline", "--no-extras", "--max-iterations", "100"], 2)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d.get("replicas_only") is True
-    assert "could not be set up on rank(s) [1]" in d["sharded_run"]["skipped"] and "sharded" not in d
+    # (both mapping mechanisms were tried - hipIpc handles, then shared file descriptors - and the refusing rank is named for each)
+    assert "ipc: failed on rank(s) [1]" in d["sharded_run"]["skipped"] and "fd: failed on rank(s) [1]" in d["sharded_run"]["skipped"] and "sharded" not in d
 
 
 def test_decomposed_step_two_ranks_matches_one_gpu():
