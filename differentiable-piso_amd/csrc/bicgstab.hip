@@ -1391,6 +1391,7 @@ int piso_multi_bicgstab_ilu_f32(const float* csr_val, const int* csr_rowptr, con
                                 const float* x0, float* x_out, int nx, int ny, float tol, int max_it, int transpose,
                                 int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
                                 size_t workspace_bytes, piso_stream_t stream) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   return bi_solve<float>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning,
                          iterations_out, workspace, workspace_bytes, stream);
 }
@@ -1399,6 +1400,7 @@ int piso_multi_bicgstab_ilu_f64(const double* csr_val, const int* csr_rowptr, co
                                 const double* x0, double* x_out, int nx, int ny, float tol, int max_it, int transpose,
                                 int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
                                 size_t workspace_bytes, piso_stream_t stream) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   return bi_solve<double>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning,
                           iterations_out, workspace, workspace_bytes, stream);
 }
@@ -1407,6 +1409,7 @@ int piso_multi_bicgstab_ilu_slab_f32(void* comm, const float* csr_val, const int
                                      const float* x0, float* x_out, int nx, int ny, float tol, int max_it, int transpose,
                                      int band_rows, uint8_t* warning, int* iterations_out, void* workspace, size_t workspace_bytes,
                                      piso_stream_t stream) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   if (!comm) { set_error_msg("piso_multi_bicgstab_ilu_slab_f32: NULL communicator"); return PISO_ERR_INVALID_ARG; }
   return bi_solve<float>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning, iterations_out,
                          workspace, workspace_bytes, stream, static_cast<PisoComm*>(comm));
@@ -1416,6 +1419,7 @@ int piso_multi_bicgstab_ilu_slab_f64(void* comm, const double* csr_val, const in
                                      const double* x0, double* x_out, int nx, int ny, float tol, int max_it, int transpose,
                                      int band_rows, uint8_t* warning, int* iterations_out, void* workspace, size_t workspace_bytes,
                                      piso_stream_t stream) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   if (!comm) { set_error_msg("piso_multi_bicgstab_ilu_slab_f64: NULL communicator"); return PISO_ERR_INVALID_ARG; }
   return bi_solve<double>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning, iterations_out,
                           workspace, workspace_bytes, stream, static_cast<PisoComm*>(comm));
@@ -1429,6 +1433,7 @@ int piso_multi_bicgstab_ilu_slab_local_f32(void* comm, const float* csr_val, con
                                            const float* x0, float* x_out, int nx, int ny, int periodic_x, int periodic_y, float tol, int max_it,
                                            int transpose, int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
                                            size_t workspace_bytes, piso_stream_t stream, const piso_slab_t* slab) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   if (!comm || !slab) { set_error_msg("piso_multi_bicgstab_ilu_slab_local_f32: NULL communicator / slab"); return PISO_ERR_INVALID_ARG; }
   return bi_solve<float>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning, iterations_out,
                          workspace, workspace_bytes, stream, static_cast<PisoComm*>(comm), slab, periodic_x ? 1 : 0, periodic_y ? 1 : 0);
@@ -1437,6 +1442,7 @@ int piso_multi_bicgstab_ilu_slab_local_f64(void* comm, const double* csr_val, co
                                            const double* x0, double* x_out, int nx, int ny, int periodic_x, int periodic_y, float tol, int max_it,
                                            int transpose, int band_rows, uint8_t* warning, int* iterations_out, void* workspace,
                                            size_t workspace_bytes, piso_stream_t stream, const piso_slab_t* slab) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   if (!comm || !slab) { set_error_msg("piso_multi_bicgstab_ilu_slab_local_f64: NULL communicator / slab"); return PISO_ERR_INVALID_ARG; }
   return bi_solve<double>(csr_val, csr_rowptr, csr_col, rhs, x0, x_out, nx, ny, tol, max_it, transpose, band_rows, warning, iterations_out,
                           workspace, workspace_bytes, stream, static_cast<PisoComm*>(comm), slab, periodic_x ? 1 : 0, periodic_y ? 1 : 0);

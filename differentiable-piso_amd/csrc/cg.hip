@@ -681,6 +681,7 @@ size_t piso_cg_workspace_bytes(int nx, int ny, int elem_size) {
 int piso_cg_solve_f64(int nx, int ny, int periodic_x, int periodic_y, const double* laplace, const double* divergence,
                       double* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
                       int* iterations_out, void* workspace, size_t workspace_bytes, piso_stream_t stream) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   return cg_solve<double>(nx, ny, periodic_x, periodic_y, laplace, divergence, x_out, accuracy, max_iterations,
                           rank_deficient, residual_reset, 0, iterations_out, nullptr, workspace, workspace_bytes, stream);
 }
@@ -688,6 +689,7 @@ int piso_cg_solve_f64(int nx, int ny, int periodic_x, int periodic_y, const doub
 int piso_cg_solve_f32(int nx, int ny, int periodic_x, int periodic_y, const float* laplace, const float* divergence,
                       float* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
                       int* iterations_out, void* workspace, size_t workspace_bytes, piso_stream_t stream) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   return cg_solve<float>(nx, ny, periodic_x, periodic_y, laplace, divergence, x_out, accuracy, max_iterations,
                          rank_deficient, residual_reset, 0, iterations_out, nullptr, workspace, workspace_bytes, stream);
 }
@@ -695,6 +697,7 @@ int piso_cg_solve_f32(int nx, int ny, int periodic_x, int periodic_y, const floa
 int piso_cg_solve_async_f64(int nx, int ny, int periodic_x, int periodic_y, const double* laplace, const double* divergence,
                             double* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
                             int* iterations_dev, void* workspace, size_t workspace_bytes, piso_stream_t stream) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   if (!iterations_dev) { set_error_msg("piso_cg_solve_async: iterations_dev is NULL"); return PISO_ERR_INVALID_ARG; }
   return cg_solve<double>(nx, ny, periodic_x, periodic_y, laplace, divergence, x_out, accuracy, max_iterations,
                           rank_deficient, residual_reset, 0, nullptr, nullptr, workspace, workspace_bytes, stream, iterations_dev);
@@ -703,6 +706,7 @@ int piso_cg_solve_async_f64(int nx, int ny, int periodic_x, int periodic_y, cons
 int piso_cg_solve_async_f32(int nx, int ny, int periodic_x, int periodic_y, const float* laplace, const float* divergence,
                             float* x_out, float accuracy, int max_iterations, int rank_deficient, int residual_reset,
                             int* iterations_dev, void* workspace, size_t workspace_bytes, piso_stream_t stream) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   if (!iterations_dev) { set_error_msg("piso_cg_solve_async: iterations_dev is NULL"); return PISO_ERR_INVALID_ARG; }
   return cg_solve<float>(nx, ny, periodic_x, periodic_y, laplace, divergence, x_out, accuracy, max_iterations,
                          rank_deficient, residual_reset, 0, nullptr, nullptr, workspace, workspace_bytes, stream, iterations_dev);
@@ -711,6 +715,7 @@ int piso_cg_solve_async_f32(int nx, int ny, int periodic_x, int periodic_y, cons
 int piso_cg_fixed_iterations_f64(int nx, int ny, int periodic_x, int periodic_y, const double* laplace,
                                  const double* divergence, double* x_out, int rank_deficient, int iterations,
                                  float* kernel_ms_out, void* workspace, size_t workspace_bytes, piso_stream_t stream) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   if (iterations < 1) { set_error_msg("piso_cg_fixed_iterations: iterations < 1"); return PISO_ERR_INVALID_ARG; }
   return cg_solve<double>(nx, ny, periodic_x, periodic_y, laplace, divergence, x_out, 0.f, iterations, rank_deficient,
                           1 << 30, iterations, nullptr, kernel_ms_out, workspace, workspace_bytes, stream);

@@ -107,88 +107,31 @@ __device__ __forceinline__ F karg(unsigned off) {
   return out;
 }
 
-// coefficient rows in flight per wave (A/B builds: -DPISO_PERSIST1_DEPTH=n + scripts/build_variant.py / scripts/ab.sh).  Round 3, 16-row
-// regions at 2048^2, with the back-and-forth row order (kZigZag): 3 rows 12.5 us, 4 rows 11.8 us, 5 rows 11.5 us per iteration,
-// 6 rows spill.  (Round 2, cyclic order, before the loop was put on its VALU diet: 4 rows 17.8 us with 15 spilled VGPRs, 3 rows
-// 17.2 us, 2 rows 21.1 us; small regions 4 rows 7.05, 3 rows 8.2 us.)
+// ---- the three shape parameters an A/B build may still override (-DPISO_PERSIST1_<NAME>=n with scripts/build_variant.py); everything
+// else that used to be a compile-time switch here is folded to the variant that shipped (the measurements that decided each one
+// are in profiles/README.md, "persistent CG kernel: variants measured and dropped").
+// Coefficient rows in flight per wave of the 16-row kernel on a symmetric matrix (kDeep); every other shape: 3 / 4.  With the
+// back-and-forth row order: 3 rows 12.5 us, 4 rows 11.8 us, 5 rows 11.5 us per iteration (round 3), 6 rows spill.
 #ifndef PISO_PERSIST1_DEPTH
-#define PISO_PERSIST1_DEPTH 5                   // ... of the 16-row single-GPU kernel on a symmetric matrix (kDeep); every other shape: 3 / 4
+#define PISO_PERSIST1_DEPTH 5
 #endif
-#ifndef PISO_PERSIST1_RESIDENT
-#define PISO_PERSIST1_RESIDENT 0                // coefficient rows (of 16) that stay in registers, see kRes
-#endif
-#ifndef PISO_PERSIST1_ZIGZAG
-#define PISO_PERSIST1_ZIGZAG 1                  // the U pass walks a wave's rows downwards (see kZigZag)
-#endif
-#ifndef PISO_PERSIST1_ZIGZAG_SMALL
-#define PISO_PERSIST1_ZIGZAG_SMALL 1
-#endif
-#ifndef PISO_PERSIST1_RING_SMALL
-#define PISO_PERSIST1_RING_SMALL 1
-#endif
-#ifndef PISO_PERSIST1_ASMCNT_SLAB
-#define PISO_PERSIST1_ASMCNT_SLAB 1
-#endif
-#ifndef PISO_PERSIST1_LEAN_SLAB
-#define PISO_PERSIST1_LEAN_SLAB 1
-#endif
-#ifndef PISO_PERSIST1_ZIGZAG_SLAB
-#define PISO_PERSIST1_ZIGZAG_SLAB 1          // (round 3: off - the slab variant had no registers for the rows held across the turn)
-#endif
-#ifndef PISO_PERSIST1_RING_SLAB
-#define PISO_PERSIST1_RING_SLAB 1            // ring values through LDS broadcast reads in the slab variant as well
-#endif
-#ifndef PISO_PERSIST1_DEEP_SLAB
-#define PISO_PERSIST1_DEEP_SLAB 1            // the five-row coefficient pipeline in the slab variant as well
-#endif
-#ifndef PISO_PERSIST1_EXIT_KARGS
-#define PISO_PERSIST1_EXIT_KARGS 1            // the exit block reads its pointers again from the kernarg segment
-#endif
-#ifndef PISO_PERSIST1_POLL_DELAY
-#define PISO_PERSIST1_POLL_DELAY 24             // s_sleep units (64 cycles) between publishing a record and the first polling pass
-#endif
-#ifndef PISO_PERSIST1_HIER
-#define PISO_PERSIST1_HIER 1                    // chip-wide launches exchange through the tree workgroup -> XCD leader -> everybody (grid_exchange8_hier)
-#endif
-#ifndef PISO_PERSIST1_SH_LATE
-#define PISO_PERSIST1_SH_LATE 1
-#endif
-#ifndef PISO_PERSIST1_PARK_RING
-#define PISO_PERSIST1_PARK_RING 1
-#endif
-#ifndef PISO_PERSIST1_LOCAL_ALL
-#define PISO_PERSIST1_LOCAL_ALL 1               // XCD-local launches: every wave polls the group's records (no second barrier): grid_exchange8_local
-#endif
+// Rows of z' = L p that the U pass finds precomputed (kAhead, <= DEPTH).  Round 6 A/B on one box (2048^2, us per iteration):
+// DEPTH 5 / AHEAD 2 9.6 - 10.7 (shipped), 4 / 4 10.6 - 10.8, 5 / 3 10.2 - 11.0 (1 VGPR spilled), 5 / 4 11.1 - 11.4 (3), 5 / 5 11.8 - 12.7.
 #ifndef PISO_PERSIST1_AHEAD
-#define PISO_PERSIST1_AHEAD 2                   // rows of z' = L p that the U pass finds precomputed (see kAhead)
+#define PISO_PERSIST1_AHEAD 2
 #endif
-#ifndef PISO_PERSIST1_KEEP_Z
-#define PISO_PERSIST1_KEEP_Z 1                  // small regions: U reuses D's z' instead of computing it again (see kKeepZ)
-#endif
+// Small regions: U reuses D's z' where z' of all rows of a wave fits this many registers (kKeepZ).  64 would cover the 16-row
+// kernel: 26 - 35 VGPRs spill at any DEPTH (round 6), i.e. the registers beside r and p are what z' has no room in.
 #ifndef PISO_PERSIST1_KEEP_Z_REGS
-#define PISO_PERSIST1_KEEP_Z_REGS 32            // ... where z' of all rows of a wave fits this many registers
+#define PISO_PERSIST1_KEEP_Z_REGS 32
 #endif
-#ifndef PISO_PERSIST1_PACK
-#define PISO_PERSIST1_PACK 1                    // end cells of a region's rows published as one packed block per region (see kPack)
-#endif
-#ifndef PISO_PERSIST1_POLL_DELAY2
-#define PISO_PERSIST1_POLL_DELAY2 40            // s_sleep units in front of the first polling pass of the tree's second level (2048^2, behind the rows computed ahead: 24 -> 9.12, 32 / 40 -> 8.94 us per iteration, six processes each on one box)
-#endif
-#ifndef PISO_PERSIST1_POLL_DELAY2_NOAHEAD
-#define PISO_PERSIST1_POLL_DELAY2_NOAHEAD 8     // ... where no rows are computed ahead in front of it (small regions on mid-size grids: 24 -> 8: 4.27 -> 4.15 us at 512^2 / 1024 x 256, 0: 4.22)
-#endif
-#ifndef PISO_PERSIST1_RZ_KARG
-#define PISO_PERSIST1_RZ_KARG 1                 // the z' buffer of an iteration's parity: its address from the kernarg segment (an s_load per iteration) instead of two descriptors' bases in SGPRs across the loop
-#endif
-#ifndef PISO_PERSIST1_POLL_DELAY2_XG
-#define PISO_PERSIST1_POLL_DELAY2_XG 8          // ... of the slab instance's node level: ONE wave per rank polls there, an early pass queues in front of nobody (2048^2 in a ring of one: 40 -> 8 units 10.05 -> 9.67 us per iteration; 0 / 16 / 24: 9.67 / 9.72 / 9.78; 48 / 80: 10.2 / 11.4)
-#endif
-#ifndef PISO_PERSIST1_LOCAL_DELAY
-#define PISO_PERSIST1_LOCAL_DELAY 8             // XCD-local exchange with one working wave per SIMD: s_sleep units in front of the first polling pass
-#endif
-#ifndef PISO_PERSIST1_POLL_SLEEP
-#define PISO_PERSIST1_POLL_SLEEP 1              // s_sleep units (64 cycles) between two polling passes
-#endif
+// s_sleep units (64 cycles) of the exchanges' polling (constants, not switches):
+constexpr int kPollDelay = 24;                   // between publishing a record and the first polling pass (flat exchange)
+constexpr int kPollDelay2 = 40;                  // tree, second level, behind the rows computed ahead (2048^2: 24 -> 9.12, 32 / 40 -> 8.94 us per iteration)
+constexpr int kPollDelay2NoAhead = 8;            // ... where nothing is computed ahead (512^2 / 1024 x 256: 24 -> 8: 4.27 -> 4.15 us, 0: 4.22)
+constexpr int kPollDelay2Xg = 8;                 // ... of the slab instance's node level (ring of one, 2048^2: 40 -> 8: 10.05 -> 9.67 us)
+constexpr int kLocalDelay = 8;                   // XCD-local exchange with one working wave per SIMD
+constexpr int kPollSleep = 1;                    // between two polling passes
 constexpr int kX1Values = 8;                     // sums per exchange
 constexpr int kX1RecWords = 16;                  // 8-byte words per record: 2 per sum {32 payload bits | 32-bit epoch}
 
@@ -228,12 +171,8 @@ __device__ __forceinline__ double lanes_xor8(double v) { return dpp_move<0x128>(
 // half) of one register with the even rows (the lower half) of another - two swaps of the value with itself leave "mine" and "the
 // partner's" in two registers of EVERY lane, no trip through the LDS crossbar (ds_bpermute: ~100 cycles each in a dependent chain
 // that every wave of the chip waits for).  Both lanes of a pair add the same two numbers (a + b, b + a: the same bits), as before.
-#ifndef PISO_PERSIST1_PERMLANE_SWAP
-#define PISO_PERSIST1_PERMLANE_SWAP 1
-#endif
 template <int ROWS>
 __device__ __forceinline__ double sum_xor_rows(double v) {
-#if PISO_PERSIST1_PERMLANE_SWAP
   const unsigned long long b = (unsigned long long)__double_as_longlong(v);
   const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
   const auto r0 = ROWS == 16 ? __builtin_amdgcn_permlane16_swap(lo, lo, false, false) : __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
@@ -241,9 +180,6 @@ __device__ __forceinline__ double sum_xor_rows(double v) {
   const double x = __longlong_as_double((long long)(((unsigned long long)r1[0] << 32) | r0[0]));
   const double y = __longlong_as_double((long long)(((unsigned long long)r1[1] << 32) | r0[1]));
   return x + y;
-#else
-  return v + __shfl_xor(v, ROWS, 64);                       // (ds_bpermute_b32 x 2)
-#endif
 }
 __device__ __forceinline__ double sum_xor16(double v) { return sum_xor_rows<16>(v); }
 __device__ __forceinline__ double sum_xor32(double v) { return sum_xor_rows<32>(v); }
@@ -329,7 +265,7 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
     unsigned spins = 0;
     // a first poll that finds every record beats two passes: the records of 256 workgroups that finish their row loops together
     // need ~0.6 us to become visible; measured at 2048^2: no delay 11.7, s_sleep 16 .. 32 11.4, 48 11.7, 64 11.9 us per iteration
-    if constexpr (!LOCAL) { if (PISO_PERSIST1_POLL_DELAY > 0) __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_DELAY); }
+    if constexpr (!LOCAL) { if (kPollDelay > 0) __builtin_amdgcn_s_sleep(kPollDelay); }
     while (true) {
       bool ok = true;
 #pragma unroll
@@ -342,7 +278,7 @@ __device__ __forceinline__ bool grid_exchange8(const PersistCtl& c, T (&v)[kX1Va
       }
       if (__all(ok)) break;
       if (++spins > (1u << 22)) { good = false; break; }
-      __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_SLEEP);
+      __builtin_amdgcn_s_sleep(kPollSleep);
     }
     tsplit(2);
     // even lanes assemble their sum from their own word (low half) and the neighbour lane's (high half); records of a lane
@@ -566,7 +502,7 @@ __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[
         bad |= (((present >> (i * 4)) >> (lw >> 4)) & 1u) ? ((unsigned)(w[i] & 0xffffffffull) ^ epoch) : 0u;
       if (__all(bad == 0)) break;
       if (++spins > (1u << 22)) { mygood = false; break; }
-      __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_SLEEP);
+      __builtin_amdgcn_s_sleep(kPollSleep);
     }
     tsplit(2);
     double acc = 0;
@@ -605,7 +541,7 @@ __device__ __forceinline__ bool grid_exchange8_hier(const PersistCtl& c, T (&v)[
         for (int i = 0; i < 2; ++i) bad |= (unsigned)(w[i] & 0xffffffffull) ^ epoch;
         if (__all(bad == 0)) break;
         if (++spins > kPeerSpinLimit) { mygood = false; break; }      // (kPeerSpinLimit < spin0)
-        __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_SLEEP);
+        __builtin_amdgcn_s_sleep(kPollSleep);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -683,7 +619,7 @@ __device__ __forceinline__ bool grid_exchange8_local(const PersistCtl& c, T (&v)
     // (one working wave per SIMD - c.waves = 4: the record needs ~0.2 us to arrive and a first pass that misses it queues in front
     // of the one that would find it: 256^2 3.33 -> 3.15 us per iteration with 8 units, 4: 3.21, 12: 3.23; with two working waves per
     // SIMD - 512 x 256 - any delay loses: 3.84 / 3.83 / 3.92 / 4.00 / 4.10 with 0 / 4 / 8 / 12 / 16)
-    if (PISO_PERSIST1_LOCAL_DELAY > 0 && c.waves < kPersistWaves) __builtin_amdgcn_s_sleep(PISO_PERSIST1_LOCAL_DELAY);
+    if (kLocalDelay > 0 && c.waves < kPersistWaves) __builtin_amdgcn_s_sleep(kLocalDelay);
     while (true) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) w[i] = __hip_atomic_load(rec + lw + i * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -692,7 +628,7 @@ __device__ __forceinline__ bool grid_exchange8_local(const PersistCtl& c, T (&v)
       for (int i = 0; i < 8; ++i) bad |= (lw < lim - i * 64) ? ((unsigned)(w[i] & 0xffffffffull) ^ epoch) : 0u;
       if (__all(bad == 0)) break;
       if (++spins > (1u << 22)) { mygood = false; break; }
-      __builtin_amdgcn_s_sleep(PISO_PERSIST1_POLL_SLEEP);
+      __builtin_amdgcn_s_sleep(kPollSleep);
     }
     tsplit(2);
     double acc = 0;
@@ -797,12 +733,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // half and side (5 VALU instructions per row and pass in a loop that is bound by VALU issue), through the LDS it is one
   // broadcast read per row and pass that every lane receives (ring_issue) and no VALU slot at all.
   // (the slab variant and the fp64-coefficient fallback have no registers for the values in flight: they keep the DPP shifts)
-  constexpr bool kRingLds = (!SLAB || PISO_PERSIST1_RING_SLAB != 0) && sizeof(CT) == 4 && (NQ == 1 || PISO_PERSIST1_RING_SMALL != 0);
-  // kLean: the round-3 forms of the end-cell store (range-checked, all lanes) and of the coefficient offset (kept in a VGPR)
-  constexpr bool kLean = !SLAB || PISO_PERSIST1_LEAN_SLAB != 0;
+  constexpr bool kRingLds = sizeof(CT) == 4;
   // kParkRing: the ring-column copies of p AND r (one value per lane) live in the wave's LDS ring block between their two uses per
   // iteration (D's start, U's end) instead of in registers across both row loops
-  constexpr bool kParkRing = kRingLds && PISO_PERSIST1_PARK_RING != 0;
+  constexpr bool kParkRing = kRingLds;
   constexpr int kRingBytes = 64 * (int)sizeof(T) + 64 * (int)sizeof(CT) + (kParkRing ? 64 * (int)sizeof(T) : 0);
   constexpr unsigned kRingR = 64u * (unsigned)sizeof(T) + 64u * (unsigned)sizeof(CT);      // byte offset of the parked r column inside a ring block
   __shared__ __attribute__((aligned(16))) unsigned char ring_s[kRingLds ? kPersistWaves * NQ * kRingBytes : 16];
@@ -842,10 +776,10 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   }
   const int slot = LOCAL ? wg : (int)blockIdx.x;           // my exchange record
   // chip-wide launches: the exchange is a tree over the XCDs (grid_exchange8_hier); where am I in it?
-  constexpr bool kHier = !LOCAL && PISO_PERSIST1_HIER != 0;
+  constexpr bool kHier = !LOCAL;
   static_assert(!SLAB || kHier, "the node level of the slab instance rides on the tree exchange");
   unsigned hx = 0;
-  constexpr bool kLocalAll = LOCAL && PISO_PERSIST1_LOCAL_ALL != 0;     // XCD-local launches: every wave polls the group's records itself
+  constexpr bool kLocalAll = LOCAL;     // XCD-local launches: every wave polls the group's records itself
   __shared__ int hier_s[(kHier || kLocalAll) ? 4 : 1];
   if constexpr (kLocalAll) { if (threadIdx.x == 0) hier_s[2] = 0; }          // (the sticky flag; the barriers of the set-up below publish it)
   if constexpr (kHier) {
@@ -932,7 +866,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // otherwise unused).  In place every end cell dirtied a cache line of its own in the writer's L2 and was fetched as a line of
   // its own by the reader: 28 + 28 lines per region and iteration against 4 + 4 - and ~1 MB per XCD of L2 capacity that the
   // coefficient rows (4.19 MB per XCD at 2048^2 on a 4 MB L2) were missing.
-  constexpr bool kPack = PISO_PERSIST1_PACK != 0 && R > 2 && V == 2;
+  constexpr bool kPack = R > 2 && V == 2;
   unsigned vT[NQ], vEnd[NQ];                               // vEnd: where lanes 0 and 63 publish their end cells, beyond any buffer elsewhere
   // copies of r (registers) and of the direction (LDS / registers, `edge`) on the ring around my regions
   Vec<T, V> rhb[NQ], rha[NQ], pnb[NQ], pna[NQ];
@@ -950,7 +884,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     for (int q = 0; q < NQ; ++q) {
       const int cq = (tx0[q] * 64 + lane) * V;
       vT[q] = (unsigned)(cq * sizeof(T));
-      vEnd[q] = (!kLean || lane == 0 || lane == 63) ? vT[q] : 0x80000000u;
+      vEnd[q] = (lane == 0 || lane == 63) ? vT[q] : 0x80000000u;
       if constexpr (kPack) vEnd[q] = lane == 0 ? (unsigned)(tx0[q] * 64 * V * sizeof(T)) : (lane == 63 ? (unsigned)(tx0[q] * 64 * V * sizeof(T)) + (unsigned)(R * 16) : 0x80000000u);
       T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V;
 #pragma unroll
@@ -1061,7 +995,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   constexpr int NT = NQ * R;
   // (the deep pipeline pays where the loop has registers to spare: the slab variant and the four-array / fp64-coefficient variants
   // keep the round-2 depth, they spill otherwise)
-  constexpr bool kDeep = NQ == 1 && NT == 16 && SYM && RECON && (!SLAB || PISO_PERSIST1_DEEP_SLAB != 0) && sizeof(T) == 8;
+  constexpr bool kDeep = NQ == 1 && NT == 16 && SYM && RECON && sizeof(T) == 8;
   constexpr int depth_max = kDeep ? PISO_PERSIST1_DEPTH : ((NQ == 1) ? 3 : kPersistMaxDepth);
   // (small regions whose rows carry the diagonal too - systems with open boundaries, BASELINE config 4: 8 registers per row - get the
   // registers for FOUR rows in flight as well: with regions of 2 rows that is every row of the wave, i.e. the coefficients stay
@@ -1071,7 +1005,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   constexpr int D = (NT >= Dw) ? Dw : NT;
   constexpr int kBaseLoads = (SYM ? 2 : 4) + (RECON ? 0 : 1);          // vector loads every row issues (some rows one or two more)
   Vec<CT, V> cS[NT], cW[NT], cE[NT], cN[NT], cSh[NQ];
-  bool first_fill = false;                                 // (compile-time after unrolling: only the prologue loads the resident rows)
   Vec<T, V> cD[NT];
   CT eW[NQ];
   // byte offset of row j0[q] + jj: recomputed at every use (two scalar instructions) from a value the optimiser cannot see
@@ -1083,33 +1016,26 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     return (j + (unsigned)jj) * row_bytes;
   };
   auto coef_offset = [&](int q) __attribute__((always_inline)) -> unsigned {
-    unsigned o = vT[q];
-    if constexpr (!kLean) asm volatile("" : "+v"(o));       // (recomputed at every use: a VGPR less where registers spill)
-    return (unsigned)((unsigned long long)o * sizeof(CT) / sizeof(T));
+    return (unsigned)((unsigned long long)vT[q] * sizeof(CT) / sizeof(T));
   };
-  // The first kRes rows of a wave's rows keep their coefficients in registers for the whole launch (loaded by the prologue, never
-  // reissued).  Why: both stencil passes stream the S / W rows of the workgroup's cells, 4.19 MB per XCD and pass at 2048^2 - just
-  // above the 4 MB of an XCD's L2, so a cyclic sweep misses almost every time and the row loops run at the speed of the memory
-  // fabric (measured 33.5 MB in 3.6 us).  With kRes of 16 rows resident the streamed set is (16 - kRes) / 16 of that and fits.
-  // kZigZag: D walks the rows of a wave upwards (t = 0 .. NT-1), U walks them downwards.  The coefficient rows a pass ends with are
+  // Both stencil passes stream the S / W rows of the workgroup's cells, 4.19 MB per XCD and pass at 2048^2 - just above the 4 MB of
+  // an XCD's L2, so a cyclic sweep misses almost every time and the row loops run at the speed of the memory fabric (measured 33.5 MB
+  // in 3.6 us).  Hence the back-and-forth order: D walks the rows of a wave upwards (t = 0 .. NT-1), U walks them downwards.  The coefficient rows a pass ends with are
   // the rows the next pass starts with: they are still in registers (Dc rows per turn are never reloaded) and the rows behind them
   // are the most recently used lines of the XCD's L2 - a cyclic sweep over a set just above the L2's capacity misses every time,
   // a back-and-forth sweep misses only what does not fit.  (Measured before: both row loops ran at the speed of the memory
   // fabric, ~6 TB/s of coefficient rows, not at the speed of their arithmetic.)
-  constexpr bool kZigZag = PISO_PERSIST1_ZIGZAG != 0 && (!SLAB || PISO_PERSIST1_ZIGZAG_SLAB != 0) && (NQ == 1 || PISO_PERSIST1_ZIGZAG_SMALL != 0);
   // kAhead: z' = L p of the first rows of the U pass does not depend on alpha - it is computed WHILE the exchange's records travel
   // (behind the publish, in front of the polling: the SIMDs have nothing else to do for a microsecond or two) and kept in
   // registers; U then skips the stencil of those rows.  With the back-and-forth order these are the rows D ended with: their
   // coefficients are still in registers.  Same instructions on the same registers as D's z': bitwise the same values.
-  constexpr int kAhead = (kHier && kZigZag && NQ == 1 && NT == 16 && SYM && RECON && sizeof(T) == 8 && sizeof(CT) == 4) ? PISO_PERSIST1_AHEAD : 0;
+  constexpr int kAhead = (kHier && NQ == 1 && NT == 16 && SYM && RECON && sizeof(T) == 8 && sizeof(CT) == 4) ? PISO_PERSIST1_AHEAD : 0;
   static_assert(kAhead <= Dw || kAhead == 0, "the rows computed ahead are rows whose coefficients D left in registers");
-  constexpr bool kShLate = kAhead > 0 && !SLAB && NQ == 1 && SYM && PISO_PERSIST1_SH_LATE != 0;
+  constexpr bool kShLate = kAhead > 0 && !SLAB && NQ == 1 && SYM;
   // kKeepZ (small regions: a wave's rows are few): z' of D stays in registers until U has used it - U runs no stencil at all (the
   // 16-row instances have no registers for it: they compute z' twice, bitwise the same, and kAhead moves part of that off the path)
-  constexpr bool kKeepZ = PISO_PERSIST1_KEEP_Z != 0 && NT * (int)sizeof(T) * V / 4 <= PISO_PERSIST1_KEEP_Z_REGS;
-  constexpr int kRes = (NQ == 1 && NT == 16 && SYM && RECON) ? PISO_PERSIST1_RESIDENT : 0;
+  constexpr bool kKeepZ = NT * (int)sizeof(T) * V / 4 <= PISO_PERSIST1_KEEP_Z_REGS;
   auto issue_coef = [&](int t) __attribute__((always_inline)) {
-    if (t < kRes && !first_fill) return;
     const int q = t / R, jj = t - q * R;
     const unsigned vCq = coef_offset(q);
     const unsigned sT = row_base(q, jj, rowT), sC = row_base(q, jj, rowC);
@@ -1247,13 +1173,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
       // no exec mask to build, no data to select (2 compares + 2 selects per row in a loop that is bound by VALU issue)
       if constexpr (kPack) {
         bst<T, V, kPub>(Rd, vEnd[q], row_base(q, 1, rowT) + (unsigned)(jj * 16), val);
-      } else if constexpr (kLean) {
-        bst<T, V, kPub>(Rd, vEnd[q], sT, val);
       } else {
-        const bool last = lane == 63;
-        const T dat = last ? val.v[V - 1] : val.v[0];
-        const unsigned off = vT[q] + (last ? (unsigned)((V - 1) * sizeof(T)) : 0u);
-        if (lane == 0 || last) bst1<T, kPub>(Rd, off, sT, dat);
+        bst<T, V, kPub>(Rd, vEnd[q], sT, val);
       }
     }
   };
@@ -1310,10 +1231,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     }
   };
   if (has[0]) {
-    first_fill = true;
 #pragma unroll
-    for (int t = 0; t < (D > kRes ? D : kRes); ++t) issue_coef(t);
-    first_fill = false;
+    for (int t = 0; t < D; ++t) issue_coef(t);
   }
 
   unsigned epoch = c.epoch0;
@@ -1341,7 +1260,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     // (16-row regions and the slab instances are short of scalar registers: the buffer's address comes from the kernarg segment, not
     // from four SGPRs held across the loop - 83 -> 58 spilled SGPRs in the 16-row slab instance, 28 -> 23 in the plain one.  Small
     // regions keep the descriptors: their iteration is a latency chain and the scalar load sits on it - 256^2 2.70 -> 2.79 us)
-    if constexpr (SLAB || (PISO_PERSIST1_RZ_KARG != 0 && NT == 16)) {
+    if constexpr (SLAB || NT == 16) {
       typedef CgArgs<T> A;
       Rz = make_rsrc(karg<T*>((unsigned)offsetof(KArgs, a) + (unsigned)offsetof(A, zp) + 8u * (unsigned)(k & 1)), nbytesT);
     } else {
@@ -1400,7 +1319,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         PISO_SB_A1;
         // (rows 0 .. D-1 of the U pass are issued behind the drain of the perimeter stores, see the exchange: issued here they would
         // be in flight when the wave waits for vmcnt(0), and the wait would cover their trip as well)
-        if constexpr (D < NT) { if (t + D < NT || !kZigZag) issue_coef(t + D < NT ? t + D : t + D - NT); }
+        if constexpr (D < NT) { if (t + D < NT) issue_coef(t + D); }
         if constexpr (kShLate) { if (t + D == NT - 1) reload_csh(); }
         PISO_SB_A2;
       }
@@ -1421,7 +1340,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
         }
       }
     };
-    if constexpr (kHier) healthy = grid_exchange8_hier<T, (SLAB ? PISO_PERSIST1_POLL_DELAY2_XG : (kAhead > 0 ? PISO_PERSIST1_POLL_DELAY2 : PISO_PERSIST1_POLL_DELAY2_NOAHEAD)), SLAB>(c, sD, epoch, smem, hx, hier_s + 2, z_ahead, (kPersistDiag && c.timing) ? tsub : nullptr, sl_off, smem + 2 * kX1Sm);
+    if constexpr (kHier) healthy = grid_exchange8_hier<T, (SLAB ? kPollDelay2Xg : (kAhead > 0 ? kPollDelay2 : kPollDelay2NoAhead)), SLAB>(c, sD, epoch, smem, hx, hier_s + 2, z_ahead, (kPersistDiag && c.timing) ? tsub : nullptr, sl_off, smem + 2 * kX1Sm);
     else if constexpr (kLocalAll) healthy = grid_exchange8_local<T>(c, sD, epoch, smem, slot, nslots, hier_s + 2, (kPersistDiag && c.timing) ? tsub : nullptr);
     else healthy = grid_exchange8<T, LOCAL>(c, sD, epoch, smem, slot, nslots, NoPrefetch(), (kPersistDiag && c.timing) ? tsub : nullptr);
     tick(1);
@@ -1449,12 +1368,12 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     int cnt_wave = 0;                                        // #{|r_{k+1}| >= accuracy} of the whole wave, counted on the scalar unit
     if (has[0]) {
       issue_halos(Rz);                                       // (requested later in U, the stall moves into D: measured)
-      if constexpr (kAhead < NT && !kKeepZ) ring_issue(kZigZag ? NT - 1 - kAhead : 0);
+      if constexpr (kAhead < NT && !kKeepZ) ring_issue(NT - 1 - kAhead);
 #pragma unroll
       for (int tt = 0; tt < NT; ++tt) {
-        const int t = kZigZag ? NT - 1 - tt : tt;
+        const int t = NT - 1 - tt;                          // U walks the rows downwards
         const int q = t / R, jj = t - q * R;
-        if constexpr (!kKeepZ) { if (tt + 1 < NT && tt + 1 > kAhead) ring_issue(kZigZag ? t - 1 : t + 1); }     // (row kAhead's values were requested in front of the loop)
+        if constexpr (!kKeepZ) { if (tt + 1 < NT && tt + 1 > kAhead) ring_issue(t - 1); }     // (row kAhead's values were requested in front of the loop)
         T* xl = xs + (size_t)(wave * NQ + q) * R * 64 * V + lane * V + jj * 64 * V;
         Vec<T, V> xv = ldv<T, V>(xl);                        // x += alpha p (:303); the LDS latency hides under the stencil
         Vec<T, V> z;
@@ -1475,18 +1394,13 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
             // (inline asm: left to the compiler the sixteen rows' masks are parked in VGPR lanes - v_writelane / v_readlane pairs,
             // VALU slots - and counted after the loop)
             const unsigned long long over = __ballot(!(absval(rn) < accuracy));
-            if constexpr (kLean || PISO_PERSIST1_ASMCNT_SLAB != 0) {
-              int ones;
-              asm volatile("s_bcnt1_i32_b64 %1, %2\n\ts_add_i32 %0, %0, %1" : "+s"(cnt_wave), "=&s"(ones) : "s"(over) : "scc");
-            } else {
-              cnt_wave += __builtin_popcountll(over);
-            }
+            int ones;
+            asm volatile("s_bcnt1_i32_b64 %1, %2\n\ts_add_i32 %0, %0, %1" : "+s"(cnt_wave), "=&s"(ones) : "s"(over) : "scc");
           }
         }
         PISO_SB_B1;
         if constexpr (D < NT) {
-          if constexpr (kZigZag) { if (t - D >= 0) issue_coef(t - D); }       // downwards; rows D-1 .. 0 stay in registers for the next D pass
-          else issue_coef(t + D < NT ? t + D : t + D - NT);                  // wraps: rows 0 .. D-1 for D of the next iteration
+          if (t - D >= 0) issue_coef(t - D);                 // downwards; rows D-1 .. 0 stay in registers for the next D pass
         }
         PISO_SB_B2;
       }
@@ -1535,7 +1449,7 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   if (!first && healthy && !st.done) {
     T sX[kX1Values] = {0, 0, 0, 0, 0, 0, lU[0], lU[1]};
     ++epoch;
-    if constexpr (kHier) healthy = grid_exchange8_hier<T, PISO_PERSIST1_POLL_DELAY2_NOAHEAD, SLAB>(c, sX, epoch, smem, hx, hier_s + 2, NoPrefetch(), nullptr, sl_off, smem + 2 * kX1Sm);     // (nothing to compute ahead)
+    if constexpr (kHier) healthy = grid_exchange8_hier<T, kPollDelay2NoAhead, SLAB>(c, sX, epoch, smem, hx, hier_s + 2, NoPrefetch(), nullptr, sl_off, smem + 2 * kX1Sm);     // (nothing to compute ahead)
     else if constexpr (kLocalAll) healthy = grid_exchange8_local<T>(c, sX, epoch, smem, slot, nslots, hier_s + 2);
     else healthy = grid_exchange8<T, LOCAL>(c, sX, epoch, smem, slot, nslots);
     tOut[1] = sX[6]; tOut[2] = sX[7];
@@ -1544,7 +1458,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // ---- back to the global-memory state of the two-kernel path (iteration k reads its direction from p[k & 1])
   // (the pointers of the exit are read again from the kernarg segment: held in SGPRs across the loop they are spilled, and the
   // reloads of OTHER spilled values land in the row loops)
-#if PISO_PERSIST1_EXIT_KARGS
   struct { T *r, *x, *pk, *partsB, *scal; const T* gB; CgState* state; int nB; } ax;       // (pk: p[k & 1])
   struct { int* err; } cx;
   {
@@ -1557,10 +1470,6 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
     ax.nB = karg<int>(ao + (unsigned)offsetof(A, nB));
     cx.err = karg<int*>(co + (unsigned)offsetof(PersistCtl, err));
   }
-#else
-  struct { T *r, *x, *pk, *partsB, *scal; const T* gB; CgState* state; int nB; } ax = {a.r, a.x, a.p[k & 1], a.partsB, a.scal, a.gB, a.state, a.nB};
-  const PersistCtl& cx = c;
-#endif
   {
     const rsrc_t Rr = make_rsrc(ax.r, nbytesT), Rx = make_rsrc(ax.x, nbytesT), Rp = make_rsrc(ax.pk, nbytesT);
 #pragma unroll

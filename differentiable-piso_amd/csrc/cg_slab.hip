@@ -838,6 +838,7 @@ int piso_comm_stats(void* comm, long long* out4) {      // (six values: see incl
 // msgs28 = 4 x {count, off[3], len[3]} (element offsets into `vec`).  Ring neighbours always (without a periodic y axis the wrap
 // rows travel and nobody reads them).  One launch; the elements cross xGMI as 8-byte words written into the consumer's mailbox.
 int piso_comm_exchange(void* comm, void* vec, int dtype, const int* msgs28, piso_stream_t stream_) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   PisoComm* pc = static_cast<PisoComm*>(comm);
   if (!pc || !vec || !msgs28) { set_error_msg("piso_comm_exchange: invalid argument"); return PISO_ERR_INVALID_ARG; }
   if (pc->world == 1 && opt(OPT_SLAB_FORCE) <= 0) return PISO_OK;        // (slab_force: test knob - a ring of one rank exchanges with itself)
@@ -891,6 +892,7 @@ int piso_cg_solve_slab_f64(void* comm, int nx, int ny_local, int periodic_x, int
                            const double* divergence_local, double* x_out_local, double* x_out_global, float accuracy,
                            int max_iterations, int rank_deficient, int residual_reset, int* iterations_out, void* workspace,
                            size_t workspace_bytes, piso_stream_t stream_) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   if (!comm || nx < 1 || ny_local < 1 || !laplace_local || !divergence_local || !x_out_local || !workspace || residual_reset < 1) {
     set_error_msg("piso_cg_solve_slab_f64: invalid argument");
     return PISO_ERR_INVALID_ARG;
@@ -926,6 +928,7 @@ int piso_cg_solve_slab_emulated_f64(int slabs, int nx, int ny, int periodic_x, i
                                     const double* divergence, double* x_out, float accuracy, int max_iterations,
                                     int rank_deficient, int residual_reset, int* iterations_out, void* workspace,
                                     size_t workspace_bytes, piso_stream_t stream_) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   if (slabs < 1 || nx < 1 || ny < slabs || ny % slabs != 0 || !laplace || !divergence || !x_out || !workspace || residual_reset < 1) {
     set_error_msg("piso_cg_solve_slab_emulated_f64: invalid argument (ny must be a multiple of slabs)");
     return PISO_ERR_INVALID_ARG;

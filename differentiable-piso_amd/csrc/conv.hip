@@ -693,6 +693,7 @@ size_t piso_conv2d_wgrad_workspace_bytes(int ks, int cin, int cout) {
 
 int piso_conv2d_forward(const float* in, const float* w_laid_out, float* out, int H, int W, int cin, int cout, int ks, int pad, int leaky_out,
                         piso_stream_t stream_) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   ConvGeom g;
   g.H = H; g.W = W; g.pad = pad; g.cin = cin; g.cout = cout;
   g.Ho = H + 2 * pad - ks + 1; g.Wo = W + 2 * pad - ks + 1;
@@ -716,6 +717,7 @@ int piso_conv2d_forward(const float* in, const float* w_laid_out, float* out, in
 
 int piso_conv2d_wgrad(const float* in, const float* grad_out, float* dw, int H, int W, int cin, int cout, int ks, int pad, void* workspace,
                       size_t workspace_bytes, piso_stream_t stream_) {
+  const piso::OptScope knobs;                              // (the call works on a snapshot of the knobs, options.h)
   ConvGeom g;
   g.H = H; g.W = W; g.pad = pad; g.cin = cin; g.cout = cout;
   g.Ho = H + 2 * pad - ks + 1; g.Wo = W + 2 * pad - ks + 1;

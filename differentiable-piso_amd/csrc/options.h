@@ -1,5 +1,7 @@
 // Tuning / test knobs of libpiso_hip.so.  Every knob has a default taken ONCE, when the library is loaded, from the
 // environment variable PISO_<NAME> (upper case); afterwards only piso_set_option() changes it.  -1 = "not set / automatic".
+// None of them changes WHAT is computed: they pick between implementations that return bitwise the same result (kernel instance, staging,
+// launch shape) or switch a check / a measurement aid on and off.  Stores and loads are atomic; a call works on a snapshot (OptScope).
 #pragma once
 
 namespace piso {
@@ -31,7 +33,18 @@ enum Opt {
   OPT_COUNT
 };
 
-int opt(Opt o);                       // current value (-1 = not set)
+int opt(Opt o);                       // value of the calling entry point's snapshot (inside an OptScope), else the live value (-1 = not set)
 inline bool opt_on(Opt o) { return opt(o) > 0; }
+
+// Every public entry point that reads knobs opens an OptScope first: ALL knobs are copied once (atomically, one by one) into a
+// thread-local snapshot and `opt()` answers from that copy until the scope closes.  A piso_set_option() from another thread - a test
+// flipping a knob while autograd's backward thread is inside a solve - therefore never changes a decision in the MIDDLE of a call
+// (which kernel instance runs, whether the result is verified): a call sees the knobs as they were when it started.  Re-entrant.
+struct OptScope {
+  OptScope();
+  ~OptScope();
+  OptScope(const OptScope&) = delete;
+  OptScope& operator=(const OptScope&) = delete;
+};
 
 }  // namespace piso

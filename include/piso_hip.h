@@ -67,22 +67,18 @@ const char* piso_version(void);
 const char* piso_last_error_string(void);
 /* Number of visible HIP devices (0 if none; never initialises a context). */
 int piso_device_count(void);
-/* Tuning / test knobs (no counterpart in the reference).  Each knob `name` takes its default ONCE, at library load, from the
- * environment variable PISO_<NAME IN UPPER CASE>; -1 = not set (automatic).  Process-wide, not thread-safe against a
- * concurrent solve.  Names: cg_persist (0 forbid / 1 force the persistent CG kernel), cg_persist_r (2|4|16 rows per region),
- * cg_persist_half (0: small regions never run with one working wave per SIMD and twice the workgroups; 1: wherever that fits the
- * chip, also where it pushes a grid out of one XCD),
- * cg_persist_nq (regions of 2 rows, ONE per wave instead of two: 0 never, 1 wherever the chip holds them; default: grids that need
- * more than one XCD's worth of workgroups, and grids of at most 256 regions, which stay on one XCD either way),
- * bicg_fold (0: the scalar stages of BiCGStab always run as launches of their own; default: folded into the kernels that consume
- * them on one GPU), bicg_sweep_lds (0: sweeps and factorisation address memory in scan order instead of staging rows through LDS),
- * bicg_fuse_p (0: the direction update of BiCGStab is a launch of its own instead of part of the forward sweep that reads it),
- * slab_force (1: a communicator of ONE rank still runs the slab code paths - a ring with itself; tests), conv_lds (0: the closure's
- * forward / input-gradient convolutions read their operands straight from L2 instead of staging them through LDS),
- * cg_segment (iterations per persistent launch),
- * cg_persist_timing, cg_rpw, cg_maxblocks, cg_nt, cg_no_compact, cg_no_recon, cg_no_sym, cg_verify (0: skip the true-residual
- * check of persistent solves; 2: test knob, treat it as failed), cg_pad (0: never run a small wall-bounded grid that the
- * persistent kernel cannot tile on a zero-padded one). */
+/* Tuning / test knobs (no counterpart in the reference).  NONE of them changes what is computed: a knob picks between implementations
+ * that return bitwise the same result (which kernel instance runs, how operands are staged, launch shapes) or switches a check / a
+ * measurement aid on and off.  Each knob `name` takes its default ONCE, at library load, from the environment variable
+ * PISO_<NAME IN UPPER CASE>; -1 = not set (automatic).  The store is process-wide and atomic; every entry point that reads knobs copies
+ * ALL of them when it is entered and works on that snapshot, so a piso_set_option() from another thread (a test flipping a knob while an
+ * autograd backward thread is inside a solve) never changes a decision in the middle of a call.  The list, with what each one selects,
+ * is differentiable-piso_amd/csrc/options.h; the ones callers outside the tests use:
+ *   cg_persist (0 forbid / 1 force the persistent CG kernel; default by grid size), cg_persist_r (2|4|16 rows per region),
+ *   cg_segment (iterations per persistent launch), cg_verify (0: skip the true-residual check of persistent solves),
+ *   slab_force (1: a communicator of ONE rank still runs the slab code paths - a ring with itself),
+ *   bicg_fold / bicg_sweep_lds / bicg_fuse_p (0: the un-fused forms of the BiCGStab stages), conv_lds (0: closure convolutions read
+ *   their operands straight from L2). */
 int piso_set_option(const char* name, int value);
 int piso_get_option(const char* name, int* value_out);
 
