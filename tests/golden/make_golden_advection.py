@@ -24,7 +24,10 @@ the control volumes around the faces, and every piece of it is something the ref
 executed below on the interior dual cells (everything they read lies inside the padded arrays: no extrapolation of PhiFlow's is
 involved).  Stored per case and velocity: per FACE of every control volume `face_flux_phi` = F * (mean phi on the face) and `face_flux` = F,
 order (y lo, y hi, x lo, x hi) - with them a test can state every non-Dirichlet row, also next to no-slip cells, from the rule
-"neighbour open (active, or an in-grid no-slip cell) -> F phi_face, else F phi_P" (`:256-258, 275-277`); and the sums `own` and
+"neighbour open (active, or an in-grid no-slip cell) -> F phi_face, else F phi_P" (`:256-258, 275-277`) - and, with `face_dphi` =
+phi_N - phi_P across the same faces (PhiFlow's `axis_gradient` of the padded phi), every row of the DIFFUSIVE part from "open ->
+nu area / h (phi_N - phi_P); closed by a no-slip cell across the component's own axis -> -2 nu area / h phi_P (the wall's ghost value
+-phi_P); closed otherwise -> nothing" (`:265-266, 287-288`); and the sums `own` and
 `cross` (the two axes' terms) and `cross_closed` = (F_lo - F_hi) phi_P of the
 cross-stream axis, which is what a face on the FAR side of an open boundary keeps (the kernel reads the masks of the cells (i, j -+ 1)
 BEHIND the face for the cross-stream terms, and those lie outside the grid - same finding as in make_golden_diffusion.py).
@@ -144,11 +147,21 @@ def conservative_terms(vel, phi, domain, own_axis):
             idx = (along, other) if axis == 0 else (other, along)
             face_flux_phi.append(fp[idx])
             face_flux.append(f[idx])
+    # phi_N - phi_P across the same four faces (the diffusive part's per-face difference): PhiFlow's axis_gradient of the padded phi
+    face_dphi = []
+    ph = np.asarray(c_phi.data, np.float64)
+    for axis in (0, 1):
+        g = np.asarray(pmath.axis_gradient(ph, axis), np.float64)[0, :, :, 0]      # g[k] = phi[k + 1] - phi[k] along `axis`
+        for lo_hi in (0, 1):
+            along = slice(lo_hi, g.shape[axis] - 1 + lo_hi)                       # lo face of dual cell k: -(g[k - 1]); hi face: +g[k]
+            idx = (along, slice(1, -1)) if axis == 0 else (slice(1, -1), along)
+            face_dphi.append(g[idx] if lo_hi else -g[idx])
+    face_dphi = np.stack(face_dphi, -1)
     faces = np.stack(face_flux_phi, -1), np.stack(face_flux, -1)
     # the divergence is the sum over the faces (a check of the slicing above against StaggeredGrid.divergence)
     resid = np.abs((faces[0][..., 0] - faces[0][..., 1] + faces[0][..., 2] - faces[0][..., 3]) - (own + cross)).max()
     assert resid < 1e-7 * (1 + np.abs(own).max()), resid                         # (the box arithmetic of the padded component is float32)
-    return own, cross, cross_closed, faces[0], faces[1]
+    return own, cross, cross_closed, faces[0], faces[1], face_dphi
 
 
 def central_gradient_form(phi, domain, per_y, per_x, own_axis):
@@ -180,12 +193,13 @@ def make(name, res, d_yx, boundaries, per_yx, rng):
     for kind in KINDS:
         vel = consistent(velocity(kind, ny, nx, dy, dx, rng), ny, nx, per_y, per_x)
         terms = {k: np.zeros((1, ny + 1, nx + 1, 2)) for k in ("own", "cross", "cross_closed")}
-        terms.update({k: np.zeros((1, ny + 1, nx + 1, 2, 4)) for k in ("face_flux_phi", "face_flux")})
+        terms.update({k: np.zeros((1, ny + 1, nx + 1, 2, 4)) for k in ("face_flux_phi", "face_flux", "face_dphi")})
         for own_axis in (0, 1):
             sl = (0, slice(None), slice(0, nx), 0) if own_axis == 0 else (0, slice(0, ny), slice(None), 1)
-            for k, a in zip(("own", "cross", "cross_closed", "face_flux_phi", "face_flux"), conservative_terms(vel, phi, domain, own_axis)):
+            for k, a in zip(("own", "cross", "cross_closed", "face_flux_phi", "face_flux", "face_dphi"), conservative_terms(vel, phi, domain, own_axis)):
                 terms[k][sl] = a
         out[kind + "/vel"] = vel
+        out["face_dphi"] = terms.pop("face_dphi")                                  # (does not depend on the velocity)
         for k, a in terms.items():
             out[kind + "/" + k] = a
         if kind == "uniform":

@@ -75,7 +75,7 @@ def row_classes(c):
     return plain, far, closed
 
 
-def neighbour_open(c):
+def neighbour_open(c, with_walls=False):
     """[1, ny+1, nx+1, 2, 4] bool, faces in the fixture's order (y lo, y hi, x lo, x hi): does the row keep an off-diagonal entry towards
     that neighbour?  The reference's rule (central_difference_csr_op.cu.cc:256-258, 275-277 for u rows; :400-402, 419-421 for v rows):
     the cell it reads is active, OR the neighbour row exists inside the array (not across the domain boundary) and that cell is a no-slip
@@ -85,17 +85,20 @@ def neighbour_open(c):
     act = np.asarray(c["active"])[0, :, :, 0] == 1
     ns = np.zeros_like(act) if c["no_slip"] is None else np.asarray(c["no_slip"], bool).reshape(ny + 2, nx + 2)
     out = np.zeros((1, ny + 1, nx + 1, 2, 4), bool)
+    wall = np.zeros((1, ny + 1, nx + 1, 2, 4), bool)                              # the cell read is a no-slip cell (whatever else it is)
     for j in range(ny + 1):
         for i in range(nx + 1):
             if j < ny:                                                            # u(i, j), array [ny, nx + 1]
                 cells = ((j, i + 1), (j + 2, i + 1), (j + 1, i), (j + 1, i + 1))
                 inside = (j > 0, j < ny - 1, i > 0, i < nx)
                 out[0, j, i, 1] = [act[cl] or (ins and ns[cl]) for cl, ins in zip(cells, inside)]
+                wall[0, j, i, 1] = [ns[cl] for cl in cells]
             if i < nx:                                                            # v(i, j), array [ny + 1, nx]
                 cells = ((j, i + 1), (j + 1, i + 1), (j + 1, i), (j + 1, i + 2))
                 inside = (j > 0, j < ny, i > 0, i < nx - 1)
                 out[0, j, i, 0] = [act[cl] or (ins and ns[cl]) for cl, ins in zip(cells, inside)]
-    return out
+                wall[0, j, i, 0] = [ns[cl] for cl in cells]
+    return (out, wall) if with_walls else out
 
 
 def lhs_of(got_Mphi_flat, c, g):
@@ -163,6 +166,44 @@ def test_oracle_every_non_dirichlet_row_from_the_per_face_fluxes(name, kind):
     if name == "cavity":                                                           # the rows the sums-form test has to leave out
         assert rows.sum() - plain.sum() >= 20
         assert (~opn[rows]).any() and opn[rows].any()
+
+
+def check_every_diffusive_row(name, got_Mphi_flat, c, g, nu):
+    """EVERY non-Dirichlet row of the DIFFUSIVE part (zero velocity, scalar nu) from the fixture's per-face differences phi_N - phi_P
+    (PhiFlow's axis_gradient of the reference-padded phi) and the reference's rule (central_difference_csr_op.cu.cc:256-266, 275-288):
+    open -> nu area / h (phi_N - phi_P); closed by a no-slip cell ACROSS the component's own axis -> -2 nu area / h phi_P (the wall's
+    ghost value is -phi_P: the factor the cavity's wall shear depends on, validated against Ghia in tests/test_ldc_ghia.py); closed
+    otherwise -> nothing (free slip / zero normal gradient)."""
+    ny, nx = c["ny"], c["nx"]
+    dy, dx = c["dx_yx"]
+    lhs = lhs_of(got_Mphi_flat, c, g)
+    rows = ~np.asarray(c["dirichlet_mask"], bool)
+    rows[0, ny, :, 1] = False
+    rows[0, :, nx, 0] = False
+    opn, wall = neighbour_open(c, with_walls=True)
+    coef = np.array([dx / dy, dx / dy, dy / dx, dy / dx])                          # area / h of the faces (y lo, y hi, x lo, x hi)
+    cross = np.zeros((1, 1, 1, 2, 4), bool)
+    cross[0, 0, 0, 1, :2] = True                                                   # u rows: the y faces are across the own axis (x)
+    cross[0, 0, 0, 0, 2:] = True                                                   # v rows: the x faces
+    phi = g["phi"].astype(np.float64)[..., None]
+    per_face = np.where(opn, g["face_dphi"], np.where(wall & cross, -2.0 * phi, 0.0)) * coef
+    want = nu * per_face.sum(-1)
+    scale = np.abs(want[rows]).max()
+    tol = 2e-6 * (BETA * np.abs(g["phi"]).max() + scale) + 1e-5 * scale
+    err = np.abs(lhs - want)
+    assert err[rows].max() <= tol, (name, err[rows].max(), tol)
+    return rows, opn, wall & cross & ~opn
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_every_non_dirichlet_row_of_the_diffusive_part(name):
+    g, c = advection_case(name, "random")
+    c["vel"] = np.zeros_like(c["vel"])
+    c["viscosity"] = 0.35
+    _, _, prod = oracle_product(c, g)
+    rows, opn, noslip_closed = check_every_diffusive_row(name, prod, c, g, 0.35)
+    if name == "cavity":                                                           # rows with the wall factor 2 exist and are covered
+        assert noslip_closed[rows].any(-1).sum() >= 10
 
 
 @pytest.mark.parametrize("name", ["xper_ywall", "spatial_ml"])
@@ -234,6 +275,15 @@ def test_hip_assembly_is_the_references_conservative_central_flux(name, kind):
 def test_hip_every_non_dirichlet_row_from_the_per_face_fluxes(name, kind):
     g, c = advection_case(name, kind)
     check_every_row(name, kind, hip_product(c, g), c, g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_every_non_dirichlet_row_of_the_diffusive_part(name):
+    g, c = advection_case(name, "random")
+    c["vel"] = np.zeros_like(c["vel"])
+    c["viscosity"] = 0.35
+    check_every_diffusive_row(name, hip_product(c, g), c, g, 0.35)
 
 
 @pytest.mark.gpu

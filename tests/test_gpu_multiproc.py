@@ -295,7 +295,10 @@ def test_bench_line_contract_on_one_gpu():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # `bound` names what the kernel's own SQ counters show (the round-5 verdict: "hbm" was a mislabel for a kernel whose vectors never
+    # leave the chip); achieved / peak / frac stay the contract's HBM figure and the contract's enum value is kept beside it
+    assert r["bound"] == "valu+latency" and r["bound_enum_of_the_contract"].startswith("hbm")
+    assert r["unit"] == "GB/s" and 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
