@@ -1093,11 +1093,13 @@ def main():
                 try:
                     # a WHOLE oracle step (forward + reverse sweep, the bench's solver settings) TIMED for real at 1024^2 - the largest
                     # size at which that takes about a minute - with the pricing formula of the 2048^2 figure evaluated beside it
-                    ts = cpu_baseline_pricing_check(args.tol, args.max_iterations, args.residual_reset, n=1024)
+                    # (1024^2 needs ~1 min on the GPU box's 128 threads; a host with few cores times the same step at 512^2 instead)
+                    n_timed = 1024 if (os.cpu_count() or 1) >= 32 else 512
+                    ts = cpu_baseline_pricing_check(args.tol, args.max_iterations, args.residual_reset, n=n_timed)
                     ts["steps_per_s"] = 1.0 / ts["measured_s_per_step"]
-                    ts["kind"] = "timed (not priced): one fwd + adjoint PISO step of the C oracle at 1024^2, OpenMP CG on %d threads" % out["cpu_baseline"]["cores"]
+                    ts["kind"] = "timed (not priced): one fwd + adjoint PISO step of the C oracle at %d^2, OpenMP CG on %d threads" % (n_timed, out["cpu_baseline"]["cores"])
                     out["cpu_baseline"]["timed_step"] = ts
-                    out["cpu_baseline"]["value_is"] = "priced from timed samples at 2048^2 (see sample); timed_step is a whole step timed at 1024^2"
+                    out["cpu_baseline"]["value_is"] = "priced from timed samples at 2048^2 (see sample); timed_step is a whole step timed at %d^2" % n_timed
                 except Exception as e:
                     out["cpu_baseline"]["timed_step"] = {"error": repr(e)}
             except Exception as e:   # the baseline must never sink the GPU number

@@ -6,7 +6,7 @@
 #   4. rocprofv3 --kernel-trace --stats of a fixed-work BiCGStab run (scripts/bench_bicg.py)  -> <tag>_bicgstab2048_kernel_stats.csv
 #   5. scripts/make_traffic_json.py condenses 2 + 3 into traffic.json (with the sha of the kernel sources it was measured on)
 # Raw traces stay in /tmp on the box; only summaries are copied to gpurun_out/prof/ (64 MiB cap).  Usage: profile_bench.sh <tag>
-R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the snapshot's root)}
+R=${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the root of the snapshot)}
 TAG=${1:-rXX}
 OUT=$R/gpurun_out/prof
 mkdir -p $OUT $R/scripts/_bin
