@@ -976,10 +976,10 @@ static Geo make_geo(int nx, int ny, int band_rows) {
   // automatic (2048^2: 8 rows).  The rows of a band are sequential and a band is one workgroup: 2048^2 has 257 bands of 16 rows = ONE workgroup
   // of four waves per CU, and a sweep is then bound by the latency of its row chain (75 / 100 us); 513 bands of 8 rows keep two
   // workgroups per CU busy and halve the chain - 591 instead of 713 us per iteration, the SAME iteration counts (the matrices are
-  // strongly diagonally dominant: 3 iterations to 1e-6, 5 to 1e-9 with bands of 4 .. 32 rows; scripts/bicg_bands.py).  Bands of 4
+  // strongly diagonally dominant: 3 iterations to 1e-6, 5 to 1e-9 with bands of 4 .. 32 rows; a round-4 A/B script, results in profiles/README.md).  Bands of 4
   // rows gain nothing more at 2048^2 (the sweeps then move ~6 TB/s) and cost an iteration at 256^2.
   // Round 5: smaller grids get lower bands by the same argument - a band is one workgroup, and two components x ny / R bands should be
-  // about two workgroups per CU: ny >= 2048: 8 rows, >= 1024: 4, >= 256: 2.  Measured (scripts/bicg_bands.py, solve to 1e-6, same
+  // about two workgroups per CU: ny >= 2048: 8 rows, >= 1024: 4, >= 256: 2.  Measured (round 5, solve to 1e-6, same
   // iteration counts): 1024^2 0.833 -> 0.767 ms, 512^2 0.519 -> 0.429, 256^2 0.440 -> 0.366.
   // (grids of fewer than 256 rows - the lid-driven cavity - keep 8: nothing there is bound by the bands' parallelism, and at the
   // reference script's loose 1e-3 the preconditioner decides which iterate inside the tolerance a solve stops at)

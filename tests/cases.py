@@ -138,7 +138,7 @@ def product_setup(c, lin_tol=1e-5, lin_max_it=2000, lin_double=False, p_tol=1e-5
 def pressure_system(nx, ny, walls=False, seed=11):
     """A doubly periodic (or, walls=True, wall-bounded) pressure system at any size for the kernel-level CG tests and benchmarks:
     random A0 face weights in [0.5, 1.5) with consistent periodic duplicates (a symmetric matrix), the HIP Laplace matrix of it
-    [nx * ny, 5] float64 on the device and a zero-mean right-hand side.  (Was `case()` of scripts/diag_persist1.py.)"""
+    [nx * ny, 5] float64 on the device and a zero-mean right-hand side."""
     import torch
     from diffpiso.solvers import laplace_matrix_native
     dev = torch.device("cuda")

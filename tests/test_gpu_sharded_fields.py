@@ -273,7 +273,7 @@ def test_sharded_config5_4096_eight_slabs_fields_after_fixed_iterations_vs_one_g
     the pressure solves stopped after 100 UN-shifted CG iterations on both sides (the shifted operator's iterates are not
     reproducible between summation orders) - FIELDS of the eight slabs against the one-GPU step, not just the loss.
     A step with UNCONVERGED solves is ill-conditioned: white noise of 1e-7 (one float32 ulp) on the initial velocity moves u by 1e-4,
-    p by 2.5e-3 and dL/du_0 by 1e-3 after 100 iterations (measured at 1024^2, scripts/sens_sharded.py; the truncated Krylov
+    p by 2.5e-3 and dL/du_0 by 1e-3 after 100 iterations (measured at 1024^2 in round 5; the truncated Krylov
     polynomial depends on its right-hand side).  That sensitivity is the yardstick: the eight slabs must differ from the one-GPU
     step by LESS than a one-ulp perturbation of the one-GPU input does (measured: ten times less) - at the slab edges as well.  The
     converged comparisons (1e-6 / 1e-5) are the tests above.
