@@ -1035,6 +1035,11 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
   // kKeepZ (small regions: a wave's rows are few): z' of D stays in registers until U has used it - U runs no stencil at all (the
   // 16-row instances have no registers for it: they compute z' twice, bitwise the same, and kAhead moves part of that off the path)
   constexpr bool kKeepZ = NT * (int)sizeof(T) * V / 4 <= PISO_PERSIST1_KEEP_Z_REGS;
+  // kCountLate (16-row regions, round 6): the residual count is taken in a pass of its own, only in the iterations whose count the
+  // stopping test reads ((k + 1) % 5 == 0): 32 fp64 compares less per wave in 4 of 5 iterations of a loop bound by VALU issue
+  // (A/B on one box, four rounds: 10.19 - 10.32 against 10.22 - 10.48 us per iteration).  Small regions keep the count in the row loop:
+  // their iteration is a latency chain, a branch more on it buys nothing.
+  constexpr bool kCountLate = NT == 16 && !RAGGED;
   auto issue_coef = [&](int t) __attribute__((always_inline)) {
     const int q = t / R, jj = t - q * R;
     const unsigned vCq = coef_offset(q);
@@ -1389,8 +1394,8 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           const T rn = fma(-alpha, z.v[e] + vsc, rr[q][jj].v[e]);
           rr[q][jj].v[e] = rn;
           lU[0] += rn;
-          // (one compare per cell; ballot + popcount + add run on the scalar unit - the loop is bound by VALU issue.  A NaN counts.)
-          {
+          if constexpr (!kCountLate) {
+            // (one compare per cell; ballot + popcount + add run on the scalar unit - the loop is bound by VALU issue.  A NaN counts.)
             // (inline asm: left to the compiler the sixteen rows' masks are parked in VGPR lanes - v_writelane / v_readlane pairs,
             // VALU slots - and counted after the loop)
             const unsigned long long over = __ballot(!(absval(rn) < accuracy));
@@ -1403,6 +1408,22 @@ __global__ __launch_bounds__(kPersistThreads) void cg_persist1(CgArgs<T> a, Pers
           if (t - D >= 0) issue_coef(t - D);                 // downwards; rows D-1 .. 0 stay in registers for the next D pass
         }
         PISO_SB_B2;
+      }
+      if constexpr (kCountLate) {
+        // #{|r_{k+1}| >= accuracy} is looked at by the stopping test of iteration k + 1 only if (k + 1) % 5 == 0 (:312-335): counted in a
+        // pass of its own over the registers, in those iterations only (one wave-uniform branch; 32 fp64 compares less in 4 of 5 iterations)
+        if ((k + 1) % 5 == 0) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int q = t / R, jj = t - q * R;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+              const unsigned long long over = __ballot(!(absval(rr[q][jj].v[e]) < accuracy));
+              int ones;
+              asm volatile("s_bcnt1_i32_b64 %1, %2\n\ts_add_i32 %0, %0, %1" : "+s"(cnt_wave), "=&s"(ones) : "s"(over) : "scc");
+            }
+          }
+        }
       }
       // the ring: the same update with the neighbours' z' (beyond a wall there is no cell: the copies stay 0)
 #pragma unroll
