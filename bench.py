@@ -363,6 +363,13 @@ def slab_kernel_loopback(n, device, iters=2000):
             st = comm.stats()
             out.update(persistent_slab_iterations=st["persistent_iterations"], persistent_fallbacks=st["persistent_fallbacks"],
                        verification_failures=st["verification_failures"])
+            # the same measurement the N > 1 line makes between every pair of ranks (sharded.hop_us_matrix), here on the rank's OWN
+            # mailbox: what the uncached access path costs without a link - the hop a node adds comes on top of it
+            try:
+                out["own_mailbox_hop_us"] = comm.hop_matrix(2000)[0][0]
+                out["peer_map"] = comm.peer_map
+            except Exception as e:
+                out["own_mailbox_hop_us"] = repr(e)
             return out
         finally:
             N.set_option("slab_hop_ticks", 0)
