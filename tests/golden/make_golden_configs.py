@@ -272,5 +272,7 @@ if __name__ == "__main__":
         make_bench_unrolled(512, 16)
     if "bench1024_unroll16" in which:
         make_bench_unrolled(1024, 16)
+    if "bench2048_unroll16" in which:    # the metric workload at the metric size (~7 h on 8 cores; reverse sweep at 1e-10 as bench2048_tight_step)
+        make_bench_unrolled(2048, 16, TIGHT_SOLVER_2048)
     if "bench512" in which:       # quick look at the workload at a small size (not committed)
         make_bench2048(512)

@@ -201,6 +201,14 @@ def test_benchmark_workload_1024_sixteen_steps_converged():
     _bench_unrolled("bench1024_tight_unroll16.npz", _TIGHT)
 
 
+def test_benchmark_workload_2048_sixteen_steps_converged():
+    """... and at the metric's own size, 2048^2: the north star's sentence as it stands (the oracle needs ~7 h on 8 threads for this
+    fixture; the reverse sweep's pressure solves run at 1e-10, see TIGHT_SOLVER_2048)."""
+    if not os.path.isfile(os.path.join(HERE, "golden", "bench2048_tight_unroll16.npz")):
+        pytest.skip("fixture not generated")
+    _bench_unrolled("bench2048_tight_unroll16.npz", _TIGHT)
+
+
 # Converged fixtures (round 3: pressure solves to max|r| < 1e-12, advection 1e-9): velocity, PRESSURE and both back-propagated
 # gradients are held to the north star's 1e-5 (dL/dp_0 against the size of its summands, see _bench_step).  At the round-2
 # tolerance of 1e-8 two correct solvers still differed by 3e-3 .. 1e-2 in the pressure's smoothest modes (tolerance / smallest
