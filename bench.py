@@ -402,11 +402,36 @@ def slab_kernel_loopback(n, device, iters=2000):
     return out
 
 
+def _stable_host_memory_for_the_cpu_baseline():
+    """The CPU baseline moved by +-40 % between boxes and rounds: its arrays are allocated (first touched) by the main thread, i.e. on
+    ONE NUMA node of a two-socket host, and 128 OpenMP threads then read them across the socket link.  Interleave this process's future
+    pages over all nodes that have memory (set_mempolicy(MPOL_INTERLEAVE), x86-64 syscall 238; the GPU legs are over by now) and pin the
+    OpenMP threads to cores.  Best effort: returns what it did for the record."""
+    import ctypes
+    did = {}
+    for k, v in (("OMP_PROC_BIND", "spread"), ("OMP_PLACES", "cores")):      # (read by libgomp when the oracle's library is loaded)
+        if k not in os.environ:
+            os.environ[k] = v
+            did[k] = v
+    try:
+        nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+        if len(nodes) > 1:
+            mask = ctypes.c_ulong(sum(1 << k for k in nodes))
+            rc = ctypes.CDLL(None, use_errno=True).syscall(238, 3, ctypes.byref(mask), max(nodes) + 2)   # MPOL_INTERLEAVE = 3
+            did["numa"] = "interleaved over nodes %s" % nodes if rc == 0 else "set_mempolicy failed (errno %d)" % ctypes.get_errno()
+        else:
+            did["numa"] = "one node"
+    except Exception as e:       # noqa: BLE001
+        did["numa"] = "not set: %r" % (e,)
+    return did
+
+
 def cpu_baseline(P, n, tol, cg_iters_per_step, bicg_solves_per_step=2, sample_iters=240):
     """The C oracle (a port of the reference's algorithms) on the host cores, bounded sample of the SAME 2048^2 workload:
     one matrix assembly, one BiCGStab(ILU0) solve (both single-threaded: sequential triangular sweeps) and `sample_iters`
     CG iterations on all cores (OpenMP) are timed; a step is priced as 2 assemblies + 2 BiCGStab solves + the CG iterations
     per fwd+adjoint step observed on the GPU."""
+    host = _stable_host_memory_for_the_cpu_baseline()
     from oracle import native as O, piso_ref as R
     s = R.OracleSetup(n, n, (2 * np.pi / n,) * 2, (True, True), np.zeros((1, n + 1, n + 1, 2), bool),
                       np.ones((1, n + 2, n + 2, 1), np.float32), np.ones((1, n + 2, n + 2, 1), np.float32),
@@ -429,7 +454,7 @@ def cpu_baseline(P, n, tol, cg_iters_per_step, bicg_solves_per_step=2, sample_it
     O.cg_solve_omp(n, n, True, True, L, div, 1e-30, sample_iters, True, 1000)
     t_cg_iter = (time.perf_counter() - t0) / sample_iters
     step_s = 2 * t_asm + bicg_solves_per_step * t_bicg + cg_iters_per_step * t_cg_iter
-    return dict(value=1.0 / step_s, unit="PISO steps/s (fwd+adjoint) at %d^2" % n, cores=threads, kind="port",
+    return dict(value=1.0 / step_s, unit="PISO steps/s (fwd+adjoint) at %d^2" % n, cores=threads, kind="port", host_memory=host,
                 sample=("C oracle at %d^2: %d CG iterations on %d OpenMP threads (%.4f s each; os.cpu_count() = %s) + 1 assembly "
                         "(%.2f s) + 1 BiCGStab-ILU0 solve (%.2f s, %s its), the last two on 1 thread; step priced as 2 assemblies + "
                         "%d BiCGStab solves + %d CG iterations (the count per fwd+adjoint step observed on the GPU)")
