@@ -154,3 +154,47 @@ def pressure_system(nx, ny, walls=False, seed=11):
     L = laplace_matrix_native(nx, ny, act, act, a0, torch.float64)
     b = torch.randn(nx * ny, generator=g, dtype=torch.float64).to(dev); b -= b.mean()
     return L, b
+
+
+# ------------------------------------------------------------------------------------------------ full-size configurations
+# (inputs of the full-size oracle fixtures, tests/golden/make_golden_configs.py, and of the GPU tests that load those fixtures)
+def tml_case():
+    """Config 3 inputs (also used by the GPU test): x periodic, y walls, tanh shear layer + perturbation."""
+    ny, nx = 256, 512
+    c = make_case("xper_ywall", ny, nx, seed=0, viscosity=1e-3)
+    yy = (np.arange(ny) + 0.5) / ny
+    c["vel"][0, :ny, :, 1] += np.tanh(2.0 * (yy - 0.5) * 8)[:, None].astype(f32)
+    c["vel"] = np.where(c["dirichlet_mask"], c["dirichlet_values"], c["vel"]).astype(f32)
+    return c
+
+
+def sml_case():
+    """Config 4 inputs (also used by the GPU test): spatially evolving mixing layer 1024x256 with the sponge viscosity field."""
+    from diffpiso.setups import sponge_viscosity_field
+    ny, nx = 256, 1024
+    c = make_case("spatial_ml", ny, nx, seed=0, viscosity=2e-3)
+    c["viscosity"] = sponge_viscosity_field((ny, nx), 2e-3, int(nx * 0.875), 2e-3 * 20)
+    return c
+
+
+CFG4_SIMPAR = dict(HRres=[256, 1024], sponge_ratio=0.875, dx_ratio=1)
+
+
+def sml_network(dp, torch):
+    """The closure of config 4 with seeded weights: VALID padding + restore_shape and zero buffer width
+    (spatial_mixing_layer_differentiable_training.py:46,49-50,55), damped so that the forcing stays a perturbation."""
+    net, weights, _ = dp.initialise_fullyconv_network([[0, 0], [0, 0]], padding="VALID", restore_shape=True, seed=1,
+                                                      initialiser="normal")      # (the draw the committed fixture was made with)
+    with torch.no_grad():
+        for w in net.weights:
+            w.mul_(0.6)
+    return net
+
+
+def sml_wrapper(F):
+    def neural_network_wrapper(neural_network, input, fluid, physical_parameters, simulation_parameters, loss_buffer_width, buffer_width):
+        # spatial_mixing_layer_differentiable_training.py:6-10: no closure inside the sponge layer
+        sponge_start = int(simulation_parameters["HRres"][1] * simulation_parameters["sponge_ratio"]) // simulation_parameters["dx_ratio"]
+        out = neural_network(input[:, :, :sponge_start, :])
+        return F.pad(out, (0, 0, 0, int(fluid.resolution[1]) - sponge_start))
+    return neural_network_wrapper

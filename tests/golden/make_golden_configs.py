@@ -33,7 +33,8 @@ sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 from oracle import piso_ref as R  # noqa: E402
-from tests.cases import make_case, oracle_setup  # noqa: E402
+from tests.cases import CFG4_SIMPAR, make_case, oracle_setup, sml_case, sml_network, sml_wrapper, tml_case  # noqa: E402,F401
+# (the case builders live in tests/cases.py, NOT here: the GPU tests rebuild their inputs without importing this generator)
 
 f32 = np.float32
 STRIDE = 8
@@ -47,16 +48,6 @@ def sub(a):
 
 def nrm(a):
     return float(np.linalg.norm(np.asarray(a, np.float64)))
-
-
-def tml_case():
-    """Config 3 inputs (also used by the GPU test): x periodic, y walls, tanh shear layer + perturbation."""
-    ny, nx = 256, 512
-    c = make_case("xper_ywall", ny, nx, seed=0, viscosity=1e-3)
-    yy = (np.arange(ny) + 0.5) / ny
-    c["vel"][0, :ny, :, 1] += np.tanh(2.0 * (yy - 0.5) * 8)[:, None].astype(f32)
-    c["vel"] = np.where(c["dirichlet_mask"], c["dirichlet_values"], c["vel"]).astype(f32)
-    return c
 
 
 CFG3_SOLVER = dict(lin_tol=1e-8, lin_max_it=300, lin_double=False, p_tol=1e-9, p_max_it=10000, p_reset=1000)
@@ -79,40 +70,8 @@ def make_cfg3():
     print("cfg3", meta)
 
 
-def sml_case():
-    """Config 4 inputs (also used by the GPU test): spatially evolving mixing layer 1024x256 with the sponge viscosity field."""
-    from diffpiso.setups import sponge_viscosity_field
-    ny, nx = 256, 1024
-    c = make_case("spatial_ml", ny, nx, seed=0, viscosity=2e-3)
-    c["viscosity"] = sponge_viscosity_field((ny, nx), 2e-3, int(nx * 0.875), 2e-3 * 20)
-    return c
-
-
 CFG4_SOLVER = dict(lin_tol=1e-8, lin_max_it=300, lin_double=False, p_tol=1e-9, p_max_it=40000, p_reset=1000)
 CFG4_STEPS = 16
-CFG4_SIMPAR = dict(HRres=[256, 1024], sponge_ratio=0.875, dx_ratio=1)
-
-
-def sml_network(dp, torch):
-    """The closure of config 4 with seeded weights: VALID padding + restore_shape and zero buffer width
-    (spatial_mixing_layer_differentiable_training.py:46,49-50,55), damped so that the forcing stays a perturbation."""
-    net, weights, _ = dp.initialise_fullyconv_network([[0, 0], [0, 0]], padding="VALID", restore_shape=True, seed=1,
-                                                      initialiser="normal")      # (the draw the committed fixture was made with)
-    with torch.no_grad():
-        for w in net.weights:
-            w.mul_(0.6)
-    return net
-
-
-def sml_wrapper(F):
-    def neural_network_wrapper(neural_network, input, fluid, physical_parameters, simulation_parameters, loss_buffer_width, buffer_width):
-        # spatial_mixing_layer_differentiable_training.py:6-10: no closure inside the sponge layer
-        sponge_start = int(simulation_parameters["HRres"][1] * simulation_parameters["sponge_ratio"]) // simulation_parameters["dx_ratio"]
-        out = neural_network(input[:, :, :sponge_start, :])
-        return F.pad(out, (0, 0, 0, int(fluid.resolution[1]) - sponge_start))
-    return neural_network_wrapper
-
-
 def make_cfg4():
     import torch
     import torch.nn.functional as F

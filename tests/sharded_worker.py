@@ -13,7 +13,6 @@ CASE:  fixture:bench1024_tight_step.npz      the benchmark's workload at 1024^2 
                                              cavity: solid lid row, no-slip mask), converged solves
        box:NX:NY:STEPS:TOL:MAXIT:SHIFT[:PERSIST]   decaying turbulence on an NX x NY periodic box (bench.py's builder); SHIFT 0: un-shifted CG;
                                              PERSIST 0: two-kernel CG iteration"""
-import importlib.util
 import json
 import os
 import sys
@@ -22,13 +21,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "differentiable-piso_amd"))
 HERE = os.path.dirname(os.path.abspath(__file__))
-
-
-def _gen():
-    spec = importlib.util.spec_from_file_location("make_golden_configs", os.path.join(HERE, "golden", "make_golden_configs.py"))
-    m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
-    return m
 
 
 def build_case(case, device):
@@ -52,7 +44,7 @@ def build_case(case, device):
                     nx=n, ny=n, p_tol_adjoint=sv.get("p_tol_adjoint"))
     if kind == "fixture":
         from tests.cases import product_setup
-        G = _gen()
+        from tests import cases as G                    # (the full-size case builders: tests/cases.py, not the fixture generator)
         d = np.load(os.path.join(HERE, "golden", rest))
         meta = json.loads(str(d["meta"]))
         c = G.tml_case()

@@ -2,8 +2,7 @@
 the CPU oracle offline; the GPU box only loads the .npz): config 3 (temporal mixing layer 512x256, 4 steps fwd + adjoint),
 config 4 (spatial mixing layer 1024x256 + CNN closure, 16-step unroll, weight gradients) and one forward + reverse step of the
 benchmark's own 2048^2 workload with the benchmark's settings.  Inputs are rebuilt from the same seeded builders and checked
-against the norms stored with the fixture."""
-import importlib.util
+against the norms stored with the fixture (the builders live in tests/cases.py; the fixture generator is not imported here)."""
 import json
 import os
 
@@ -11,18 +10,12 @@ import numpy as np
 import pytest
 import torch
 
+from tests import cases as C
 from tests.cases import product_setup
 from tests.test_gpu_step import rel
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-
-
-def _gen():
-    spec = importlib.util.spec_from_file_location("make_golden_configs", os.path.join(HERE, "golden", "make_golden_configs.py"))
-    m = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(m)
-    return m
 
 
 def _load(name):
@@ -64,9 +57,8 @@ def _check(tag, got, want_sub, want_norm, stride, tol, failures=None, scale_norm
 def test_config3_temporal_mixing_layer_512x256_four_steps_fwd_adjoint():
     """Advection solve in float32 (cast_to_double=False, the reference's setting), lin_tol 1e-8, pressure 1e-9."""
     import diffpiso as dp
-    G = _gen()
     d, meta = _load("cfg3_tml_512x256.npz")
-    c = G.tml_case()
+    c = C.tml_case()
     assert abs(np.linalg.norm(c["vel"].astype(np.float64)) - float(d["in_vel_norm"])) < 1e-6 * float(d["in_vel_norm"])
     P = product_setup(c, **meta["solver"])
     stride = int(d["stride"])
@@ -93,18 +85,17 @@ def test_config4_spatial_mixing_layer_1024x256_cnn_closure_16_step_unroll():
     import copy
     import torch.nn.functional as F
     import diffpiso as dp
-    G = _gen()
     d, meta = _load("cfg4_sml_1024x256_cnn.npz")
-    c = G.sml_case()
+    c = C.sml_case()
     assert abs(np.linalg.norm(c["vel"].astype(np.float64)) - float(d["in_vel_norm"])) < 1e-6 * float(d["in_vel_norm"])
     P = product_setup(c, **meta["solver"])
     stride, steps = int(d["stride"]), meta["steps"]
-    net = copy.deepcopy(G.sml_network(dp, torch)).cuda()
-    wrapper = G.sml_wrapper(F)
+    net = copy.deepcopy(C.sml_network(dp, torch)).cuda()
+    wrapper = C.sml_wrapper(F)
     vel_t = P["vel_tensor"].clone().requires_grad_(True)
     velocity = dp.StaggeredGrid(vel_t, P["velocity"].box, extrapolation=P["velocity"].extrapolation)
     visc = torch.tensor(c["viscosity"], device="cuda")
-    sim_par = dict(G.CFG4_SIMPAR, dt=c["dt"], dt_ratio=1)
+    sim_par = dict(C.CFG4_SIMPAR, dt=c["dt"], dt_ratio=1)
     td = dict(step_count=steps, loss_influence_range=steps + 1, pressure_included=True, HR_buffer_width=[[0, 0], [0, 0]])
     out = dp.run_piso_steps(velocity, P["pressure"], P["domain"], None, sim_par, td, net, wrapper, P["sim"], visc, None, None)
     vn, pn, warn = out[3], out[4], out[6]
