@@ -52,6 +52,13 @@ if g("SQ_WAVES") and g("SQ_INSTS_VALU"):
             print("%-18s per wave and iteration: %.1f" % (key, g(key) / w / ITERS))
 if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
     print("LDS bank-conflict cycles / LDS active cycles: %.4f" % (g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")))
+if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
+    print("L2 (TCC) hit rate: %.3f   (TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum); requests per iteration %.0f)" % (
+        g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), (g("TCC_HIT_sum") + g("TCC_MISS_sum")) / ITERS))
+if g("TCC_EA0_RDREQ_sum") and g("TCC_EA0_RDREQ_DRAM_sum") is not None:
+    # (TCC_EA0_RDREQ_DRAM counts requests ADDRESSED to device memory: the Infinity Cache sits in front of HBM and is not told apart)
+    print("L2 read requests to the fabric per iteration: %.0f, of which addressed to device memory %.3f" % (
+        g("TCC_EA0_RDREQ_sum") / ITERS, g("TCC_EA0_RDREQ_DRAM_sum") / g("TCC_EA0_RDREQ_sum")))
 if g("SQ_WAVE_CYCLES") and g("SQ_WAVES"):
     # quad-cycles per wave and iteration -> shader cycles per iteration (a wave lives for the whole launch)
     print("shader cycles per iteration (4 x SQ_WAVE_CYCLES / waves / iterations): %.0f" % (4 * g("SQ_WAVE_CYCLES") / g("SQ_WAVES") / ITERS))
@@ -72,6 +79,8 @@ if json_out and g("SQ_WAVE_CYCLES") and g("SQ_WAVES"):
                "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")},
            "valu_cycles_per_instruction": 4 * g("SQ_ACTIVE_INST_VALU") / g("SQ_INSTS_VALU") if g("SQ_INSTS_VALU") else None,
            "shader_cycles_per_iteration": 4 * wc / w / ITERS,
+           "l2_hit_rate": (g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))) if (g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0) else None,
+           "l2_read_requests_to_dram_share": (g("TCC_EA0_RDREQ_DRAM_sum") / g("TCC_EA0_RDREQ_sum")) if g("TCC_EA0_RDREQ_sum") else None,
            "lds_bank_conflict_share": (g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")) if g("SQ_LDS_IDX_ACTIVE") else None,
            "source": "scripts/profile_sq.sh: rocprofv3 --kernel-trace --pmc <one SQ group per pass> -- python3 scripts/bench_cg.py %d" % n,
            "units": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves; fractions are of a wave's life, "
